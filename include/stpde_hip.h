@@ -1,0 +1,140 @@
+/*
+ * stpde_hip.h -- C ABI of libstpde_hip.so: the MI355X (gfx950) device path behind the MeshfreeFlowNet
+ * operator API (PDELayer / query_local_implicit_grid / ImNet / regular_nd_grid_interpolation).
+ *
+ * The reference (maxjiang93/space_time_pde) is pure Python on PyTorch and has NO native interface; each
+ * entry point below states which reference code (file:line under /root/reference) it replaces.  The
+ * binding a maintainer adds is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch caching allocator);
+ *     the library never allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, nothing synchronises;
+ *   - return value: 0 = ok, otherwise one of STPDE_E_*; stpde_last_error() gives the text;
+ *   - all arithmetic is IEEE fp32 (no fast-math, no FMA contraction outside MFMA), indices int32.
+ *
+ * Fragment ("stash") layout used by the jet kernels.  Query points are grouped in tiles of 2 points =
+ * 16 corner rows (row j = 8*point_in_tile + corner, corner = 4*b0+2*b1+b2 as
+ * src/regular_nd_grid_interpolation.py:55-56).  A block of 16 rows x 16 features is stored as 64 lanes x 4
+ * floats (1 KiB): lane = 16*g + j holds features 4g..4g+3 of row j -- exactly the C/D register image of
+ * v_mfma_f32_16x16x4_f32 for out^T = W * in^T, which is also the B-operand image of the next layer, so
+ * layers chain without any re-layout.  A layer buffer is [tile][stream][feature_tile][64][4] floats.
+ * Streams: 0 = value, 1..3 = d/dr_k (if S1 == 3), then S2 second-order pairs (pair0[k], pair1[k]).
+ */
+#ifndef STPDE_HIP_H
+#define STPDE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STPDE_OK 0
+#define STPDE_E_BADARG 1      /* shape / size / enum out of the supported range -> ValueError */
+#define STPDE_E_UNSUPPORTED 2 /* stream configuration not compiled in            -> NotImplementedError */
+#define STPDE_E_LAUNCH 3      /* HIP launch failure                              -> RuntimeError */
+
+#define STPDE_ACT_TANH 0
+#define STPDE_ACT_RELU 1
+#define STPDE_ACT_SOFTPLUS 2
+#define STPDE_ACT_ELU 3
+#define STPDE_ACT_SWISH 4
+#define STPDE_ACT_LEAKYRELU 5
+
+#define STPDE_XT 3 /* the augmented raw input [r(3) ; latent(c) ; 1 ; 0-pad] occupies 3 feature tiles: c <= 44 */
+
+/* Derivative-stream configuration shared by the jet kernels. */
+typedef struct {
+  int S1;        /* 0 (value only) or 3 (value + d/dr_0..2)                         */
+  int S2;        /* number of second-order streams: 0, 2 or 6 compiled in           */
+  int pair0[6];  /* second-order stream k is d2/dr_pair0[k] dr_pair1[k]             */
+  int pair1[6];
+  int act;       /* STPDE_ACT_*  (src/nonlinearities.py:15-22)                       */
+  float act_param; /* swish beta; leaky-relu slope is fixed at 0.01 (torch default) */
+} stpde_jet_cfg;
+
+int stpde_version(void);
+int stpde_last_error(char* buf, unsigned long n);
+
+/* ---- a1/a2: clip, cell index, corner gather, weights, relative coords ------------------------------
+ * Replaces regular_nd_grid_interpolation_coefficients (src/regular_nd_grid_interpolation.py:14-78) +
+ * the torch.cat of local_implicit_grid.py:49 for dim = 3.  Writes the augmented input X
+ * [ntiles][3][64][4], per-point coefficients coef[P][16] = {omega[b][d] (6), domega[b][d] (6), kappa[d] (3), 0}
+ * and cell[P] = linear index of corner 0 in the latent grid.  lo_c/hi_c = xmin+eps / xmax-eps and
+ * cube = (xmax-xmin)/(size-1) are computed by the caller with the reference's own fp32 expressions
+ * (:48-51) so that floor(q/cube) is bit-identical (:52).  xmin must be 0 (quirk: :52 ignores xmin).
+ * P must be even; pts [P][3] (a chunk of the [B*N] point list starting at p_base); latent [B][n0][n1][n2][C]
+ * contiguous. */
+typedef struct {
+  int P, N, B, n0, n1, n2, C;
+  int p_base; /* global index of pts[0]: batch of point p is min((p_base + p) / N, B - 1) */
+  float lo_c[3], hi_c[3], cube[3];
+} stpde_gather_desc;
+int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X, float* coef,
+                     int* cell, void* stream);
+
+/* ---- a4/a5/a6/a7: one IM-NET layer on all derivative streams --------------------------------------
+ * Replaces the addmm + activation + cat of src/implicit_net.py:48-54 evaluated on the
+ * [b*p*2^d, d+c] matrix of src/local_implicit_grid.py:53, together with the torch.autograd.grad sweeps of
+ * src/pde.py:8-9 (forward-mode streams instead of reverse sweeps).
+ * out_pre[tile][S][MT] = W_h * act_jet(in_pre[tile][S][KT]) + W_s * X + tangent consts   (pre-activations)
+ * first_hidden != 0: the input is layer 0's output, regenerated on the fly from X (in_pre ignored). */
+typedef struct {
+  int ntiles, KT, MT, first_hidden;
+  stpde_jet_cfg cfg;
+} stpde_layer_desc;
+int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X, const float* Wh_pack,
+                        const float* Ws_pack, const float* tanc, const float* W0s_pack, const float* tanc0,
+                        float* out_pre, void* stream);
+
+/* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
+ * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
+ *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when
+ * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise. */
+int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
+                        const float* X, const float* W0s_pack, const float* tanc0, float* abar0, void* stream);
+
+/* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
+ * (columns: hidden inputs, then r(3), latent(c), bias, pad).  SP = streams present in abar_out (S, or 1+S1 for
+ * layer 0).  first_hidden as above.  Accumulates with fp32 atomics; caller zero-fills dW_aug. */
+int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* X,
+                    const float* W0s_pack, const float* tanc0, float* dW_aug, void* stream);
+
+/* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
+ * jets[(s*n_out + ch)*ldp + p] (ldp >= P lets a chunk of points write into a larger [S][n_out][Ptotal] array)
+ * from out_pre[tile][S][1][64][4] (fc5 output) and coef; and its adjoint. */
+int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* out_pre, const float* coef,
+                         float* jets, long ldp, void* stream);
+int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
+                         const float* coef, float* abar_out, void* stream);
+
+/* ---- backward of the gather: d latent (index_put accumulate, backward of :65-66) --------------------
+ * xbar = sum_l W_s,l^T * abar_l(value stream); latent channels are scatter-added into dlatent
+ * [B][n0][n1][n2][C] at the 8 corner nodes of each point.  nlayers <= 8. */
+typedef struct {
+  int ntiles, nlayers, C, n1, n2;
+  int MT[8];
+  int SP[8];
+} stpde_xbar_desc;
+/* abar / WsT_pack: HOST arrays of nlayers device pointers. */
+int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+                           const int* cell, float* dlatent, void* stream);
+
+/* ---- a2/a3 for any dim 1..4: plain multilinear interpolation ---------------------------------------
+ * Replaces regular_nd_grid_interpolation (src/regular_nd_grid_interpolation.py:81-104) and the three outputs
+ * of ..._coefficients (:14-78).  grid [B][n_0..n_{dim-1}][C], pts [B*N][dim].  Any output pointer may be NULL. */
+typedef struct {
+  int P, N, B, dim, C;
+  int n[4];
+  float lo_c[4], hi_c[4], cube[4];
+} stpde_interp_desc;
+int stpde_interp_fwd(const stpde_interp_desc* d, const float* grid, const float* pts, float* out /*[P][C]*/,
+                     float* corner_values /*[P][2^dim][C]*/, float* weights /*[P][2^dim]*/,
+                     float* x_relative /*[P][2^dim][dim]*/, void* stream);
+/* dgrid[node] += w_j * out_bar[p] (out_bar [P][C]) and/or corner_bar[p][j] ([P][2^dim][C]); either may be NULL. */
+int stpde_interp_bwd_grid(const stpde_interp_desc* d, const float* pts, const float* out_bar,
+                          const float* corner_bar, float* dgrid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,149 @@
+"""ctypes binding of libstpde_hip.so (C ABI declared in include/stpde_hip.h).
+
+The library is built in-tree by ``build_library()`` (``hipcc --offload-arch=gfx950``) and is the ONLY device
+path of this package: there is no CPU or eager fallback for the operators it implements, and loading fails
+loudly when the shared object is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
+_SOURCES = ["jet_layer.hip", "jet_wgrad.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "api.cpp"]
+_HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
+
+ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
+XT = 3
+
+
+class JetCfg(C.Structure):
+    _fields_ = [("S1", C.c_int), ("S2", C.c_int), ("pair0", C.c_int * 6), ("pair1", C.c_int * 6),
+                ("act", C.c_int), ("act_param", C.c_float)]
+
+
+class GatherDesc(C.Structure):
+    _fields_ = [("P", C.c_int), ("N", C.c_int), ("B", C.c_int), ("n0", C.c_int), ("n1", C.c_int), ("n2", C.c_int),
+                ("C", C.c_int), ("p_base", C.c_int), ("lo_c", C.c_float * 3), ("hi_c", C.c_float * 3),
+                ("cube", C.c_float * 3)]
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg)]
+
+
+class XbarDesc(C.Structure):
+    _fields_ = [("ntiles", C.c_int), ("nlayers", C.c_int), ("C", C.c_int), ("n1", C.c_int), ("n2", C.c_int),
+                ("MT", C.c_int * 8), ("SP", C.c_int * 8)]
+
+
+class InterpDesc(C.Structure):
+    _fields_ = [("P", C.c_int), ("N", C.c_int), ("B", C.c_int), ("dim", C.c_int), ("C", C.c_int),
+                ("n", C.c_int * 4), ("lo_c", C.c_float * 4), ("hi_c", C.c_float * 4), ("cube", C.c_float * 4)]
+
+
+def _sources():
+    return [os.path.join(_CSRC, s) for s in _SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into libstpde_hip.so (cross-compiles without a GPU)."""
+    srcs = _sources()
+    deps = srcs + [os.path.join(_CSRC, "common.h"), os.path.join(_HERE, "..", "include", "stpde_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in deps if os.path.exists(p))
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    objdir = os.path.join(_CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if (not force and os.path.exists(o)
+                and os.path.getmtime(o) >= max(os.path.getmtime(p) for p in [s] + deps[len(srcs):])):
+            continue
+        flags = _HIPFLAGS if s.endswith(".hip") else ["-O3", "-std=c++17", "-fPIC"]
+        cmd = ["hipcc"] + flags + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+_VP = C.c_void_p
+
+_SIGNATURES = {
+    "stpde_version": ([], C.c_int),
+    "stpde_last_error": ([C.c_char_p, C.c_ulong], C.c_int),
+    "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
+    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 9, C.c_int),
+    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 8, C.c_int),
+    "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 7, C.c_int),
+    "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
+    "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),
+    "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),
+    "stpde_interp_fwd": ([C.POINTER(InterpDesc)] + [_VP] * 7, C.c_int),
+    "stpde_interp_bwd_grid": ([C.POINTER(InterpDesc)] + [_VP] * 5, C.c_int),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def register_signatures(sigs):
+    """Let sibling modules (e.g. the conv3d binding) add their entry points before the first load."""
+    _SIGNATURES.update(sigs)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the shared object is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "libstpde_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "-- this package has no CPU/eager fallback for its HIP operators." % LIB_PATH)
+                h = C.CDLL(LIB_PATH)
+                for name, (argtypes, restype) in _SIGNATURES.items():
+                    fn = getattr(h, name)          # AttributeError if the symbol is missing
+                    fn.argtypes = argtypes
+                    fn.restype = restype
+                _lib = h
+    return _lib
+
+
+_EXC = {1: ValueError, 2: NotImplementedError, 3: RuntimeError}
+
+
+def check(rc):
+    if rc != 0:
+        buf = C.create_string_buffer(512)
+        lib().stpde_last_error(buf, 512)
+        raise _EXC.get(rc, RuntimeError)("libstpde_hip: " + buf.value.decode())
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,151 @@
+// Shared device helpers for libstpde_hip (gfx950 / CDNA4 only: wave64, v_mfma_f32_16x16x4_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/stpde_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define XT STPDE_XT
+
+// One v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[l&15][l>>4], B[l>>4][l&15],
+// D rows 4*(l>>4)+r (r = register), column l&15.  Exact fp32 (k-ordered fma chain).
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// sigma and its first three derivatives; conventions at kinks follow torch (relu'(0)=0, softplus threshold 20).
+struct ActD {
+  float s0, s1, s2, s3;
+};
+
+__device__ __forceinline__ ActD act_eval(int act, float prm, float a) {
+  ActD r;
+  switch (act) {
+    case STPDE_ACT_TANH: {
+      float t = tanhf(a);
+      float u = 1.f - t * t;
+      r.s0 = t;
+      r.s1 = u;
+      r.s2 = -2.f * t * u;
+      r.s3 = -2.f * u * (1.f - 3.f * t * t);
+    } break;
+    case STPDE_ACT_RELU: {
+      float m = a > 0.f ? 1.f : 0.f;
+      r.s0 = a * m;
+      r.s1 = m;
+      r.s2 = 0.f;
+      r.s3 = 0.f;
+    } break;
+    case STPDE_ACT_LEAKYRELU: {
+      float m = a > 0.f ? 1.f : 0.01f;
+      r.s0 = a * m;
+      r.s1 = m;
+      r.s2 = 0.f;
+      r.s3 = 0.f;
+    } break;
+    case STPDE_ACT_SOFTPLUS: {
+      if (a > 20.f) {
+        r.s0 = a;
+        r.s1 = 1.f;
+        r.s2 = 0.f;
+        r.s3 = 0.f;
+      } else {
+        float s = 1.f / (1.f + expf(-a));
+        float q = s * (1.f - s);
+        r.s0 = log1pf(expf(a));
+        r.s1 = s;
+        r.s2 = q;
+        r.s3 = q * (1.f - 2.f * s);
+      }
+    } break;
+    case STPDE_ACT_ELU: {
+      if (a > 0.f) {
+        r.s0 = a;
+        r.s1 = 1.f;
+        r.s2 = 0.f;
+        r.s3 = 0.f;
+      } else {
+        float e = expf(a);
+        r.s0 = expm1f(a);
+        r.s1 = e;
+        r.s2 = e;
+        r.s3 = e;
+      }
+    } break;
+    default: {  // STPDE_ACT_SWISH: x * sigmoid(beta x)
+      float ba = prm * a;
+      float s = 1.f / (1.f + expf(-ba));
+      float q = s * (1.f - s);
+      float c = 1.f - 2.f * s;
+      r.s0 = a * s;
+      r.s1 = s + ba * q;
+      r.s2 = prm * q * (2.f + ba * c);
+      r.s3 = prm * prm * q * (3.f * c + ba * (c * c - 2.f * q));
+    } break;
+  }
+  return r;
+}
+
+__device__ __forceinline__ float sel3(int d, float a0, float a1, float a2) { return d == 0 ? a0 : (d == 1 ? a1 : a2); }
+
+// Forward jet of the activation on one fragment block: pre[S] (a, adot_d, addot_p) -> h[S].
+template <int S1, int S2>
+__device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ActD s = act_eval(cfg.act, cfg.act_param, pre[0][r]);
+    h[0][r] = s.s0;
+    if (S1 == 3) {
+      float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
+      h[1][r] = s.s1 * a0;
+      h[2][r] = s.s1 * a1;
+      h[3][r] = s.s1 * a2;
+#pragma unroll
+      for (int p = 0; p < S2; ++p) {
+        float u = sel3(cfg.pair0[p], a0, a1, a2), v = sel3(cfg.pair1[p], a0, a1, a2);
+        h[4 + p][r] = s.s2 * u * v + s.s1 * pre[4 + p][r];
+      }
+    }
+  }
+}
+
+// Adjoint: given pre[S] and hbar[S], produce abar[S] (adjoint of the pre-activation streams).
+template <int S1, int S2>
+__device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
+                                            f32x4* abar) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ActD s = act_eval(cfg.act, cfg.act_param, pre[0][r]);
+    float ab = s.s1 * hbar[0][r];
+    if (S1 == 3) {
+      float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
+      float d0 = s.s1 * hbar[1][r], d1 = s.s1 * hbar[2][r], d2 = s.s1 * hbar[3][r];
+      ab += s.s2 * (a0 * hbar[1][r] + a1 * hbar[2][r] + a2 * hbar[3][r]);
+#pragma unroll
+      for (int p = 0; p < S2; ++p) {
+        int e0 = cfg.pair0[p], e1 = cfg.pair1[p];
+        float u = sel3(e0, a0, a1, a2), v = sel3(e1, a0, a1, a2);
+        float hb = hbar[4 + p][r];
+        ab += (s.s3 * u * v + s.s2 * pre[4 + p][r]) * hb;
+        float t0 = s.s2 * v * hb;  // d hdd / d adot_{e0}
+        float t1 = s.s2 * u * hb;  // d hdd / d adot_{e1}
+        d0 += (e0 == 0 ? t0 : 0.f) + (e1 == 0 ? t1 : 0.f);
+        d1 += (e0 == 1 ? t0 : 0.f) + (e1 == 1 ? t1 : 0.f);
+        d2 += (e0 == 2 ? t0 : 0.f) + (e1 == 2 ? t1 : 0.f);
+        abar[4 + p][r] = s.s1 * hb;
+      }
+      abar[1][r] = d0;
+      abar[2][r] = d1;
+      abar[3][r] = d2;
+    }
+    abar[0][r] = ab;
+  }
+}
+
+// Host-side helpers (api.cpp)
+void stpde_set_error(const char* fmt, ...);
+int stpde_check_launch(const char* what);

@@ -1,0 +1,385 @@
+// Local-implicit-grid glue kernels for dim = 3:
+//   k_gather      clip + cell index + corner gather + relative coords  -> augmented MLP input X (fragment layout)
+//                 and per-point interpolation coefficients               (src/regular_nd_grid_interpolation.py:48-76,
+//                                                                         src/local_implicit_grid.py:49)
+//   k_reduce_fwd  corner-weighted sum of the MLP output on every derivative stream (src/local_implicit_grid.py:59
+//                 and what the src/pde.py:8-9 sweeps differentiate through)
+//   k_reduce_bwd  its adjoint
+//   k_xbar        d latent: xbar = sum_l W_s,l^T abar_l, scatter-added at the 8 corner nodes (backward of the
+//                 advanced-index gather at src/regular_nd_grid_interpolation.py:65-66)
+// All of these are HBM/L2-bound byte movers; no MFMA except the small xbar GEMM.
+#include "common.h"
+
+struct PointGeom {
+  float om[2][3];   // omega[b][d] = |q_d - pos_opposite| / cube_d
+  float dom[2][3];  // d omega / d q_d (sign * s_d / cube_d)
+  float rel[2][3];  // (q_d - pos) / cube_d
+  float kap[3];     // s_d / cube_d
+  int i0[3];
+};
+
+// Same fp32 expression sequence as the reference (division, no reciprocal, no contraction).
+__device__ __forceinline__ PointGeom point_geom(const float* p, const float* lo_c, const float* hi_c,
+                                                const float* cube, const int* n) {
+  PointGeom gm;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float x = p[d];
+    const float m = fminf(x, hi_c[d]);
+    const float q = fmaxf(m, lo_c[d]);
+    // derivative of the clip: min/max backward split ties evenly (quirk a-Q2)
+    const float s = (x < hi_c[d] ? 1.f : (x == hi_c[d] ? 0.5f : 0.f)) * (m > lo_c[d] ? 1.f : (m == lo_c[d] ? 0.5f : 0.f));
+    const float cs = cube[d];
+    const float fl = floorf(q / cs);
+    int i0 = (int)fl;
+    i0 = i0 < 0 ? 0 : (i0 > n[d] - 2 ? n[d] - 2 : i0);  // only NaN / out-of-box inputs ever hit the clamp
+    const float i0f = (float)i0;
+    const float p0 = i0f * cs;
+    const float p1 = (i0f + 1.f) * cs;
+    gm.i0[d] = i0;
+    gm.kap[d] = s / cs;
+    // bit 0: pos = p0, opposite = p1 ; bit 1: pos = p1, opposite = p0
+    const float t0 = q - p1, t1 = q - p0;
+    gm.om[0][d] = fabsf(t0) / cs;
+    gm.om[1][d] = fabsf(t1) / cs;
+    gm.dom[0][d] = (t0 > 0.f ? 1.f : (t0 < 0.f ? -1.f : 0.f)) / cs * s;
+    gm.dom[1][d] = (t1 > 0.f ? 1.f : (t1 < 0.f ? -1.f : 0.f)) / cs * s;
+    gm.rel[0][d] = (q - p0) / cs;
+    gm.rel[1][d] = (q - p1) / cs;
+  }
+  return gm;
+}
+
+struct GatherArgs {
+  stpde_gather_desc d;
+  const float* pts;
+  const float* latent;
+  float* X;
+  float* coef;
+  int* cell;
+};
+
+// one thread per (tile, xt, lane): writes one float4 of X
+__global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int ntiles = a.d.P / 2;
+  if (gid >= (size_t)ntiles * XT * 64) return;
+  const int lane = gid & 63;
+  const int xt = (gid >> 6) % XT;
+  const int tile = (gid >> 6) / XT;
+  const int g = lane >> 4, j = lane & 15;
+  const int p = tile * 2 + (j >> 3);
+  const int corner = j & 7;
+  const int bit[3] = {(corner >> 2) & 1, (corner >> 1) & 1, corner & 1};
+  const int n[3] = {a.d.n0, a.d.n1, a.d.n2};
+  float pt[3] = {a.pts[(size_t)p * 3], a.pts[(size_t)p * 3 + 1], a.pts[(size_t)p * 3 + 2]};
+  PointGeom gm = point_geom(pt, a.d.lo_c, a.d.hi_c, a.d.cube, n);
+  int b = (a.d.p_base + p) / a.d.N;
+  b = b > a.d.B - 1 ? a.d.B - 1 : b;
+  const size_t node0 = (((size_t)b * n[0] + gm.i0[0]) * n[1] + gm.i0[1]) * n[2] + gm.i0[2];
+  const size_t node = node0 + ((size_t)bit[0] * n[1] + bit[1]) * n[2] + bit[2];
+  const int C = a.d.C;
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * xt + 4 * g + r;
+    float val = 0.f;
+    if (f < 3) {
+      const float r0 = bit[0] ? gm.rel[1][0] : gm.rel[0][0];
+      const float r1 = bit[1] ? gm.rel[1][1] : gm.rel[0][1];
+      const float r2 = bit[2] ? gm.rel[1][2] : gm.rel[0][2];
+      val = sel3(f, r0, r1, r2);
+    } else if (f < 3 + C)
+      val = a.latent[node * C + (f - 3)];
+    else if (f == 3 + C)
+      val = 1.f;  // bias column
+    v[r] = val;
+  }
+  st4(a.X + gid * 4, v);
+  if (xt == 0 && g == 0 && corner == 0) {
+    float* cf = a.coef + (size_t)p * 16;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      cf[d] = gm.om[0][d];
+      cf[3 + d] = gm.om[1][d];
+      cf[6 + d] = gm.dom[0][d];
+      cf[9 + d] = gm.dom[1][d];
+      cf[12 + d] = gm.kap[d];
+    }
+    cf[15] = 0.f;
+    a.cell[p] = (int)node0;
+  }
+}
+
+extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X,
+                                float* coef, int* cell, void* stream) {
+  if (!d || d->P <= 0 || (d->P & 1) || d->N <= 0 || d->p_base < 0 || d->B <= 0 || d->n0 < 2 || d->n1 < 2 || d->n2 < 2 || d->C < 1 ||
+      3 + d->C + 1 > 16 * XT || !pts || !latent || !X || !coef || !cell) {
+    stpde_set_error("lig_gather: bad argument (P even, grid >= 2 per dim, C <= %d)", 16 * XT - 4);
+    return STPDE_E_BADARG;
+  }
+  if ((size_t)d->B * d->n0 * d->n1 * d->n2 >= (1u << 31)) {
+    stpde_set_error("lig_gather: latent grid too large for int32 node index");
+    return STPDE_E_BADARG;
+  }
+  GatherArgs a{*d, pts, latent, X, coef, cell};
+  const size_t nthreads = (size_t)(d->P / 2) * XT * 64;
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_gather");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// corner reduction
+// ---------------------------------------------------------------------------------------------------------
+struct CornerW {
+  float w, dw[3], ddw[3];  // ddw index: pair (0,1)->0, (0,2)->1, (1,2)->2
+};
+
+__device__ __forceinline__ CornerW corner_weights(const float* cf, int corner) {
+  const int bit[3] = {(corner >> 2) & 1, (corner >> 1) & 1, corner & 1};
+  float om[3], dm[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    om[d] = bit[d] ? cf[3 + d] : cf[d];
+    dm[d] = bit[d] ? cf[9 + d] : cf[6 + d];
+  }
+  CornerW c;
+  c.w = om[0] * om[1] * om[2];
+  c.dw[0] = dm[0] * om[1] * om[2];
+  c.dw[1] = om[0] * dm[1] * om[2];
+  c.dw[2] = om[0] * om[1] * dm[2];
+  c.ddw[0] = dm[0] * dm[1] * om[2];
+  c.ddw[1] = dm[0] * om[1] * dm[2];
+  c.ddw[2] = om[0] * dm[1] * dm[2];
+  return c;
+}
+
+__device__ __forceinline__ float pair_ddw(const CornerW& c, int d, int e) {
+  if (d == e) return 0.f;
+  const int s = d + e;  // 1 -> (0,1), 2 -> (0,2), 3 -> (1,2)
+  return s == 1 ? c.ddw[0] : (s == 2 ? c.ddw[1] : c.ddw[2]);
+}
+
+struct ReduceArgs {
+  stpde_jet_cfg cfg;
+  int P, n_out;
+  long ldp;
+  const float* src;  // fwd: out_pre [tile][S][1][256]; bwd: jets_bar [S][n_out][P]
+  const float* coef;
+  float* dst;  // fwd: jets [S][n_out][P]; bwd: abar_out [tile][S][1][256]
+};
+
+// one thread per (point, channel)
+__global__ __launch_bounds__(256) void k_reduce_fwd(ReduceArgs a) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)a.P * a.n_out) return;
+  const int p = gid / a.n_out, ch = gid % a.n_out;
+  const int S1 = a.cfg.S1, S2 = a.cfg.S2, S = 1 + S1 + S2;
+  float cf[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 v = ld4(a.coef + (size_t)p * 16 + 4 * i);
+    cf[4 * i] = v[0];
+    cf[4 * i + 1] = v[1];
+    cf[4 * i + 2] = v[2];
+    cf[4 * i + 3] = v[3];
+  }
+  const float* kap = cf + 12;
+  float y[10];
+#pragma unroll
+  for (int s = 0; s < 10; ++s) y[s] = 0.f;
+  const int tile = p >> 1;
+  for (int corner = 0; corner < 8; ++corner) {
+    const int j = ((p & 1) << 3) | corner;
+    const int lane = ((ch >> 2) << 4) | j;
+    const float* base = a.src + (size_t)tile * S * 256 + lane * 4 + (ch & 3);
+    float f[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) f[s] = s < S ? base[(size_t)s * 256] : 0.f;
+    CornerW c = corner_weights(cf, corner);
+    y[0] += c.w * f[0];
+    if (S1 == 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) y[1 + d] += c.dw[d] * f[0] + c.w * kap[d] * f[1 + d];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (k < S2) {
+          const int d = a.cfg.pair0[k], e = a.cfg.pair1[k];
+          const float kd = sel3(d, kap[0], kap[1], kap[2]), ke = sel3(e, kap[0], kap[1], kap[2]);
+          const float dwd = sel3(d, c.dw[0], c.dw[1], c.dw[2]), dwe = sel3(e, c.dw[0], c.dw[1], c.dw[2]);
+          const float fd = sel3(d, f[1], f[2], f[3]), fe = sel3(e, f[1], f[2], f[3]);
+          y[4 + k] += pair_ddw(c, d, e) * f[0] + dwd * ke * fe + dwe * kd * fd + c.w * kd * ke * f[4 + k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 10; ++s)
+    if (s < S) a.dst[((size_t)s * a.n_out + ch) * a.ldp + p] = y[s];
+}
+
+// one thread per (point, corner, feature 0..15): writes the S stream values of abar_out (zeros for ch >= n_out)
+__global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)a.P * 128) return;
+  const int ch = gid & 15, corner = (gid >> 4) & 7, p = gid >> 7;
+  const int S1 = a.cfg.S1, S2 = a.cfg.S2, S = 1 + S1 + S2;
+  const int tile = p >> 1;
+  const int j = ((p & 1) << 3) | corner;
+  const int lane = ((ch >> 2) << 4) | j;
+  float* base = a.dst + (size_t)tile * S * 256 + lane * 4 + (ch & 3);
+  float fb[10];
+#pragma unroll
+  for (int s = 0; s < 10; ++s) fb[s] = 0.f;
+  if (ch < a.n_out) {
+    float cf[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = ld4(a.coef + (size_t)p * 16 + 4 * i);
+      cf[4 * i] = v[0];
+      cf[4 * i + 1] = v[1];
+      cf[4 * i + 2] = v[2];
+      cf[4 * i + 3] = v[3];
+    }
+    const float* kap = cf + 12;
+    float yb[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) yb[s] = s < S ? a.src[((size_t)s * a.n_out + ch) * a.ldp + p] : 0.f;
+    CornerW c = corner_weights(cf, corner);
+    fb[0] = c.w * yb[0];
+    if (S1 == 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        fb[0] += c.dw[d] * yb[1 + d];
+        fb[1 + d] = c.w * kap[d] * yb[1 + d];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (k < S2) {
+          const int d = a.cfg.pair0[k], e = a.cfg.pair1[k];
+          const float kd = sel3(d, kap[0], kap[1], kap[2]), ke = sel3(e, kap[0], kap[1], kap[2]);
+          const float dwd = sel3(d, c.dw[0], c.dw[1], c.dw[2]), dwe = sel3(e, c.dw[0], c.dw[1], c.dw[2]);
+          const float g = yb[4 + k];
+          fb[0] += pair_ddw(c, d, e) * g;
+          const float te = dwd * ke * g;  // -> f_{1+e}
+          const float td = dwe * kd * g;  // -> f_{1+d}
+          fb[1] += (e == 0 ? te : 0.f) + (d == 0 ? td : 0.f);
+          fb[2] += (e == 1 ? te : 0.f) + (d == 1 ? td : 0.f);
+          fb[3] += (e == 2 ? te : 0.f) + (d == 2 ? td : 0.f);
+          fb[4 + k] = c.w * kd * ke * g;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 10; ++s)
+    if (s < S) base[(size_t)s * 256] = fb[s];
+}
+
+static int check_reduce(const stpde_jet_cfg* cfg, int P, int n_out, const void* a, const void* b, const void* c) {
+  if (!cfg || P <= 0 || (P & 1) || n_out < 1 || n_out > 16 || !a || !b || !c || (cfg->S1 != 0 && cfg->S1 != 3) ||
+      cfg->S2 < 0 || cfg->S2 > 6 || (cfg->S1 == 0 && cfg->S2 != 0)) {
+    stpde_set_error("lig_reduce: bad argument");
+    return STPDE_E_BADARG;
+  }
+  return STPDE_OK;
+}
+
+extern "C" int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* out_pre,
+                                    const float* coef, float* jets, long ldp, void* stream) {
+  int rc = check_reduce(cfg, P, n_out, out_pre, coef, jets);
+  if (rc) return rc;
+  if (ldp < P) {
+    stpde_set_error("lig_reduce_fwd: ldp < P");
+    return STPDE_E_BADARG;
+  }
+  ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets};
+  const size_t n = (size_t)P * n_out;
+  hipLaunchKernelGGL(k_reduce_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_reduce_fwd");
+}
+
+extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
+                                    const float* coef, float* abar_out, void* stream) {
+  int rc = check_reduce(cfg, P, n_out, jets_bar, coef, abar_out);
+  if (rc) return rc;
+  if (ldp < P) {
+    stpde_set_error("lig_reduce_bwd: ldp < P");
+    return STPDE_E_BADARG;
+  }
+  ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out};
+  const size_t n = (size_t)P * 128;
+  hipLaunchKernelGGL(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_reduce_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// xbar = sum_l W_s,l^T abar_l (value stream)  ->  scatter-add into d latent
+// ---------------------------------------------------------------------------------------------------------
+struct XbarArgs {
+  stpde_xbar_desc d;
+  const float* abar[8];
+  const float* wst[8];  // [MT_l][XT][256]
+  const int* cell;
+  float* dlatent;
+};
+
+__global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.d.ntiles) return;
+  const int lo = lane * 4;
+  f32x4 acc[XT];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) acc[xt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < a.d.nlayers; ++l) {
+    const int MT = a.d.MT[l], SP = a.d.SP[l];
+    const float* ab = a.abar[l] + (size_t)tile * SP * MT * 256 + lo;  // stream 0
+    const float* w = a.wst[l] + lo;
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 B = ld4(ab + (size_t)mt * 256);
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+        f32x4 wv = ld4(w + ((size_t)mt * XT + xt) * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[xt] = mfma4(wv[r], B[r], acc[xt]);
+      }
+    }
+  }
+  const int g = lane >> 4, j = lane & 15;
+  const int p = tile * 2 + (j >> 3), corner = j & 7;
+  const int n1 = a.d.n1, n2 = a.d.n2, C = a.d.C;
+  const size_t node =
+      (size_t)a.cell[p] + ((size_t)((corner >> 2) & 1) * n1 + ((corner >> 1) & 1)) * n2 + (corner & 1);
+  float* dst = a.dlatent + node * C;
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * xt + 4 * g + r;
+      if (f >= 3 && f < 3 + C) atomicAdd(dst + (f - 3), acc[xt][r]);
+    }
+}
+
+extern "C" int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar,
+                                      const float* const* WsT_pack, const int* cell, float* dlatent, void* stream) {
+  if (!d || d->ntiles <= 0 || d->nlayers < 1 || d->nlayers > 8 || d->C < 1 || 3 + d->C + 1 > 16 * XT || !abar ||
+      !WsT_pack || !cell || !dlatent) {
+    stpde_set_error("lig_xbar_scatter: bad argument");
+    return STPDE_E_BADARG;
+  }
+  XbarArgs a{};
+  a.d = *d;
+  for (int l = 0; l < d->nlayers; ++l) {
+    if (!abar[l] || !WsT_pack[l] || d->MT[l] < 1 || d->SP[l] < 1) {
+      stpde_set_error("lig_xbar_scatter: bad layer %d", l);
+      return STPDE_E_BADARG;
+    }
+    a.abar[l] = abar[l];
+    a.wst[l] = WsT_pack[l];
+  }
+  a.cell = cell;
+  a.dlatent = dlatent;
+  hipLaunchKernelGGL(k_xbar, dim3((d->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_xbar");
+}

@@ -1,0 +1,432 @@
+"""Host driver of the fused LIG + IM-NET jet path (dim = 3) on libstpde_hip.
+
+Computes y = query_local_implicit_grid(imnet, latent, pts) together with its first and selected second
+derivatives w.r.t. the query coordinates ("jets") in one forward pass of HIP kernels, and the gradients w.r.t.
+the IM-NET parameters and the latent grid in one backward pass.  This replaces, for the hot path,
+  * src/local_implicit_grid.py:47-59 + src/regular_nd_grid_interpolation.py:48-76 (gather, weights, rel coords),
+  * src/implicit_net.py:48-54 (6 addmm + activations + concats on the [b*p*8, 35] matrix),
+  * the 23-25 ``torch.autograd.grad(create_graph=True)`` sweeps of src/pde.py:8-9 and their double backward.
+
+Everything here is plumbing (buffer allocation, weight packing by index gather, launch order); all arithmetic on
+query points runs in the HIP library.  There is no fallback: tensors must be CUDA/HIP float32.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import XT, GatherDesc, JetCfg, LayerDesc, XbarDesc, check, ptr, stream_ptr
+
+_FRAG = 256  # floats per 16x16 fragment block
+
+
+# ------------------------------------------------------------------------------------------------------------
+# architecture plan: index maps between nn.Linear parameters and MFMA operand packs
+# ------------------------------------------------------------------------------------------------------------
+class ImNetPlan:
+    """Static layout information for one IM-NET architecture (src/implicit_net.py:31-36)."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, dim, in_features, out_features, nf):
+        key = (dim, in_features, out_features, nf)
+        if key not in cls._cache:
+            cls._cache[key] = cls(*key)
+        return cls._cache[key]
+
+    def __init__(self, dim, in_features, out_features, nf):
+        if dim != 3:
+            raise ValueError("the HIP jet path is built for dim=3 query points")
+        if nf % 16 != 0:
+            raise ValueError("the HIP jet path needs nf to be a multiple of 16 (hidden widths are MFMA tiles)")
+        self.dz = dim + in_features
+        if self.dz + 1 > 16 * XT:
+            raise ValueError("in_features too large for the 3-tile augmented input (max 44)")
+        if out_features > 16:
+            raise ValueError("out_features > 16 not supported by the HIP jet path")
+        self.dim, self.cin, self.cout, self.nf = dim, in_features, out_features, nf
+        widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf, out_features]
+        self.layers = []
+        theta_off = 0
+        for l in range(6):
+            kh = 0 if l == 0 else widths[l - 1]
+            skip = l < 5
+            kin = kh + (self.dz if skip else 0)
+            m = widths[l]
+            lay = dict(M=m, Kh=kh, KT=kh // 16, MT=(m + 15) // 16, skip=skip, Kin=kin, w_off=theta_off,
+                       b_off=theta_off + m * kin)
+            theta_off += m * kin + m
+            self.layers.append(lay)
+        self.n_theta = theta_off
+        self._build_indices()
+        self._dev = {}
+
+    def _build_indices(self):
+        zero = self.n_theta  # index of the appended 0.0
+        lane = np.arange(64)
+        g, j = lane >> 4, lane & 15
+        r = np.arange(4)
+        pack_chunks, unpack = [], np.zeros(self.n_theta, dtype=np.int64)
+        self.pack_off = []
+        self.dw_off = []
+        pk, dwo = 0, 0
+        for lay in self.layers:
+            M, Kh, KT, MT, Kin = lay["M"], lay["Kh"], lay["KT"], lay["MT"], lay["Kin"]
+            Mp, Ka = 16 * MT, 16 * (KT + XT)
+            aug = np.full((Mp, Ka), zero, dtype=np.int64)
+            rows = np.arange(M)[:, None]
+            if Kh:
+                aug[:M, :Kh] = lay["w_off"] + rows * Kin + np.arange(Kh)[None, :]
+            if lay["skip"]:
+                aug[:M, 16 * KT:16 * KT + self.dz] = lay["w_off"] + rows * Kin + Kh + np.arange(self.dz)[None, :]
+            aug[:M, 16 * KT + self.dz] = lay["b_off"] + np.arange(M)
+            # unpack map: theta element -> position in the flat dW_aug buffer
+            if Kh:
+                unpack[lay["w_off"] + rows * Kin + np.arange(Kh)[None, :]] = dwo + rows * Ka + np.arange(Kh)[None, :]
+            if lay["skip"]:
+                unpack[lay["w_off"] + rows * Kin + Kh + np.arange(self.dz)[None, :]] = \
+                    dwo + rows * Ka + 16 * KT + np.arange(self.dz)[None, :]
+            unpack[lay["b_off"] + np.arange(M)] = dwo + np.arange(M) * Ka + 16 * KT + self.dz
+            offs = {}
+
+            def add(name, arr):
+                nonlocal pk
+                offs[name] = (pk, arr.size)
+                pack_chunks.append(arr.reshape(-1))
+                pk += arr.size
+
+            mt = np.arange(MT)
+            # A operand of W_h: [KT][MT][lane][r] = aug[16mt + j, 16kt + 4g + r]
+            if KT:
+                kt = np.arange(KT)
+                add("Wh", aug[(16 * mt[None, :, None, None] + j[None, None, :, None]),
+                              (16 * kt[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :])])
+                # A operand of W_h^T: [MT][KT][lane][r] = aug[16mt + 4g + r, 16kt + j]
+                add("WhT", aug[(16 * mt[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
+                               (16 * kt[None, :, None, None] + j[None, None, :, None])])
+            xt = np.arange(XT)
+            add("Ws", aug[(16 * mt[None, :, None, None] + j[None, None, :, None]),
+                          (16 * (KT + xt)[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :])])
+            add("WsT", aug[(16 * mt[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
+                           (16 * (KT + xt)[None, :, None, None] + j[None, None, :, None])])
+            d = np.arange(3)
+            add("tanc", aug[(16 * mt[None, :, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
+                            (16 * KT + d)[:, None, None, None] + 0 * mt[None, :, None, None]])
+            self.pack_off.append(offs)
+            self.dw_off.append((dwo, Mp, Ka))
+            dwo += Mp * Ka
+        self.pack_index_np = np.concatenate(pack_chunks)
+        self.unpack_index_np = unpack
+        self.n_pack = pk
+        self.n_dw = dwo
+
+    def device_indices(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.pack_index_np).to(device),
+                              torch.from_numpy(self.unpack_index_np).to(device))
+        return self._dev[key]
+
+    def pack(self, params):
+        """params: 12 tensors (w0, b0, ..., w5, b5) -> flat pack buffer (one index gather)."""
+        dev = params[0].device
+        pidx, _ = self.device_indices(dev)
+        theta = torch.cat([p.detach().reshape(-1).float() for p in params] + [torch.zeros(1, device=dev)])
+        return theta[pidx]
+
+    def pack_view(self, packs, l, name):
+        off, n = self.pack_off[l][name]
+        return packs[off:off + n]
+
+    def unpack_grads(self, dw_flat, params):
+        _, uidx = self.device_indices(dw_flat.device)
+        gtheta = dw_flat[uidx]
+        out, o = [], 0
+        for p in params:
+            n = p.numel()
+            out.append(gtheta[o:o + n].view_as(p))
+            o += n
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# stream configuration
+# ------------------------------------------------------------------------------------------------------------
+def make_cfg(act, act_param, first, pairs):
+    """Map a derivative request onto a compiled stream configuration; returns (JetCfg, S, padded_pairs)."""
+    pairs = [tuple(sorted(p)) for p in pairs]
+    if pairs and not first:
+        first = True
+    if not first:
+        s1, s2, pp = 0, 0, []
+    elif not pairs:
+        s1, s2, pp = 3, 0, []
+    elif len(pairs) <= 2:
+        s1, s2, pp = 3, 2, pairs + [pairs[-1]] * (2 - len(pairs))
+    elif len(pairs) <= 6:
+        s1, s2, pp = 3, 6, pairs + [pairs[-1]] * (6 - len(pairs))
+    else:
+        raise NotImplementedError("more than 6 second-order derivative pairs")
+    cfg = JetCfg()
+    cfg.S1, cfg.S2 = s1, s2
+    for k, (a, b) in enumerate(pp):
+        cfg.pair0[k], cfg.pair1[k] = a, b
+    cfg.act = _lib.ACT_CODES[act]
+    cfg.act_param = float(act_param)
+    return cfg, 1 + s1 + s2, pp
+
+
+def box_constants(shape3, xmin, xmax):
+    """lo_c, hi_c, cube with the reference's own fp32 expression sequence
+    (src/regular_nd_grid_interpolation.py:40-51), evaluated on the host."""
+    dim = len(shape3)
+
+    def as_vec(v):
+        if isinstance(v, (int, float)):
+            return float(v) * torch.ones([dim], dtype=torch.float32)
+        if torch.is_tensor(v):
+            return v.detach().to("cpu", torch.float32).reshape(-1)
+        return torch.tensor(np.asarray(v)).to(torch.float32).reshape(-1)
+
+    lo, hi = as_vec(xmin), as_vec(xmax)
+    if lo.numel() != dim or hi.numel() != dim:
+        raise ValueError("xmin/xmax must have one entry per grid dimension")
+    if bool((lo != 0).any()):
+        # quirk a-Q1: the reference computes ind0 = floor(q / cubesize) with no xmin offset, so xmin != 0
+        # silently mis-indexes there; the HIP path refuses instead of reproducing or "fixing" it.
+        raise ValueError("xmin must be 0 (the reference's cell index ignores xmin)")
+    size = torch.tensor(list(shape3)).float()
+    eps = 1e-6 * (hi - lo)
+    cube = (hi - lo) / (size - 1)
+    return (lo + eps).tolist(), (hi - eps).tolist(), cube.tolist()
+
+
+_box_cache = {}
+_box_lock = threading.Lock()
+
+
+def cached_box_constants(shape3, xmin, xmax):
+    """Avoid a device sync per call when xmin/xmax are device tensors that do not change."""
+    if torch.is_tensor(xmin) or torch.is_tensor(xmax):
+        key = (tuple(shape3), id(xmin), id(xmax), getattr(xmin, "_version", 0), getattr(xmax, "_version", 0))
+    else:
+        key = (tuple(shape3), repr(xmin), repr(xmax))
+    with _box_lock:
+        if key not in _box_cache:
+            if len(_box_cache) > 64:
+                _box_cache.clear()
+            _box_cache[key] = box_constants(shape3, xmin, xmax)
+        return _box_cache[key]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the autograd function
+# ------------------------------------------------------------------------------------------------------------
+class _Meta:
+    pass
+
+
+def _layer_desc(ntiles, lay, cfg, first_hidden):
+    d = LayerDesc()
+    d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg = ntiles, lay["KT"], lay["MT"], int(first_hidden), cfg
+    return d
+
+
+def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
+    """Run gather + layers 1..5 + reduce for points [p0, p0+Pc) ; returns the buffers backward needs."""
+    plan, cfg, S = meta.plan, meta.cfg, meta.S
+    L = _lib.lib()
+    st = stream_ptr()
+    Pc = pts_c.shape[0]
+    nt = Pc // 2
+    dev = pts_c.device
+    X = torch.empty(nt * XT * _FRAG, device=dev)
+    coef = torch.empty(Pc * 16, device=dev)
+    cell = torch.empty(Pc, device=dev, dtype=torch.int32)
+    gd = GatherDesc()
+    gd.P, gd.N, gd.B = Pc, meta.N, meta.B
+    gd.n0, gd.n1, gd.n2, gd.C = latent.shape[1], latent.shape[2], latent.shape[3], latent.shape[4]
+    for k in range(3):
+        gd.lo_c[k], gd.hi_c[k], gd.cube[k] = meta.lo_c[k], meta.hi_c[k], meta.cube[k]
+    gd.p_base = p0
+    check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(coef), ptr(cell), st))
+    bufs = [None]
+    pv = plan.pack_view
+    prev = None
+    for l in range(1, 6):
+        lay = plan.layers[l]
+        out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
+        d = _layer_desc(nt, lay, cfg, l == 1)
+        check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")), ptr(pv(packs, l, "Ws")),
+                                    ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tanc")),
+                                    ptr(out), st))
+        bufs.append(out)
+        prev = out
+    check(L.stpde_lig_reduce_fwd(C.byref(cfg), Pc, plan.cout, ptr(bufs[5]), ptr(coef),
+                                 C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
+    return dict(X=X, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc)
+
+
+def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
+    plan, cfg, S = meta.plan, meta.cfg, meta.S
+    L = _lib.lib()
+    st = stream_ptr()
+    Pc, p0 = saved["Pc"], saved["p0"]
+    nt = Pc // 2
+    X, coef, cell, bufs = saved["X"], saved["coef"], saved["cell"], saved["bufs"]
+    dev = X.device
+    pv = plan.pack_view
+    # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer)
+    check(L.stpde_lig_reduce_bwd(C.byref(cfg), Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
+                                 jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
+    SP0 = 1 + cfg.S1
+    abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
+    for l in range(5, 0, -1):
+        lay = plan.layers[l]
+        d = _layer_desc(nt, lay, cfg, l == 1)
+        off, mp, ka = plan.dw_off[l]
+        if meta.need_wgrad:
+            check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
+                                    ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tanc")),
+                                    ptr(dw_flat[off:off + mp * ka]), st))
+        check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
+                                    ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
+                                    ptr(pv(packs, 0, "tanc")), ptr(abar0), st))
+    if meta.need_wgrad:
+        lay = plan.layers[0]
+        d = _layer_desc(nt, lay, cfg, False)
+        off, mp, ka = plan.dw_off[0]
+        check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), None, None,
+                                ptr(dw_flat[off:off + mp * ka]), st))
+    if dlatent is not None:
+        xd = XbarDesc()
+        xd.ntiles, xd.nlayers, xd.C = nt, 5, plan.cin
+        xd.n1, xd.n2 = meta.grid_shape[1], meta.grid_shape[2]
+        ab = (C.c_void_p * 5)()
+        wt = (C.c_void_p * 5)()
+        for l in range(5):
+            xd.MT[l] = plan.layers[l]["MT"]
+            xd.SP[l] = SP0 if l == 0 else S
+            ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
+            wt[l] = pv(packs, l, "WsT").data_ptr()
+        check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
+
+
+class LigJetFunction(torch.autograd.Function):
+    """jets[S, n_out, P] of the LIG+IM-NET composite; differentiable w.r.t. latent grid and IM-NET parameters."""
+
+    @staticmethod
+    def forward(ctx, meta, latent, pts, *params):
+        packs = meta.plan.pack(params)
+        P = pts.shape[0]
+        jets = torch.empty(meta.S, meta.plan.cout, P, device=pts.device)
+        need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        saved = []
+        chunk = meta.chunk
+        for p0 in range(0, P, chunk):
+            s = _forward_chunk(meta, packs, latent, pts[p0:p0 + chunk], jets, p0)
+            if need_grad:
+                saved.append(s)
+        ctx.meta, ctx.packs, ctx.saved = meta, packs, saved
+        ctx.n_params = len(params)
+        ctx.lat_shape = latent.shape
+        ctx.params = params
+        ctx.used = False
+        return jets
+
+    @staticmethod
+    def backward(ctx, jets_bar):
+        if ctx.used:
+            raise RuntimeError("LigJetFunction.backward ran twice: the activation stash is consumed in place "
+                               "(retain_graph is not supported on the HIP jet path)")
+        ctx.used = True
+        meta = ctx.meta
+        jets_bar = jets_bar.contiguous()
+        dev = jets_bar.device
+        meta.need_wgrad = any(ctx.needs_input_grad[3:])
+        need_lat = ctx.needs_input_grad[1]
+        dw_flat = torch.zeros(meta.plan.n_dw, device=dev) if meta.need_wgrad else None
+        dlatent = torch.zeros(ctx.lat_shape, device=dev) if need_lat else None
+        for s in ctx.saved:
+            _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent)
+            s["bufs"] = None  # release the stash chunk by chunk
+        ctx.saved = []
+        grads = [None] * ctx.n_params
+        if meta.need_wgrad:
+            g = meta.plan.unpack_grads(dw_flat, ctx.params)
+            grads = [gi if need else None for gi, need in zip(g, ctx.needs_input_grad[3:])]
+        return (None, dlatent, None) + tuple(grads)
+
+
+def activation_name(module):
+    """Map an activation module to the library's enum name; returns (name, param) or None if unknown."""
+    import torch.nn as nn
+    from . import nonlinearities
+    if isinstance(module, nonlinearities.Swish):
+        return "swish", module.beta
+    table = [(nn.Tanh, "tanh"), (nn.ReLU, "relu"), (nn.Softplus, "softplus"), (nn.ELU, "elu"),
+             (nn.LeakyReLU, "leakyrelu")]
+    for cls, name in table:
+        if type(module) is cls:
+            if name == "softplus" and (module.beta != 1 or module.threshold != 20):
+                return None
+            if name == "elu" and module.alpha != 1.0:
+                return None
+            if name == "leakyrelu" and module.negative_slope != 0.01:
+                return None
+            return name, 0.0
+    return None
+
+
+def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=1 << 16):
+    """HIP evaluation of y and its coordinate derivatives.
+
+    imnet: implicit_net.ImNet (dim=3); latent_grid [b, n0, n1, n2, c]; query_pts [b, p, 3].
+    Returns (jets [S, n_out, b*p] with S = 1 + 3*first + len(padded pairs), padded_pairs).
+    Stream order: value, d/dq_0, d/dq_1, d/dq_2, then d2/dq_a dq_b per pair.
+    """
+    if not (latent_grid.is_cuda and query_pts.is_cuda):
+        raise RuntimeError("the HIP jet path needs CUDA/HIP tensors (no CPU fallback)")
+    if latent_grid.dim() != 5 or query_pts.dim() != 3 or query_pts.shape[-1] != 3:
+        raise ValueError("lig_jets expects latent_grid [b,n0,n1,n2,c] and query_pts [b,p,3]")
+    if latent_grid.dtype != torch.float32 or query_pts.dtype != torch.float32:
+        raise ValueError("lig_jets is fp32 only")
+    an = activation_name(imnet.activ)
+    if an is None:
+        raise NotImplementedError("activation %r is not implemented in the HIP jet path" % (imnet.activ,))
+    act, prm = an
+    if act == "swish":
+        if prm.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("gradient w.r.t. the learnable swish beta is not implemented in the HIP path")
+        prm = float(prm.detach())
+    B, N = query_pts.shape[0], query_pts.shape[1]
+    if latent_grid.shape[0] != B:
+        raise ValueError("batch mismatch between latent_grid and query_pts")
+    plan = ImNetPlan.get(imnet.dim, imnet.in_features, imnet.out_features, imnet.nf)
+    if latent_grid.shape[-1] != plan.cin:
+        raise ValueError("latent channels != imnet.in_features")
+    meta = _Meta()
+    meta.plan = plan
+    meta.cfg, meta.S, ppairs = make_cfg(act, prm, first, list(pairs))
+    meta.B, meta.N = B, N
+    meta.grid_shape = tuple(latent_grid.shape[1:4])
+    meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)
+    meta.need_wgrad = True
+    P = B * N
+    pts = query_pts.detach().reshape(P, 3).contiguous()
+    pad = P & 1
+    if pad:
+        pts = torch.cat([pts, pts[-1:]], 0)
+    meta.P_pad = P + pad
+    meta.chunk = max(2, chunk_points & ~1)
+    lat = latent_grid.contiguous()
+    params = []
+    for k in range(6):
+        params += [imnet.fc[k].weight, imnet.fc[k].bias]
+    jets = LigJetFunction.apply(meta, lat, pts, *params)
+    if pad:
+        jets = jets[:, :, :P]
+    return jets, ppairs

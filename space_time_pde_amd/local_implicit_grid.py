@@ -1,0 +1,91 @@
+"""Local implicit grid query (mirrors src/local_implicit_grid.py:10-61 of the reference).
+
+``query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax)`` keeps the reference signature.  When it
+is called from inside ``PDELayer.__call__`` (which announces the derivatives its equations need through
+``jet_context``) with an ``ImNet`` decoder on CUDA tensors and 3-d query points, the whole
+gather -> MLP -> corner-weighted sum, INCLUDING the coordinate derivatives, runs in the HIP jet kernels
+(lig_jet.py).  A plain call (no PDE layer) on the same kind of inputs runs the value-only HIP path.
+Other decoders / dimensions use the generic composed formulation.
+"""
+import threading
+
+import torch
+
+from . import lig_jet
+from . import regular_nd_grid_interpolation as rgi
+from .implicit_net import ImNet
+
+_tls = threading.local()
+stats = {"hip_jet_calls": 0, "hip_value_calls": 0, "generic_calls": 0}
+
+
+class JetRequest:
+    """Set by PDELayer around ``forward_method``: which derivatives of y w.r.t. the points it will need."""
+
+    def __init__(self, x, first, pairs):
+        self.x, self.first, self.pairs = x, first, list(pairs)
+        self.y = None          # the tensor handed back to the caller
+        self.jets = None       # [S, n_out, P]
+        self.pairs_out = None  # second-order pairs in stream order (after padding)
+
+
+class jet_context:
+    def __init__(self, req):
+        self.req = req
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "req", None)
+        _tls.req = self.req
+        return self.req
+
+    def __exit__(self, *exc):
+        _tls.req = self.prev
+        return False
+
+
+def _fast_eligible(model, latent_grid, query_pts):
+    return (isinstance(model, ImNet) and model.dim == 3 and latent_grid.dim() == 5 and query_pts.dim() == 3
+            and query_pts.shape[-1] == 3 and latent_grid.is_cuda and query_pts.is_cuda
+            and latent_grid.dtype == torch.float32 and query_pts.dtype == torch.float32
+            and model.nf % 16 == 0 and model.out_features <= 16 and model.in_features <= 44
+            and latent_grid.shape[-1] == model.in_features
+            and lig_jet.activation_name(model.activ) is not None
+            and not (lig_jet.activation_name(model.activ)[0] == "swish" and model.activ.beta.requires_grad
+                     and torch.is_grad_enabled()))
+
+
+def _xmin_is_zero(xmin):
+    if isinstance(xmin, (int, float)):
+        return xmin == 0
+    if torch.is_tensor(xmin):
+        return None  # decided (and cached) inside lig_jet.box_constants
+    return all(float(v) == 0 for v in xmin)
+
+
+def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
+    """Query a local implicit grid: y = sum_j w_j * model([x_rel_j ; latent_j]) (reference :47-59).
+
+    model: nn.Module taking [rows, d+c]; latent_grid [b, n1..nd, c]; query_pts [b, num_pts, d];
+    xmin/xmax: float, sequence or tensor bounds of the grid.  Returns [b, num_pts, o].
+    """
+    req = getattr(_tls, "req", None)
+    if _fast_eligible(model, latent_grid, query_pts) and _xmin_is_zero(xmin) is not False:
+        wants_point_grad = query_pts.requires_grad and torch.is_grad_enabled()
+        if req is not None and req.x is query_pts:
+            jets, pairs = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, req.first, req.pairs)
+            stats["hip_jet_calls"] += 1
+            y = jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], -1)
+            req.y, req.jets, req.pairs_out = y, jets, pairs
+            return y
+        if not wants_point_grad:
+            jets, _ = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, False, ())
+            stats["hip_value_calls"] += 1
+            return jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], -1)
+    stats["generic_calls"] += 1
+    corner_values, weights, x_relative = rgi._coefficients_autograd(latent_grid, query_pts, xmin, xmax) \
+        if (query_pts.requires_grad and torch.is_grad_enabled()) else \
+        rgi.regular_nd_grid_interpolation_coefficients(latent_grid, query_pts, xmin, xmax)
+    feats = torch.cat([x_relative, corner_values], dim=-1)
+    shp = feats.shape
+    out = model(feats.reshape(-1, shp[-1])).reshape(shp[0], shp[1], shp[2], -1)
+    return torch.sum(out * weights.unsqueeze(-1), dim=-2)

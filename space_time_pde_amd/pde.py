@@ -1,0 +1,207 @@
+"""PDE layer: equation strings -> residuals (mirrors src/pde.py:12-151 of the reference).
+
+Same public surface as the reference ``PDELayer``: ``add_equation``, ``update_forward_method``, ``eval``,
+``__call__(x, return_residue=True)``, ``eqn_num``, ``eqn_names`` and the attributes ``in_vars, out_vars, n_in,
+n_out, all_vars, eqns_raw, eqns_fn, forward_method``.
+
+Two evaluation strategies:
+
+* generic (reference semantics, any forward function): every ``dif(a, b)`` is one reverse sweep
+  ``torch.autograd.grad(a, b, ones_like(a), create_graph=True, allow_unused=True)`` (reference :8-9);
+* jets (hot path): at ``add_equation`` time the expression is rewritten with sympy -- every output symbol becomes
+  an applied function of the inputs and each nested ``dif`` is expanded with ``sympy.diff`` -- into an algebraic
+  expression of the "jet atoms" u, du/dx, d2u/dx2, ...  ``__call__`` then asks the forward method for those
+  derivatives in ONE pass (``local_implicit_grid.jet_context``); if the forward method is the HIP local-implicit-
+  grid query it answers with forward-mode jets computed by the CDNA4 kernels, and the residual is plain
+  elementwise algebra on them.  If the forward method is anything else (or post-processes the query result) the
+  generic strategy is used, exactly like the reference.
+"""
+import sympy
+import torch
+from sympy.core.function import AppliedUndef
+from sympy.parsing.sympy_parser import parse_expr
+from torch.autograd import grad
+
+from . import local_implicit_grid as _lig
+
+
+def torch_diff(y, x):
+    """``dif(y, x)``: d(sum y)/dx keeping the graph (reference pde.py:8-9)."""
+    return grad(y, x, grad_outputs=torch.ones_like(y), create_graph=True, allow_unused=True)[0]
+
+
+_TORCH_FUNCS = {"sin": torch.sin, "cos": torch.cos, "tan": torch.tan, "exp": torch.exp, "log": torch.log,
+                "sqrt": torch.sqrt, "tanh": torch.tanh, "sinh": torch.sinh, "cosh": torch.cosh, "Abs": torch.abs}
+
+
+class _JetProgram:
+    """Residual as a function of input columns and jet atoms."""
+
+    def __init__(self, fn, atoms):
+        self.fn = fn          # callable(*in_cols, *atom_tensors)
+        self.atoms = atoms    # list of (out_index, multi_index tuple sorted)  e.g. (2, ()) / (2, (1,)) / (2, (1, 1))
+
+
+class PDELayer(object):
+    """PDE Layer for querying values and computing PDE residues."""
+
+    def __init__(self, in_vars, out_vars):
+        """in_vars / out_vars: strings of variable names, e.g. 'x, y, t' and 'u, v, p'."""
+        self.in_vars = sympy.symbols(in_vars)
+        self.out_vars = sympy.symbols(out_vars)
+        if not isinstance(self.in_vars, tuple):
+            self.in_vars = (self.in_vars,)
+        if not isinstance(self.out_vars, tuple):
+            self.out_vars = (self.out_vars,)
+        self.n_in = len(self.in_vars)
+        self.n_out = len(self.out_vars)
+        self.all_vars = list(self.in_vars) + list(self.out_vars)
+        self.eqns_raw = {}   # raw string equations
+        self.eqns_fn = {}    # lambda functions (generic autograd strategy)
+        self.eqns_jet = {}   # _JetProgram or None per equation
+        self.forward_method = None
+
+    # ------------------------------------------------------------------------------------------------
+    def add_equation(self, eqn_str, eqn_name='', subs_dict=None):
+        """Add the residue expression of one equation; ``dif(y,x)`` denotes dy/dx (reference :37-86).
+
+        Raises ValueError when the expression uses symbols outside in_vars/out_vars.
+        """
+        if not eqn_name:
+            # the reference formats 'eqn_{i}' with a positional argument and therefore raises KeyError here
+            # (quirk a-Q5); the documented intent -- a default name eqn_<index> -- is implemented instead.
+            eqn_name = 'eqn_{}'.format(len(self.eqns_raw.keys()))
+        expr = parse_expr(eqn_str)
+        if subs_dict:
+            for key, val in subs_dict.items():   # sequential substitution, as the reference
+                expr = expr.subs(key, val)
+        valid_var = expr.free_symbols <= (set(self.in_vars) | set(self.out_vars))
+        if not valid_var:
+            raise ValueError('Variables in the eqn_str ({}) does not match that of '
+                             'in_vars ({}) and out_vars ({})'.format(expr.free_symbols, set(self.in_vars),
+                                                                     set(self.out_vars)))
+        fn = sympy.lambdify(self.all_vars, expr, [{'dif': torch_diff}, _TORCH_FUNCS])
+        self.eqns_raw.update({eqn_name: eqn_str})
+        self.eqns_fn.update({eqn_name: fn})
+        self.eqns_jet.update({eqn_name: self._compile_jet(expr)})
+
+    def _compile_jet(self, expr):
+        """Expand nested ``dif`` symbolically; returns a _JetProgram or None (not expressible with order<=2 jets)."""
+        try:
+            funcs = {v: sympy.Function(v.name)(*self.in_vars) for v in self.out_vars}
+            e = expr.subs(funcs, simultaneous=True)
+            dif = sympy.Function('dif')
+            e = e.replace(lambda t: isinstance(t, AppliedUndef) and t.func == dif and len(t.args) == 2,
+                          lambda t: sympy.Derivative(t.args[0], t.args[1]))
+            e = e.doit()
+            if e.has(dif) or e.has(sympy.Subs):
+                return None
+            fout = {f: i for i, f in enumerate(funcs.values())}
+            ivar = {v: i for i, v in enumerate(self.in_vars)}
+            atoms, repl = [], {}
+            for dv in e.atoms(sympy.Derivative):
+                if dv.expr not in fout:
+                    return None
+                mi = []
+                for v, cnt in dv.variable_count:
+                    if v not in ivar:
+                        return None
+                    mi += [ivar[v]] * int(cnt)
+                if len(mi) > 2:
+                    return None
+                key = (fout[dv.expr], tuple(sorted(mi)))
+                repl[dv] = sympy.Dummy("j%d_%s" % (key[0], "".join(map(str, key[1]))))
+                atoms.append((key, repl[dv]))
+            e = e.xreplace(repl)
+            for f, i in fout.items():
+                if e.has(f):
+                    s = sympy.Dummy("j%d_" % i)
+                    e = e.xreplace({f: s})
+                    atoms.append(((i, ()), s))
+            if e.atoms(AppliedUndef):
+                return None
+            atoms.sort(key=lambda a: (a[0][0], len(a[0][1]), a[0][1]))
+            fn = sympy.lambdify(list(self.in_vars) + [a[1] for a in atoms], e, [_TORCH_FUNCS])
+            return _JetProgram(fn, [a[0] for a in atoms])
+        except Exception:  # any sympy corner case -> generic strategy (never wrong, only slower)
+            return None
+
+    # ------------------------------------------------------------------------------------------------
+    def update_forward_method(self, forward_method):
+        """forward_method: y = forward_method(x), x (..., n_in) -> y (..., n_out)."""
+        self.forward_method = forward_method
+
+    def eval(self, x):
+        """Evaluate the output values using forward_method (reference :97-113)."""
+        if not self.forward_method:
+            raise RuntimeError('forward_method has not been defined.'
+                               'Run update_forward_method first.')
+        y = self.forward_method(x)
+        if not ((x.shape[-1] == self.n_in) and (y.shape[-1] == self.n_out)):
+            raise ValueError('Input/output dimensions ({}/{}) not equal to the dimensions of '
+                             'defined variables ({}/{}).'.format(x.shape[-1], y.shape[-1], self.n_in, self.n_out))
+        return y
+
+    def _jet_request(self, x):
+        if not (self.eqns_jet and all(p is not None for p in self.eqns_jet.values())):
+            return None
+        if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 3 and self.n_in == 3):
+            return None
+        first, pairs = False, set()
+        for prog in self.eqns_jet.values():
+            for _, mi in prog.atoms:
+                if len(mi) == 1:
+                    first = True
+                elif len(mi) == 2:
+                    pairs.add(mi)
+        return _lig.JetRequest(x, first or bool(pairs), sorted(pairs))
+
+    def _residues_from_jets(self, x, req):
+        jets, pairs = req.jets, req.pairs_out
+        shape = x.shape[:-1] + (1,)
+        stream_of = {(): 0}
+        for d in range(3):
+            stream_of[(d,)] = 1 + d
+        for k, p in enumerate(pairs):
+            stream_of.setdefault(tuple(p), 4 + k)
+        cols = [x[..., i:i + 1] for i in range(self.n_in)]
+        cache = {}
+
+        def atom(key):
+            if key not in cache:
+                cache[key] = jets[stream_of[key[1]], key[0]].reshape(shape)
+            return cache[key]
+
+        return {name: prog.fn(*(cols + [atom(k) for k in prog.atoms])) for name, prog in self.eqns_jet.items()}
+
+    def __call__(self, x, return_residue=True):
+        """y = forward(x) and, optionally, the residue of every equation (reference :115-143)."""
+        if not return_residue:
+            return self.eval(x)
+        req = self._jet_request(x)
+        if req is not None:
+            with _lig.jet_context(req):
+                y = self.eval(x)
+            if req.jets is not None and req.y is y:
+                return y, self._residues_from_jets(x, req)
+        # generic strategy: split into columns that require grad, re-assemble, differentiate by reverse sweeps
+        inputs = [x[..., i:i + 1] for i in range(x.shape[-1])]
+        for xx in inputs:
+            if not xx.requires_grad:
+                xx.requires_grad = True
+        x_ = torch.cat(inputs, axis=-1)
+        y = self.eval(x_)
+        outputs = [y[..., i:i + 1] for i in range(y.shape[-1])]
+        inputs_outputs = inputs + outputs
+        residues = {}
+        for key, fn in self.eqns_fn.items():
+            residues.update({key: fn(*inputs_outputs)})
+        return y, residues
+
+    @property
+    def eqn_num(self):
+        return len(self.eqns_raw)
+
+    @property
+    def eqn_names(self):
+        return list(self.eqns_raw.keys())

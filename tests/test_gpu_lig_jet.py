@@ -1,0 +1,157 @@
+"""GPU parity: HIP jet path (through the C-ABI library) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (fp32 path vs fp64 oracle): values/jets 2e-5 of the tensor's max magnitude; parameter / latent
+gradients 2e-4 relative to the gradient's max magnitude (they are sums of ~1e3..1e5 fp32 terms accumulated in a
+different order, with fp32 atomics); PDE-residual loss 1e-5 relative (the north-star bound).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from oracle import jet_ref as J
+
+pytestmark = pytest.mark.gpu
+
+ACTS = ["softplus", "leakyrelu", "tanh", "relu", "elu", "swish"]
+
+
+def _net(act, nf=16, cout=4, seed=0, beta=1.3):
+    from space_time_pde_amd import implicit_net, nonlinearities
+    torch.manual_seed(seed)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=cout, nf=nf,
+                             activation=nonlinearities.NONLINEARITIES[act])
+    if act == "swish":
+        with torch.no_grad():
+            net.activ.beta.fill_(beta)
+        net.activ.beta.requires_grad_(False)
+    return net
+
+
+def _params64(net):
+    return [(net.fc[k].weight.detach().double().cpu(), net.fc[k].bias.detach().double().cpu()) for k in range(6)]
+
+
+def _relerr(a, b):
+    return (a.double().cpu() - b.double()).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def _normerr(a, b):
+    return (a.double().cpu() - b.double()).norm().item() / max(b.double().norm().item(), 1e-30)
+
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("pairs", [(), ((1, 1), (2, 2)), ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))])
+def test_jets_match_oracle(hiplib, act, pairs):
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    lat = 0.5 * torch.randn(2, 4, 6, 5, 32, generator=g)
+    pts = torch.rand(2, 77, 3, generator=g)              # odd per-batch count, 154 points total
+    net = _net(act).to(dev)
+    jets, pp = lig_jet.lig_jets(net, lat.to(dev), pts.to(dev), 0., 1., True, pairs, chunk_points=64)
+    beta = torch.tensor(1.3, dtype=torch.float64)
+    ref = J.lig_jets(_params64(net), act, lat.double(), pts.double(), 0., 1., second=tuple(pp), beta=beta)
+    ref = ref.permute(0, 3, 1, 2).reshape(ref.shape[0], 4, -1)
+    assert jets.shape == ref.shape
+    for s in range(ref.shape[0]):
+        assert _relerr(jets[s], ref[s]) < 2e-5, "stream %d" % s
+
+
+def test_value_only_and_nonunit_box(hiplib):
+    from space_time_pde_amd import local_implicit_grid as lig
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(1, 5, 4, 7, 32, generator=g)
+    xmax = (2.0, 1.0, 4.0)
+    pts = torch.rand(1, 301, 3, generator=g) * torch.tensor(xmax)
+    net = _net("leakyrelu").to(dev)
+    n0 = lig.stats["hip_value_calls"]
+    with torch.no_grad():
+        y = lig.query_local_implicit_grid(net, lat.to(dev), pts.to(dev), (0., 0., 0.), xmax)
+    assert lig.stats["hip_value_calls"] == n0 + 1
+    p32 = [(w.float(), b.float()) for w, b in _params64(net)]
+    ref = O.query_lig(lambda f: O.imnet_forward(p32, f, O.activation_fn("leakyrelu")), lat, pts, (0., 0., 0.), xmax)
+    assert _relerr(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("act", ["softplus", "leakyrelu", "tanh", "elu"])
+def test_backward_matches_oracle_autograd(hiplib, act):
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(2, 200, 3, generator=g)
+    pairs = ((1, 1), (2, 2))
+    net = _net(act).to(dev)
+    latd = lat.to(dev).requires_grad_(True)
+    jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, pairs, chunk_points=128)
+    cot = torch.randn(jets.shape, generator=g)
+    (jets * cot.to(dev)).sum().backward()
+    p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
+    lat64 = lat.double().requires_grad_(True)
+    ref = J.lig_jets(p64, act, lat64, pts.double(), 0., 1., second=tuple(pp))
+    ref = ref.permute(0, 3, 1, 2).reshape(ref.shape[0], 4, -1)
+    (ref * cot.double()).sum().backward()
+    assert _relerr(latd.grad, lat64.grad) < 2e-4
+    for k in range(6):
+        assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
+        assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_golden_composite_g5(hiplib, golden_dir, act):
+    """LIG + RB2 residuals + L1 losses + backward vs vectors produced by the real reference (G5)."""
+    import os
+    from space_time_pde_amd import local_implicit_grid as lig, physics
+    d = np.load(os.path.join(golden_dir, "g5_composite.npz"))
+    dev = torch.device("cuda:0")
+    net = _net(act).to(dev)
+    with torch.no_grad():
+        for k in range(6):
+            net.fc[k].weight.copy_(torch.from_numpy(d["w%d" % k]))
+            net.fc[k].bias.copy_(torch.from_numpy(d["b%d" % k]))
+    lat = torch.from_numpy(d["latent"]).to(dev).requires_grad_(True)
+    pts = torch.from_numpy(d["pts"]).to(dev)
+    tgt = torch.from_numpy(d["targets"]).to(dev)
+    layer = physics.get_rb2_pde_layer(mean=tuple(d["mean"]), std=tuple(d["std"]), t_crop=2., z_crop=1., x_crop=1.,
+                                      use_continuity=True)
+    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, lat, p, 0., 1.))
+    n0 = lig.stats["hip_jet_calls"]
+    pred, res = layer(pts, return_residue=True)
+    assert lig.stats["hip_jet_calls"] == n0 + 1
+    reg = torch.nn.functional.l1_loss(pred, tgt)
+    st = torch.stack(list(res.values()), 0)
+    pl = torch.nn.functional.l1_loss(st, torch.zeros_like(st))
+    (1.0 * reg + 0.0125 * pl).backward()
+    assert _relerr(pred, torch.from_numpy(d[act + "_pred"])) < 2e-5
+    # piecewise-linear activations: a kink flip moves single residual values; check loss + bulk of the points
+    for k, v in res.items():
+        ref = torch.from_numpy(d["%s_res_%s" % (act, k)]).double()
+        err = (v.detach().double().cpu() - ref).abs() / ref.abs().max()
+        assert err.median().item() < 1e-5 and (err < 1e-3).double().mean().item() > 0.98, k
+    assert abs(pl.item() - float(d[act + "_pde_loss"])) / float(d[act + "_pde_loss"]) < 1e-5
+    assert abs(reg.item() - float(d[act + "_reg_loss"])) / float(d[act + "_reg_loss"]) < 1e-5
+    # piecewise-linear activations: single kink / sign flips (fp32 rounding of a pre-activation near 0) move
+    # individual gradient entries; the reference differs from its own fp64 run by 2e-3 max-rel there (SURVEY a-Q8),
+    # so those are judged in the Frobenius norm with a loose max bound; smooth activations entry-wise.
+    pl_act = act in ("leakyrelu", "relu")
+    err = _normerr if pl_act else _relerr
+    tol = 5e-3 if pl_act else 5e-4
+
+    def close(a, b):
+        assert err(a, b) < tol
+        assert _relerr(a, b) < (5e-2 if pl_act else tol)
+
+    close(lat.grad, torch.from_numpy(d[act + "_dlatent"]))
+    for k in range(3, 6):
+        close(net.fc[k].weight.grad, torch.from_numpy(d["%s_dw%d" % (act, k)]))
+        close(net.fc[k].bias.grad, torch.from_numpy(d["%s_db%d" % (act, k)]))
+    if act in ("softplus", "leakyrelu"):
+        for k in range(3):
+            close(net.fc[k].weight.grad, torch.from_numpy(d["%s_dw%d" % (act, k)]))
+
+
+def test_smoke_entry(hiplib):
+    import __graft_entry__ as ge
+    ge.smoke()
