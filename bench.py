@@ -1,0 +1,212 @@
+"""Hot-path benchmark: query-points/sec of one MeshfreeFlowNet training step (fwd + PDE residuals + bwd).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic input (experiments/rb2d/train.py:58-77 of the
+reference): latent grid -> local-implicit-grid gather -> IM-NET on every query point with the RB2 residual
+derivatives -> L1 losses -> backward to all IM-NET parameters and the latent grid.  Workload = BASELINE.json
+configs[1]: latent grid [1, 32, 128, 128, 32] (T, Z, X, C), 2^20 query points, full Rayleigh-Benard PDE set
+(3 transport equations + continuity), fp32.  With N GPUs the SAME 2^20 points are sharded across ranks
+(strong scaling); gradients are summed with one RCCL all-reduce.
+
+Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (dominant kernel, HIP-event timed) and
+``cpu_baseline`` (the CPU oracle = restatement of the reference path, timed on the host cores on a bounded
+sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MEAN, STD = (0.01, 0.0, 0.02, -0.01), (0.05, 0.3, 0.15, 0.12)
+RB2 = dict(mean=MEAN, std=STD, t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
+ALPHA_REG, ALPHA_PDE = 1.0, 0.0125
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+
+
+def algorithmic_macs(nf=32, cin=32, cout=4, n_first=3, n_second=2):
+    """Per CORNER ROW multiply-accumulates of each kernel (hidden blocks carry all streams,
+    the raw-input (skip) blocks only the value stream; 1 MAC = 2 FLOP)."""
+    dz = 3 + cin
+    widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf, cout]
+    S = 1 + n_first + n_second
+    macs = {}
+    for l in range(1, 6):
+        hidden = widths[l - 1] * widths[l]
+        skip = dz * widths[l] if l < 5 else 0
+        macs["layer%d_fwd" % l] = S * hidden + skip + (dz * widths[0] if l == 1 else 0)
+        macs["layer%d_dgrad" % l] = S * hidden
+        macs["layer%d_wgrad" % l] = S * hidden + skip
+    macs["layer0_wgrad"] = dz * widths[0]
+    T = sum(widths[l - 1] * widths[l] for l in range(1, 6))          # hidden-to-hidden blocks: every stream
+    M = T + dz * sum(widths[:5])                                       # value pass also has the raw-input blocks
+    return macs, M, T
+
+
+def make_inputs(n_pts, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    latent = (0.5 * torch.randn(1, 32, 128, 128, 32, generator=g)).to(dev)
+    pts = torch.rand(1, n_pts, 3, generator=g).to(dev)
+    tgt = torch.randn(1, n_pts, 4, generator=g).to(dev)
+    return latent, pts, tgt
+
+
+def cpu_baseline(act, chunk=4096, nchunks=3):
+    """Time the CPU oracle (restatement of the reference's 25-reverse-sweep path) on a bounded sample."""
+    from oracle import cpu_ref
+    g = torch.Generator().manual_seed(0)
+    latent = 0.5 * torch.randn(1, 32, 128, 128, 32, generator=g)
+    params = cpu_ref.imnet_init(nf=32, seed=1)
+    pde = cpu_ref.rb2_oracle(**RB2)
+    times = []
+    for c in range(nchunks + 1):
+        pts = torch.rand(1, chunk, 3, generator=g)
+        tgt = torch.randn(1, chunk, 4, generator=g)
+        t0 = time.perf_counter()
+        cpu_ref.lig_pde_step(params, act, latent, pts, tgt, pde, ALPHA_REG, ALPHA_PDE)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])              # drop the warm-up chunk
+    med = times[len(times) // 2]
+    return dict(value=chunk / med, unit="query-points/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d chunks of %d points over the same [1,32,128,128,32] latent grid, %s, median chunk %.2f s "
+                       "(the reference path cannot hold 2^20 points at once: it pseudo-batches, evaluation.py:54-60)"
+                       % (nchunks, chunk, act, med))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=1 << 20)
+    ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
+    ap.add_argument("--chunk", type=int, default=1 << 17, help="points per launch chunk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics
+
+    torch.manual_seed(1)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES[args.act]).to(dev)
+    params = [p for p in net.parameters()]
+    if world > 1:
+        for p in params:
+            dist.broadcast(p.data, 0)
+    latent0, pts_all, tgt_all = make_inputs(args.points, dev)
+    n_local = args.points // world
+    pts = pts_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
+    tgt = tgt_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
+    del pts_all, tgt_all
+    layer = physics.get_rb2_pde_layer(**RB2)
+    n_eq = layer.eqn_num
+    latent = latent0.clone().requires_grad_(True)
+    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, latent, p, 0., 1.))
+    lig_jet.DEFAULT_CHUNK = args.chunk
+
+    def step():
+        for p in params:
+            p.grad = None
+        latent.grad = None
+        pred, res = layer(pts, return_residue=True)
+        # L1 losses normalised by the GLOBAL counts so that the sharded sum equals the single-GPU mean
+        reg = (pred - tgt).abs().sum() / (args.points * 4)
+        st = torch.stack(list(res.values()), 0)
+        pde_loss = st.abs().sum() / (args.points * n_eq)
+        loss = ALPHA_REG * reg + ALPHA_PDE * pde_loss
+        loss.backward()
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in params] + [latent.grad.reshape(-1)])
+            dist.all_reduce(flat)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    lig_jet.profile = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = lig_jet.profile
+    lig_jet.profile = None
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+    assert lig.stats["hip_jet_calls"] >= args.steps, "HIP jet path was not taken"
+
+    if rank == 0:
+        macs, M, T = algorithmic_macs()
+        smooth = args.act not in ("relu", "leakyrelu")
+        fwd_flop_pt = 2 * 8 * (M + (5 if smooth else 3) * T)
+        step_flop_pt = 3 * fwd_flop_pt
+        kern = {}
+        for name, evs in prof.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            kern[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
+        dom = max(kern, key=lambda k: kern[k]["total_ms"])
+        rows_per_launch = 8 * min(args.chunk, n_local)
+        flop_launch = 2.0 * macs.get(dom, 0) * rows_per_launch
+        ach = flop_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=None,
+                        flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3),
+                        step_algorithmic_tflops=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world, 2),
+                        step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
+                                                / PEAK_F32_TFLOPS, 4),
+                        kernels={k: round(v["total_ms"] / args.steps, 2) for k, v in sorted(kern.items())})
+        out = {
+            "metric": "query-points/sec (fwd+PDE-residual bwd), rb2d 128^3 latent",
+            "value": args.points * args.steps / dt,
+            "unit": "query-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: latent [1,32,128,128,32], 2^%d query points, RB2 "
+                                   "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + latent grid"
+                                   % (args.points.bit_length() - 1, args.act),
+                       "points": args.points, "parallelism": "points sharded x%d" % world,
+                       "unet": "not in the timed step yet (latent grid is the leaf)", "loss": float(loss)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.act)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

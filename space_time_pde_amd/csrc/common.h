@@ -18,86 +18,99 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // sigma and its first three derivatives; conventions at kinks follow torch (relu'(0)=0, softplus threshold 20).
+// Branch-free (selects only) so that the evaluation can be interleaved with MFMAs by the scheduler.
 struct ActD {
   float s0, s1, s2, s3;
 };
 
-__device__ __forceinline__ ActD act_eval(int act, float prm, float a) {
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }          // v_exp_f32 path, ~2 ulp
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
+// log(1 + e) for e in [0, 1]: series below 2^-10 (where log(1+e) would cancel), v_log_f32 above
+__device__ __forceinline__ float log1p_unit(float e) {
+  const float u = 1.f + e;
+  const float big = __logf(u);
+  const float small = e * (1.f - e * (0.5f - e * 0.33333334f));
+  return e < 9.765625e-4f ? small : big;
+}
+
+template <int ACT>
+__device__ __forceinline__ ActD act_eval_t(float prm, float a) {
   ActD r;
-  switch (act) {
-    case STPDE_ACT_TANH: {
-      float t = tanhf(a);
-      float u = 1.f - t * t;
-      r.s0 = t;
-      r.s1 = u;
-      r.s2 = -2.f * t * u;
-      r.s3 = -2.f * u * (1.f - 3.f * t * t);
-    } break;
-    case STPDE_ACT_RELU: {
-      float m = a > 0.f ? 1.f : 0.f;
-      r.s0 = a * m;
-      r.s1 = m;
-      r.s2 = 0.f;
-      r.s3 = 0.f;
-    } break;
-    case STPDE_ACT_LEAKYRELU: {
-      float m = a > 0.f ? 1.f : 0.01f;
-      r.s0 = a * m;
-      r.s1 = m;
-      r.s2 = 0.f;
-      r.s3 = 0.f;
-    } break;
-    case STPDE_ACT_SOFTPLUS: {
-      if (a > 20.f) {
-        r.s0 = a;
-        r.s1 = 1.f;
-        r.s2 = 0.f;
-        r.s3 = 0.f;
-      } else {
-        float s = 1.f / (1.f + expf(-a));
-        float q = s * (1.f - s);
-        r.s0 = log1pf(expf(a));
-        r.s1 = s;
-        r.s2 = q;
-        r.s3 = q * (1.f - 2.f * s);
-      }
-    } break;
-    case STPDE_ACT_ELU: {
-      if (a > 0.f) {
-        r.s0 = a;
-        r.s1 = 1.f;
-        r.s2 = 0.f;
-        r.s3 = 0.f;
-      } else {
-        float e = expf(a);
-        r.s0 = expm1f(a);
-        r.s1 = e;
-        r.s2 = e;
-        r.s3 = e;
-      }
-    } break;
-    default: {  // STPDE_ACT_SWISH: x * sigmoid(beta x)
-      float ba = prm * a;
-      float s = 1.f / (1.f + expf(-ba));
-      float q = s * (1.f - s);
-      float c = 1.f - 2.f * s;
-      r.s0 = a * s;
-      r.s1 = s + ba * q;
-      r.s2 = prm * q * (2.f + ba * c);
-      r.s3 = prm * prm * q * (3.f * c + ba * (c * c - 2.f * q));
-    } break;
+  if (ACT == STPDE_ACT_TANH) {
+    const float e = fast_exp(-2.f * fabsf(a));
+    const float t0 = (1.f - e) * fast_rcp(1.f + e);
+    const float t = a < 0.f ? -t0 : t0;
+    const float u = 1.f - t * t;
+    r.s0 = t;
+    r.s1 = u;
+    r.s2 = -2.f * t * u;
+    r.s3 = -2.f * u * (1.f - 3.f * t * t);
+  } else if (ACT == STPDE_ACT_RELU) {
+    const float m = a > 0.f ? 1.f : 0.f;
+    r.s0 = a * m;
+    r.s1 = m;
+    r.s2 = 0.f;
+    r.s3 = 0.f;
+  } else if (ACT == STPDE_ACT_LEAKYRELU) {
+    const float m = a > 0.f ? 1.f : 0.01f;
+    r.s0 = a * m;
+    r.s1 = m;
+    r.s2 = 0.f;
+    r.s3 = 0.f;
+  } else if (ACT == STPDE_ACT_SOFTPLUS) {
+    const float e = fast_exp(-fabsf(a));
+    const float inv = fast_rcp(1.f + e);
+    const float s = a >= 0.f ? inv : e * inv;   // sigmoid(a)
+    const float q = e * inv * inv;              // s (1 - s)
+    const bool big = a > 20.f;                  // torch threshold
+    r.s0 = big ? a : fmaxf(a, 0.f) + log1p_unit(e);
+    r.s1 = big ? 1.f : s;
+    r.s2 = big ? 0.f : q;
+    r.s3 = big ? 0.f : q * (1.f - 2.f * s);
+  } else if (ACT == STPDE_ACT_ELU) {
+    const bool pos = a > 0.f;
+    const float e = fast_exp(fminf(a, 0.f));
+    r.s0 = pos ? a : expm1f(fminf(a, 0.f));
+    r.s1 = pos ? 1.f : e;
+    r.s2 = pos ? 0.f : e;
+    r.s3 = pos ? 0.f : e;
+  } else {  // STPDE_ACT_SWISH: x * sigmoid(beta x)
+    const float ba = prm * a;
+    const float e = fast_exp(-fabsf(ba));
+    const float inv = fast_rcp(1.f + e);
+    const float s = ba >= 0.f ? inv : e * inv;
+    const float q = e * inv * inv;
+    const float c = 1.f - 2.f * s;
+    r.s0 = a * s;
+    r.s1 = s + ba * q;
+    r.s2 = prm * q * (2.f + ba * c);
+    r.s3 = prm * prm * q * (3.f * c + ba * (c * c - 2.f * q));
   }
   return r;
+}
+
+// ACT >= 0: compile-time activation; ACT < 0: run-time (wave-uniform) switch
+template <int ACT>
+__device__ __forceinline__ ActD act_eval(int act, float prm, float a) {
+  if (ACT >= 0) return act_eval_t<(ACT >= 0 ? ACT : 0)>(prm, a);
+  switch (act) {
+    case STPDE_ACT_TANH: return act_eval_t<STPDE_ACT_TANH>(prm, a);
+    case STPDE_ACT_RELU: return act_eval_t<STPDE_ACT_RELU>(prm, a);
+    case STPDE_ACT_SOFTPLUS: return act_eval_t<STPDE_ACT_SOFTPLUS>(prm, a);
+    case STPDE_ACT_ELU: return act_eval_t<STPDE_ACT_ELU>(prm, a);
+    case STPDE_ACT_LEAKYRELU: return act_eval_t<STPDE_ACT_LEAKYRELU>(prm, a);
+    default: return act_eval_t<STPDE_ACT_SWISH>(prm, a);
+  }
 }
 
 __device__ __forceinline__ float sel3(int d, float a0, float a1, float a2) { return d == 0 ? a0 : (d == 1 ? a1 : a2); }
 
 // Forward jet of the activation on one fragment block: pre[S] (a, adot_d, addot_p) -> h[S].
-template <int S1, int S2>
+template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    ActD s = act_eval(cfg.act, cfg.act_param, pre[0][r]);
+    ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
     h[0][r] = s.s0;
     if (S1 == 3) {
       float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
@@ -114,12 +127,12 @@ __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x
 }
 
 // Adjoint: given pre[S] and hbar[S], produce abar[S] (adjoint of the pre-activation streams).
-template <int S1, int S2>
+template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
                                             f32x4* abar) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    ActD s = act_eval(cfg.act, cfg.act_param, pre[0][r]);
+    ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
     float ab = s.s1 * hbar[0][r];
     if (S1 == 3) {
       float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];

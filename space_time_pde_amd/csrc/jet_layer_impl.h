@@ -1,0 +1,211 @@
+// One IM-NET layer on all derivative streams, forward and input-gradient (dgrad), as a per-wave MFMA GEMM.
+//
+// Each wave owns one tile of 16 corner rows (2 query points x 8 corners) and MC output feature tiles, for all
+// S streams:   out^T[16*MC x 16] (per stream) = W[16*MC x K] * in^T[K x 16]
+// A operand = packed weights (one float4 per lane per (k-tile, m-tile) block = the 4 k-steps of the block),
+// B operand = the fragment block of the previous layer (C/D image == B image, so nothing is re-laid out),
+// accumulators = MC*S float4 per lane.  No LDS, no barriers: waves are independent and the weights stream
+// from L2 (every wave reads the same blocks).  The k-loop is software pipelined: the loads and the activation
+// jet of block kt+1 are issued while the MFMAs of block kt run.
+//
+// Replaces (reference): src/implicit_net.py:48-54 on the rows of src/local_implicit_grid.py:53, and the reverse
+// sweeps of src/pde.py:8-9 (streams carry d/dr and d2/dr2 forward instead).
+#pragma once
+#include "common.h"
+
+enum { PRO_NONE = 0, PRO_ACT = 1, PRO_L0 = 2 };
+enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
+
+struct LayerArgs {
+  const float* Bin;    // [tile][S][KT][256] B-operand source (pre-activations or adjoints)
+  const float* Wp;     // [KT][MT][256] packed A operand
+  const float* X;      // [tile][XT][256] augmented raw input
+  const float* W0s;    // [XT][KT or MT][256] packed layer-0 weights (PRO_L0 / EPI_ADJ_L0)
+  const float* tanc0;  // [3][KT or MT][256]   layer-0 tangent constants W0[:, d]
+  const float* Wsp;    // [XT][MT][256] packed skip weights (EPI_FWD)
+  const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
+  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
+  int KT, MT, ntiles;
+  stpde_jet_cfg cfg;
+};
+
+// layer-0 pre-activation block `blk` (of nblk) regenerated from the raw input: a0 = W0 x (+ bias via the ones column)
+__device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int blk, int lo, const f32x4* xb) {
+  f32x4 part[XT];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    f32x4 w = ld4(W0s + ((size_t)xt * nblk + blk) * 256 + lo);
+    f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c = mfma4(w[r], xb[xt][r], c);
+    part[xt] = c;
+  }
+  return (part[0] + part[1]) + part[2];
+}
+
+template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
+__global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
+  constexpr int S = 1 + S1 + S2;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.ntiles) return;
+  const int mt0 = blockIdx.y * MC;
+  const int KT = a.KT, MT = a.MT;
+  const int lo = lane * 4;
+
+  f32x4 acc[MC][S];
+#pragma unroll
+  for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 xb[XT];
+  if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+  }
+
+  const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
+  const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
+
+  // raw (un-activated) B block and weight blocks of k-tile kt
+  auto load_raw = [&](int kt, f32x4* raw) {
+    if (PRO == PRO_L0) {
+      raw[0] = layer0_block(a.W0s, KT, kt, lo, xb);
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
+#pragma unroll
+        for (int p = 0; p < S2; ++p) raw[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT + kt) * 256);
+    }
+  };
+  auto load_w = [&](int kt, f32x4* w) {
+#pragma unroll
+    for (int mi = 0; mi < MC; ++mi) {
+      const int mi_c = GUARD ? (mt0 + mi < MT ? mi : 0) : mi;   // clamp instead of branching
+      w[mi] = ld4(wp + ((size_t)kt * MT + mi_c) * 256);
+    }
+  };
+
+  if (KT > 0) {
+    f32x4 Bc[S], wc[MC];
+    {
+      f32x4 raw[S];
+      load_raw(0, raw);
+      if (PRO == PRO_NONE) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) Bc[st] = raw[st];
+      } else {
+        act_jet_fwd<S1, S2, ACT>(a.cfg, raw, Bc);
+      }
+      load_w(0, wc);
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+      const int kn = kt + 1 < KT ? kt + 1 : kt;   // last iteration re-fetches its own block (harmless)
+      f32x4 rawn[S], wn[MC];
+      load_raw(kn, rawn);
+      load_w(kn, wn);
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int st = 0; st < S; ++st) acc[mi][st] = mfma4(wc[mi][r], Bc[st][r], acc[mi][st]);
+      if (PRO == PRO_NONE) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) Bc[st] = rawn[st];
+      } else {
+        act_jet_fwd<S1, S2, ACT>(a.cfg, rawn, Bc);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) wc[mi] = wn[mi];
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < MC; ++mi) {
+    const int mt = mt0 + mi;
+    if (GUARD && mt >= MT) continue;
+    if (EPI == EPI_FWD) {
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+        f32x4 w = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][0] = mfma4(w[r], xb[xt][r], acc[mi][0]);
+      }
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[mi][1 + d] += ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
+      }
+#pragma unroll
+      for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[mi][st]);
+    } else {
+      f32x4 pre[S], ab[S];
+      if (EPI == EPI_ADJ) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+      } else {
+        pre[0] = layer0_block(a.W0s, MT, mt, lo, xb);
+        if (S1 == 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
+#pragma unroll
+          for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      act_jet_adj<S1, S2, -1>(a.cfg, pre, acc[mi], ab);
+      constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
+#pragma unroll
+      for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
+    }
+  }
+}
+
+template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
+static int launch_layer(const LayerArgs& a, hipStream_t stream) {
+  dim3 grid((a.ntiles + 3) / 4, (a.MT + MC - 1) / MC);
+  hipLaunchKernelGGL((k_layer<S1, S2, MC, PRO, EPI, ACT, GUARD>), grid, dim3(256), 0, stream, a);
+  return stpde_check_launch("k_layer");
+}
+
+template <int S1, int S2, int PRO>
+static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
+  constexpr int MC = 4;
+  if (a.MT % MC != 0) return launch_layer<S1, S2, MC, PRO, EPI_FWD, -1, true>(a, stream);
+  switch (a.cfg.act) {
+    case STPDE_ACT_TANH: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_TANH, false>(a, stream);
+    case STPDE_ACT_RELU: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_RELU, false>(a, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_SOFTPLUS, false>(a, stream);
+    case STPDE_ACT_ELU: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_ELU, false>(a, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_LEAKYRELU, false>(a, stream);
+    default: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_SWISH, false>(a, stream);
+  }
+}
+
+// mode: 0 = fwd (hidden input from stash), 1 = fwd first hidden (layer 0 on the fly), 2 = dgrad, 3 = dgrad into layer 0
+template <int S1, int S2>
+static int launch_mode(const LayerArgs& a, int mode, hipStream_t stream) {
+  constexpr int MC = 4;
+  switch (mode) {
+    case 0: return launch_fwd_act<S1, S2, PRO_ACT>(a, stream);
+    case 1: return launch_fwd_act<S1, S2, PRO_L0>(a, stream);
+    case 2:
+      return a.MT % MC == 0 ? launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ, -1, false>(a, stream)
+                            : launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ, -1, true>(a, stream);
+    default:
+      return a.MT % MC == 0 ? launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ_L0, -1, false>(a, stream)
+                            : launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ_L0, -1, true>(a, stream);
+  }
+}
+
+#define STPDE_DEFINE_LAYER_TU(S1, S2) \
+  int stpde_layer_launch_##S1##_##S2(const LayerArgs& a, int mode, hipStream_t stream) { return launch_mode<S1, S2>(a, mode, stream); }
+
+int stpde_layer_launch_0_0(const LayerArgs& a, int mode, hipStream_t stream);
+int stpde_layer_launch_3_0(const LayerArgs& a, int mode, hipStream_t stream);
+int stpde_layer_launch_3_2(const LayerArgs& a, int mode, hipStream_t stream);
+int stpde_layer_launch_3_6(const LayerArgs& a, int mode, hipStream_t stream);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
             for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
-        act_jet_fwd<S1, S2>(a.cfg, pre, H);
+        act_jet_fwd<S1, S2, -1>(a.cfg, pre, H);
       } else {
         // raw-input part: value stream = X_aug block, tangent stream d = unit vector e_d, second order = 0
         const int xt = kq - KT;

@@ -21,6 +21,28 @@ from ._lib import XT, GatherDesc, JetCfg, LayerDesc, XbarDesc, check, ptr, strea
 
 _FRAG = 256  # floats per 16x16 fragment block
 
+# Optional per-kernel timing (bench.py): set ``profile`` to a dict; every library call then records a pair of
+# events on the launch stream under its kernel name.  None = no overhead.
+profile = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if profile is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if profile is not None:
+            self.e1.record()
+            profile.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
 
 # ------------------------------------------------------------------------------------------------------------
 # architecture plan: index maps between nn.Linear parameters and MFMA operand packs
@@ -252,7 +274,8 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
     for k in range(3):
         gd.lo_c[k], gd.hi_c[k], gd.cube[k] = meta.lo_c[k], meta.hi_c[k], meta.cube[k]
     gd.p_base = p0
-    check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(coef), ptr(cell), st))
+    with _timed("gather"):
+        check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(coef), ptr(cell), st))
     bufs = [None]
     pv = plan.pack_view
     prev = None
@@ -260,13 +283,15 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
         lay = plan.layers[l]
         out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
         d = _layer_desc(nt, lay, cfg, l == 1)
-        check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")), ptr(pv(packs, l, "Ws")),
-                                    ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tanc")),
-                                    ptr(out), st))
+        with _timed("layer%d_fwd" % l):
+            check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")),
+                                        ptr(pv(packs, l, "Ws")), ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")),
+                                        ptr(pv(packs, 0, "tanc")), ptr(out), st))
         bufs.append(out)
         prev = out
-    check(L.stpde_lig_reduce_fwd(C.byref(cfg), Pc, plan.cout, ptr(bufs[5]), ptr(coef),
-                                 C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
+    with _timed("reduce_fwd"):
+        check(L.stpde_lig_reduce_fwd(C.byref(cfg), Pc, plan.cout, ptr(bufs[5]), ptr(coef),
+                                     C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
     return dict(X=X, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc)
 
 
@@ -280,8 +305,9 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
     dev = X.device
     pv = plan.pack_view
     # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer)
-    check(L.stpde_lig_reduce_bwd(C.byref(cfg), Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
-                                 jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
+    with _timed("reduce_bwd"):
+        check(L.stpde_lig_reduce_bwd(C.byref(cfg), Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
+                                     jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
     SP0 = 1 + cfg.S1
     abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
     for l in range(5, 0, -1):
@@ -289,18 +315,21 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
         d = _layer_desc(nt, lay, cfg, l == 1)
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
-            check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
-                                    ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tanc")),
-                                    ptr(dw_flat[off:off + mp * ka]), st))
-        check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
-                                    ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                    ptr(pv(packs, 0, "tanc")), ptr(abar0), st))
+            with _timed("layer%d_wgrad" % l):
+                check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
+                                        ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tanc")),
+                                        ptr(dw_flat[off:off + mp * ka]), st))
+        with _timed("layer%d_dgrad" % l):
+            check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
+                                        ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
         off, mp, ka = plan.dw_off[0]
-        check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), None, None,
-                                ptr(dw_flat[off:off + mp * ka]), st))
+        with _timed("layer0_wgrad"):
+            check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), None, None,
+                                    ptr(dw_flat[off:off + mp * ka]), st))
     if dlatent is not None:
         xd = XbarDesc()
         xd.ntiles, xd.nlayers, xd.C = nt, 5, plan.cin
@@ -312,7 +341,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
             xd.SP[l] = SP0 if l == 0 else S
             ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
             wt[l] = pv(packs, l, "WsT").data_ptr()
-        check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
+        with _timed("xbar_scatter"):
+            check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
 
 
 class LigJetFunction(torch.autograd.Function):
@@ -381,7 +411,10 @@ def activation_name(module):
     return None
 
 
-def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=1 << 16):
+DEFAULT_CHUNK = 1 << 16   # query points per launch chunk (bounds the per-chunk backward scratch)
+
+
+def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=None):
     """HIP evaluation of y and its coordinate derivatives.
 
     imnet: implicit_net.ImNet (dim=3); latent_grid [b, n0, n1, n2, c]; query_pts [b, p, 3].
@@ -421,7 +454,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     if pad:
         pts = torch.cat([pts, pts[-1:]], 0)
     meta.P_pad = P + pad
-    meta.chunk = max(2, chunk_points & ~1)
+    meta.chunk = max(2, (chunk_points or DEFAULT_CHUNK) & ~1)
     lat = latent_grid.contiguous()
     params = []
     for k in range(6):
