@@ -17,6 +17,17 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Store a column-major ("D") fragment block held in registers (lane 16g+j: features 4g..4g+3 of row j) into the
+// row-major ("R") image of the same 16x16 block (lane 16g'+c: rows 4g'..4g'+3 of feature c): pure addressing.
+__device__ __forceinline__ void st_R(float* block, int lane, f32x4 v) {
+  const int g = lane >> 4, j = lane & 15;
+  float* p = block + 64 * (j >> 2) + 16 * g + (j & 3);
+  p[0] = v[0];
+  p[4] = v[1];
+  p[8] = v[2];
+  p[12] = v[3];
+}
+
 // sigma and its first three derivatives; conventions at kinks follow torch (relu'(0)=0, softplus threshold 20).
 // Branch-free (selects only) so that the evaluation can be interleaved with MFMAs by the scheduler.
 struct ActD {

@@ -24,7 +24,9 @@ struct LayerArgs {
   const float* tanc0;  // [3][KT or MT][256]   layer-0 tangent constants W0[:, d]
   const float* Wsp;    // [XT][MT][256] packed skip weights (EPI_FWD)
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
-  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
+  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1][MT][256] (value stream)
+  float* OutR;         // EPI_ADJ*: R-layout copy of the adjoint [tile][S or 1+S1][MT][256] (operand of the weight gradient)
+  float* HR;           // EPI_ADJ: R-layout activated input act_jet(pre) [tile][S][MT][256] (operand of the weight gradient)
   int KT, MT, ntiles;
   stpde_jet_cfg cfg;
 };
@@ -49,23 +51,23 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= a.ntiles) return;
-  const int mt0 = blockIdx.y * MC;
   const int KT = a.KT, MT = a.MT;
   const int lo = lane * 4;
-
-  f32x4 acc[MC][S];
-#pragma unroll
-  for (int mi = 0; mi < MC; ++mi)
-#pragma unroll
-    for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
   }
-
   const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
+
+  // the wave walks all output chunks of its tile: the B blocks it re-reads stay hot in this CU's L1/L2
+  for (int mt0 = 0; mt0 < MT; mt0 += MC) {
+  f32x4 acc[MC][S];
+#pragma unroll
+  for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
 
   // raw (un-activated) B block and weight blocks of k-tile kt
@@ -157,48 +159,54 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
           for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      act_jet_adj<S1, S2, -1>(a.cfg, pre, acc[mi], ab);
+      act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab);
       constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
+      if (EPI == EPI_ADJ) {
 #pragma unroll
-      for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
+        for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
+        f32x4 H[S];
+        act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
+#pragma unroll
+        for (int st = 0; st < S; ++st) st_R(a.HR + (((size_t)tile * S + st) * MT + mt) * 256, lane, H[st]);
+      } else {
+        st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
+      }
+#pragma unroll
+      for (int st = 0; st < SO; ++st) st_R(a.OutR + (((size_t)tile * SO + st) * MT + mt) * 256, lane, ab[st]);
     }
   }
+  }  // chunk loop
 }
 
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
 static int launch_layer(const LayerArgs& a, hipStream_t stream) {
-  dim3 grid((a.ntiles + 3) / 4, (a.MT + MC - 1) / MC);
+  dim3 grid((a.ntiles + 3) / 4);
   hipLaunchKernelGGL((k_layer<S1, S2, MC, PRO, EPI, ACT, GUARD>), grid, dim3(256), 0, stream, a);
   return stpde_check_launch("k_layer");
 }
 
-template <int S1, int S2, int PRO>
+template <int S1, int S2, int PRO, int EPI>
 static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
   constexpr int MC = 4;
-  if (a.MT % MC != 0) return launch_layer<S1, S2, MC, PRO, EPI_FWD, -1, true>(a, stream);
+  if (a.MT % MC != 0) return launch_layer<S1, S2, MC, PRO, EPI, -1, true>(a, stream);
   switch (a.cfg.act) {
-    case STPDE_ACT_TANH: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_TANH, false>(a, stream);
-    case STPDE_ACT_RELU: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_RELU, false>(a, stream);
-    case STPDE_ACT_SOFTPLUS: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_SOFTPLUS, false>(a, stream);
-    case STPDE_ACT_ELU: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_ELU, false>(a, stream);
-    case STPDE_ACT_LEAKYRELU: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_LEAKYRELU, false>(a, stream);
-    default: return launch_layer<S1, S2, MC, PRO, EPI_FWD, STPDE_ACT_SWISH, false>(a, stream);
+    case STPDE_ACT_TANH: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_TANH, false>(a, stream);
+    case STPDE_ACT_RELU: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_RELU, false>(a, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_SOFTPLUS, false>(a, stream);
+    case STPDE_ACT_ELU: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_ELU, false>(a, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_LEAKYRELU, false>(a, stream);
+    default: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_SWISH, false>(a, stream);
   }
 }
 
 // mode: 0 = fwd (hidden input from stash), 1 = fwd first hidden (layer 0 on the fly), 2 = dgrad, 3 = dgrad into layer 0
 template <int S1, int S2>
 static int launch_mode(const LayerArgs& a, int mode, hipStream_t stream) {
-  constexpr int MC = 4;
   switch (mode) {
-    case 0: return launch_fwd_act<S1, S2, PRO_ACT>(a, stream);
-    case 1: return launch_fwd_act<S1, S2, PRO_L0>(a, stream);
-    case 2:
-      return a.MT % MC == 0 ? launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ, -1, false>(a, stream)
-                            : launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ, -1, true>(a, stream);
-    default:
-      return a.MT % MC == 0 ? launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ_L0, -1, false>(a, stream)
-                            : launch_layer<S1, S2, MC, PRO_NONE, EPI_ADJ_L0, -1, true>(a, stream);
+    case 0: return launch_fwd_act<S1, S2, PRO_ACT, EPI_FWD>(a, stream);
+    case 1: return launch_fwd_act<S1, S2, PRO_L0, EPI_FWD>(a, stream);
+    case 2: return launch_fwd_act<S1, S2, PRO_NONE, EPI_ADJ>(a, stream);
+    default: return launch_fwd_act<S1, S2, PRO_NONE, EPI_ADJ_L0>(a, stream);
   }
 }
 

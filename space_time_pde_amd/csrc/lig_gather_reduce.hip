@@ -55,6 +55,7 @@ struct GatherArgs {
   const float* pts;
   const float* latent;
   float* X;
+  float* XR;
   float* coef;
   int* cell;
 };
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
     v[r] = val;
   }
   st4(a.X + gid * 4, v);
+  if (a.XR) st_R(a.XR + (gid >> 6) * 256, lane, v);
   if (xt == 0 && g == 0 && corner == 0) {
     float* cf = a.coef + (size_t)p * 16;
 #pragma unroll
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
 }
 
 extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X,
-                                float* coef, int* cell, void* stream) {
+                                float* XR, float* coef, int* cell, void* stream) {
   if (!d || d->P <= 0 || (d->P & 1) || d->N <= 0 || d->p_base < 0 || d->B <= 0 || d->n0 < 2 || d->n1 < 2 || d->n2 < 2 || d->C < 1 ||
       3 + d->C + 1 > 16 * XT || !pts || !latent || !X || !coef || !cell) {
     stpde_set_error("lig_gather: bad argument (P even, grid >= 2 per dim, C <= %d)", 16 * XT - 4);
@@ -122,7 +124,7 @@ extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, co
     stpde_set_error("lig_gather: latent grid too large for int32 node index");
     return STPDE_E_BADARG;
   }
-  GatherArgs a{*d, pts, latent, X, coef, cell};
+  GatherArgs a{*d, pts, latent, X, XR, coef, cell};
   const size_t nthreads = (size_t)(d->P / 2) * XT * 64;
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_gather");
@@ -167,6 +169,7 @@ struct ReduceArgs {
   const float* src;  // fwd: out_pre [tile][S][1][256]; bwd: jets_bar [S][n_out][P]
   const float* coef;
   float* dst;  // fwd: jets [S][n_out][P]; bwd: abar_out [tile][S][1][256]
+  float* dstR; // bwd: R-layout copy of abar_out
 };
 
 // one thread per (point, channel)
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   const int j = ((p & 1) << 3) | corner;
   const int lane = ((ch >> 2) << 4) | j;
   float* base = a.dst + (size_t)tile * S * 256 + lane * 4 + (ch & 3);
+  float* baseR = a.dstR + (size_t)tile * S * 256 + 64 * (j >> 2) + 4 * ch + (j & 3);
   float fb[10];
 #pragma unroll
   for (int s = 0; s < 10; ++s) fb[s] = 0.f;
@@ -273,7 +277,10 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   }
 #pragma unroll
   for (int s = 0; s < 10; ++s)
-    if (s < S) base[(size_t)s * 256] = fb[s];
+    if (s < S) {
+      base[(size_t)s * 256] = fb[s];
+      baseR[(size_t)s * 256] = fb[s];
+    }
 }
 
 static int check_reduce(const stpde_jet_cfg* cfg, int P, int n_out, const void* a, const void* b, const void* c) {
@@ -293,21 +300,25 @@ extern "C" int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, 
     stpde_set_error("lig_reduce_fwd: ldp < P");
     return STPDE_E_BADARG;
   }
-  ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets};
+  ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets, nullptr};
   const size_t n = (size_t)P * n_out;
   hipLaunchKernelGGL(k_reduce_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_fwd");
 }
 
 extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
-                                    const float* coef, float* abar_out, void* stream) {
+                                    const float* coef, float* abar_out, float* abar_out_R, void* stream) {
   int rc = check_reduce(cfg, P, n_out, jets_bar, coef, abar_out);
   if (rc) return rc;
+  if (!abar_out_R) {
+    stpde_set_error("lig_reduce_bwd: null abar_out_R");
+    return STPDE_E_BADARG;
+  }
   if (ldp < P) {
     stpde_set_error("lig_reduce_bwd: ldp < P");
     return STPDE_E_BADARG;
   }
-  ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out};
+  ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out, abar_out_R};
   const size_t n = (size_t)P * 128;
   hipLaunchKernelGGL(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_bwd");

@@ -137,6 +137,9 @@ class ImNetPlan:
             d = np.arange(3)
             add("tanc", aug[(16 * mt[None, :, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
                             (16 * KT + d)[:, None, None, None] + 0 * mt[None, :, None, None]])
+            # the same constants in the row-major (R) fragment image: [d][mt][lane][r] = aug[16mt + (lane&15), 16KT + d]
+            add("tancR", aug[(16 * mt[None, :, None, None] + j[None, None, :, None] + 0 * r[None, None, None, :]),
+                             (16 * KT + d)[:, None, None, None] + 0 * mt[None, :, None, None]])
             self.pack_off.append(offs)
             self.dw_off.append((dwo, Mp, Ka))
             dwo += Mp * Ka
@@ -257,7 +260,7 @@ def _layer_desc(ntiles, lay, cfg, first_hidden):
     return d
 
 
-def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
+def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     """Run gather + layers 1..5 + reduce for points [p0, p0+Pc) ; returns the buffers backward needs."""
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
@@ -266,6 +269,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
     nt = Pc // 2
     dev = pts_c.device
     X = torch.empty(nt * XT * _FRAG, device=dev)
+    XR = torch.empty(nt * XT * _FRAG, device=dev) if need_grad else None
     coef = torch.empty(Pc * 16, device=dev)
     cell = torch.empty(Pc, device=dev, dtype=torch.int32)
     gd = GatherDesc()
@@ -275,7 +279,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
         gd.lo_c[k], gd.hi_c[k], gd.cube[k] = meta.lo_c[k], meta.hi_c[k], meta.cube[k]
     gd.p_base = p0
     with _timed("gather"):
-        check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(coef), ptr(cell), st))
+        check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(XR), ptr(coef), ptr(cell), st))
     bufs = [None]
     pv = plan.pack_view
     prev = None
@@ -292,43 +296,52 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0):
     with _timed("reduce_fwd"):
         check(L.stpde_lig_reduce_fwd(C.byref(cfg), Pc, plan.cout, ptr(bufs[5]), ptr(coef),
                                      C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
-    return dict(X=X, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc)
+    return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc)
 
 
 def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
+    """reduce_bwd -> for l = 5..1: dgrad_l (emits the R-layout operands) then wgrad_l -> wgrad_0 -> xbar/scatter."""
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()
     Pc, p0 = saved["Pc"], saved["p0"]
     nt = Pc // 2
-    X, coef, cell, bufs = saved["X"], saved["coef"], saved["cell"], saved["bufs"]
+    X, XR, coef, cell, bufs = saved["X"], saved["XR"], saved["coef"], saved["cell"], saved["bufs"]
     dev = X.device
     pv = plan.pack_view
-    # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer)
+    SP0 = 1 + cfg.S1
+
+    def new(nblocks):
+        return torch.empty(nt * nblocks * _FRAG, device=dev)
+
+    # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer) + its R-layout copy
+    abarR = new(S * plan.layers[5]["MT"])
     with _timed("reduce_bwd"):
         check(L.stpde_lig_reduce_bwd(C.byref(cfg), Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
-                                     jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
-    SP0 = 1 + cfg.S1
-    abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
+                                     jets_bar.shape[2], ptr(coef), ptr(bufs[5]), ptr(abarR), st))
+    abar0 = new(plan.layers[0]["MT"])          # value stream of layer 0's adjoint (column-major), for xbar
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         d = _layer_desc(nt, lay, cfg, l == 1)
         off, mp, ka = plan.dw_off[l]
-        if meta.need_wgrad:
-            with _timed("layer%d_wgrad" % l):
-                check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
-                                        ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tanc")),
-                                        ptr(dw_flat[off:off + mp * ka]), st))
+        nextR = new((S if l > 1 else SP0) * lay["KT"])
+        hinR = new(S * lay["KT"]) if l > 1 else None
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(nextR), ptr(hinR), st))
+        if meta.need_wgrad:
+            with _timed("layer%d_wgrad" % l):
+                check(L.stpde_jet_wgrad(C.byref(d), S, ptr(abarR), ptr(hinR), ptr(X), ptr(XR),
+                                        ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
+                                        ptr(dw_flat[off:off + mp * ka]), st))
+        abarR = nextR
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
         off, mp, ka = plan.dw_off[0]
         with _timed("layer0_wgrad"):
-            check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), None, None,
+            check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abarR), None, ptr(X), ptr(XR), None, None,
                                     ptr(dw_flat[off:off + mp * ka]), st))
     if dlatent is not None:
         xd = XbarDesc()
@@ -338,7 +351,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
         wt = (C.c_void_p * 5)()
         for l in range(5):
             xd.MT[l] = plan.layers[l]["MT"]
-            xd.SP[l] = SP0 if l == 0 else S
+            xd.SP[l] = 1 if l == 0 else S
             ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
             wt[l] = pv(packs, l, "WsT").data_ptr()
         with _timed("xbar_scatter"):
@@ -357,7 +370,7 @@ class LigJetFunction(torch.autograd.Function):
         saved = []
         chunk = meta.chunk
         for p0 in range(0, P, chunk):
-            s = _forward_chunk(meta, packs, latent, pts[p0:p0 + chunk], jets, p0)
+            s = _forward_chunk(meta, packs, latent, pts[p0:p0 + chunk], jets, p0, need_grad)
             if need_grad:
                 saved.append(s)
         ctx.meta, ctx.packs, ctx.saved = meta, packs, saved
