@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
@@ -51,7 +51,7 @@ def _sources():
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into libstpde_hip.so (cross-compiles without a GPU)."""
     srcs = _sources()
-    deps = srcs + [os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "jet_layer_impl.h"), os.path.join(_HERE, "..", "include", "stpde_hip.h")]
+    deps = srcs + [os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "jet_layer_impl.h"), os.path.join(_CSRC, "jet_wgrad_impl.h"), os.path.join(_HERE, "..", "include", "stpde_hip.h")]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(p) for p in deps if os.path.exists(p))
         if os.path.getmtime(LIB_PATH) >= newest:

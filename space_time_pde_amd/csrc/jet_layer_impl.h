@@ -185,10 +185,8 @@ static int launch_layer(const LayerArgs& a, hipStream_t stream) {
   return stpde_check_launch("k_layer");
 }
 
-template <int S1, int S2, int PRO, int EPI>
-static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
-  constexpr int MC = 4;
-  if (a.MT % MC != 0) return launch_layer<S1, S2, MC, PRO, EPI, -1, true>(a, stream);
+template <int S1, int S2, int PRO, int EPI, int MC>
+static int launch_fwd_act_mc(const LayerArgs& a, hipStream_t stream) {
   switch (a.cfg.act) {
     case STPDE_ACT_TANH: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_TANH, false>(a, stream);
     case STPDE_ACT_RELU: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_RELU, false>(a, stream);
@@ -197,6 +195,15 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
     case STPDE_ACT_LEAKYRELU: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_LEAKYRELU, false>(a, stream);
     default: return launch_layer<S1, S2, MC, PRO, EPI, STPDE_ACT_SWISH, false>(a, stream);
   }
+}
+
+template <int S1, int S2, int PRO, int EPI>
+static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
+  if (a.MT % 4 != 0) return launch_layer<S1, S2, 4, PRO, EPI, -1, true>(a, stream);
+  // kernels that stream their B operand from memory (everything except the layer-0-on-the-fly forward) halve that
+  // traffic with 8 output tiles per pass; S=10 would not fit the register file
+  if (PRO != PRO_L0 && S1 + S2 <= 5 && a.MT % 8 == 0) return launch_fwd_act_mc<S1, S2, PRO, EPI, 8>(a, stream);
+  return launch_fwd_act_mc<S1, S2, PRO, EPI, 4>(a, stream);
 }
 
 // mode: 0 = fwd (hidden input from stash), 1 = fwd first hidden (layer 0 on the fly), 2 = dgrad, 3 = dgrad into layer 0
