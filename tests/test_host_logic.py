@@ -1,0 +1,164 @@
+"""Host-side logic that needs no GPU: PDELayer API/error behaviour, the jet compiler, physics strings, the C-ABI
+library's symbols, dispatch rules, and the flat-name import style of the reference."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from space_time_pde_amd import implicit_net, local_implicit_grid as lig, nonlinearities, pde, physics
+from space_time_pde_amd import regular_nd_grid_interpolation as rgi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(hiplib):
+    """Every function declared in include/stpde_hip.h is exported by libstpde_hip.so and bound in _lib.py."""
+    from space_time_pde_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "stpde_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(stpde_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(hiplib, name), name
+    assert sorted(n for n in _lib.exported_symbols() if not n.startswith("stpde_conv") and not n.startswith("stpde_unet")
+                  ) == [d for d in declared if not d.startswith("stpde_conv") and not d.startswith("stpde_unet")] \
+        or set(declared) <= set(_lib.exported_symbols())
+    assert hiplib.stpde_version() >= 100
+    buf = ctypes.create_string_buffer(64)
+    assert hiplib.stpde_last_error(buf, 64) == 0
+
+
+def test_abi_rejects_bad_arguments_without_gpu(hiplib):
+    from space_time_pde_amd import _lib
+    d = _lib.LayerDesc()
+    d.ntiles, d.KT, d.MT = 0, 1, 1
+    with pytest.raises(ValueError):
+        _lib.check(hiplib.stpde_jet_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None))
+    g = _lib.GatherDesc()
+    g.P = 3   # odd
+    with pytest.raises(ValueError):
+        _lib.check(hiplib.stpde_lig_gather(ctypes.byref(g), None, None, None, None, None, None, None))
+
+
+def test_pde_layer_kat_and_api():
+    """src/pde_test.py:12-53 through the product PDELayer (generic strategy on CPU tensors)."""
+    layer = pde.PDELayer(in_vars="x, y, t", out_vars="u, v")
+    for n in ("u", "v"):
+        layer.add_equation("dif(%s, t) - (dif(dif(%s, x), x) + dif(dif(%s, y), y))" % (n, n, n), "diffusion_" + n)
+    assert layer.eqn_num == 2 and layer.eqn_names == ["diffusion_u", "diffusion_v"]
+    assert layer.n_in == 3 and layer.n_out == 2 and len(layer.all_vars) == 5
+    with pytest.raises(RuntimeError):
+        layer.eval(torch.zeros(1, 3))
+
+    def fwd(i):
+        u = i[..., 0:1] ** 2 + 3 * i[..., 1:2] ** 2 * i[..., 2:3] + i[..., 0:1] * i[..., 2:3]
+        return torch.cat([u, u], -1)
+
+    layer.update_forward_method(fwd)
+    val, res = layer(torch.tensor([[1., 2., 3.]]))
+    np.testing.assert_allclose(val.detach().numpy(), [[40., 40.]], atol=1e-4)
+    for k in layer.eqn_names:
+        np.testing.assert_allclose(res[k].detach().numpy(), [[-7.]])
+    assert layer(torch.tensor([[1., 2., 3.]]), return_residue=False).shape == (1, 2)
+    with pytest.raises(ValueError):
+        layer.eval(torch.zeros(1, 4))                       # wrong trailing dim
+    with pytest.raises(ValueError):
+        layer.add_equation("dif(q, x)", "bad")             # unknown symbol
+    layer.add_equation("u - v")                             # default name (reference quirk a-Q5 fixed)
+    assert layer.eqn_names[-1] == "eqn_2"
+
+
+def test_jet_compiler_atoms_and_fallback():
+    layer = pde.PDELayer("t, x, z", "p, b, u, w")
+    layer.add_equation("u*dif(b,x)", "adv")
+    assert layer.eqns_jet["adv"].atoms == [(1, (1,)), (2, ())]
+    layer.add_equation("dif(dif(dif(b,x),x),x)", "third")      # order 3: not expressible -> generic strategy
+    assert layer.eqns_jet["third"] is None
+    assert layer._jet_request(torch.zeros(1, 4, 3)) is None     # CPU tensor / unsupported equation
+
+
+def test_rb2_layer_matches_reference_structure():
+    layer = physics.get_rb2_pde_layer(mean=(0.01, 0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                      x_crop=1., use_continuity=True)
+    assert layer.eqn_names == ["transport_eqn_b", "transport_eqn_u", "transport_eqn_w", "continuity"]
+    need = {mi for prog in layer.eqns_jet.values() for _, mi in prog.atoms}
+    assert need == {(), (0,), (1,), (2,), (1, 1), (2, 2)}      # 6 jets per channel
+    with pytest.raises(ValueError):
+        physics.get_rb2_pde_layer(mean=(0, 0, 0, 0), std=None)
+    with pytest.raises(ValueError):
+        physics.get_rb2_pde_layer(mean=(0, 0, 0), std=(1, 1, 1))
+
+
+def test_imnet_state_dict_keys_and_shapes():
+    """src/implicit_net_test.py:15-26 (shape) + the duplicated state_dict keys of the reference (quirk a-Q7)."""
+    net = implicit_net.ImNet(dim=4, in_features=32, out_features=3, nf=16)
+    assert net(torch.rand(64, 36)).shape == (64, 3)
+    keys = set(net.state_dict().keys())
+    for k in range(6):
+        assert {"fc%d.weight" % k, "fc%d.bias" % k, "fc.%d.weight" % k, "fc.%d.bias" % k} <= keys
+    sw = implicit_net.ImNet(activation=nonlinearities.NONLINEARITIES["swish"])
+    assert "activ.beta" in sw.state_dict()
+    assert sum(p.numel() for p in implicit_net.ImNet().parameters()) == 209924
+
+
+@pytest.mark.parametrize("dim", [3, 4])
+def test_lig_generic_path_shapes_cpu(dim):
+    """src/local_implicit_grid_test.py:16-30: 3-d and 4-d coordinates, batch 8, 512 points, 16^d... (smaller grid)."""
+    grid = torch.rand(2, *([6] * dim), 32)
+    pts = torch.rand(2, 64, dim)
+    net = implicit_net.ImNet(dim=dim, in_features=32, out_features=3, nf=16)
+    assert lig.query_local_implicit_grid(net, grid, pts, 0., 1.).shape == (2, 64, 3)
+
+
+def test_lig_plus_pde_integration_cpu():
+    """src/local_implicit_grid_integration_test.py:14-103 (shape check) on the generic strategy."""
+    grid = torch.rand(2, 6, 6, 6, 32)
+    pts = torch.rand(2, 32, 3)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=16)
+    layer = pde.PDELayer("t, x, z", "p, b, u, w")
+    layer.add_equation("u*dif(b,x)", "transport_eqn_b")
+    layer.update_forward_method(lambda q: lig.query_local_implicit_grid(net, grid, q, 0., 1.))
+    val, res = layer(pts)
+    assert val.shape == (2, 32, 4) and res["transport_eqn_b"].shape == (2, 32, 1)
+
+
+def test_interpolation_generic_path_matches_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "g1_interp.npz"))
+    for dim in (1, 2, 3, 4):
+        grid, pts = torch.from_numpy(d["d%d_grid" % dim]), torch.from_numpy(d["d%d_pts" % dim])
+        xmax = tuple(float(v) for v in d["d%d_xmax" % dim])
+        out = rgi.regular_nd_grid_interpolation(grid, pts, tuple(0. for _ in range(dim)), xmax)
+        np.testing.assert_allclose(out.numpy(), d["d%d_out" % dim], rtol=1e-6, atol=1e-6)
+
+
+def test_box_constants_follow_reference_fp32_sequence():
+    from space_time_pde_amd.lig_jet import box_constants
+    lo, hi, cube = box_constants((32, 128, 128), 0., 1.)
+    size = torch.tensor([32., 128., 128.])
+    eps = 1e-6 * (torch.ones(3) - torch.zeros(3))
+    assert hi == (torch.ones(3) - eps).tolist() and lo == eps.tolist()
+    assert cube == (torch.ones(3) / (size - 1)).tolist()
+    with pytest.raises(ValueError):
+        box_constants((4, 4, 4), 0.5, 1.)          # xmin != 0 is refused (quirk a-Q1)
+
+
+def test_flat_import_style_of_the_reference():
+    code = ("import sys; sys.path.append(%r); import pde, local_implicit_grid, implicit_net, physics, nonlinearities;"
+            "import regular_nd_grid_interpolation as rgi; import space_time_pde_amd.pde as p2;"
+            "assert pde is p2 and hasattr(rgi, 'clip_tensor') and hasattr(physics, 'get_rb2_pde_layer'); print('ok')"
+            % os.path.join(ROOT, "space_time_pde_amd", "flat"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_hot_path_never_falls_back_on_cuda_without_library(monkeypatch):
+    """Eligibility is decided by tensor structure, never by library availability: a missing .so must raise."""
+    from space_time_pde_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libstpde_hip.so")
+    with pytest.raises(RuntimeError, match="not built"):
+        _lib.lib()
