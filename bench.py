@@ -3,11 +3,13 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over one batch of synthetic input (experiments/rb2d/train.py:58-77 of the
-reference): latent grid -> local-implicit-grid gather -> IM-NET on every query point with the RB2 residual
-derivatives -> L1 losses -> backward to all IM-NET parameters and the latent grid.  Workload = BASELINE.json
-configs[1]: latent grid [1, 32, 128, 128, 32] (T, Z, X, C), 2^20 query points, full Rayleigh-Benard PDE set
-(3 transport equations + continuity), fp32.  With N GPUs the SAME 2^20 points are sharded across ranks
-(strong scaling); gradients are summed with one RCCL all-reduce.
+reference): UNet3d encoder -> latent grid -> local-implicit-grid gather -> IM-NET on every query point with the RB2
+residual derivatives -> L1 losses -> backward to all IM-NET and UNet parameters.  Workload = BASELINE.json
+configs[1]: input crop [1, 4, 32, 128, 128], latent grid [1, 32, 128, 128, 32] (T, Z, X, C), 2^20 query points,
+full Rayleigh-Benard PDE set (3 transport equations + continuity), fp32.  With N GPUs the SAME 2^20 points are
+sharded across ranks (strong scaling): every rank runs the (cheap, deterministic) UNet on the same crop, the
+partial d(loss)/d(latent grid) and the IM-NET gradients are summed with RCCL all-reduces, and the UNet backward
+is replicated.
 
 Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (dominant kernel, HIP-event timed) and
 ``cpu_baseline`` (the CPU oracle = restatement of the reference path, timed on the host cores on a bounded
@@ -51,10 +53,25 @@ def algorithmic_macs(nf=32, cin=32, cout=4, n_first=3, n_second=2):
 
 def make_inputs(n_pts, dev, seed=0):
     g = torch.Generator().manual_seed(seed)
-    latent = (0.5 * torch.randn(1, 32, 128, 128, 32, generator=g)).to(dev)
+    crop = torch.randn(1, 4, 32, 128, 128, generator=g).to(dev)
     pts = torch.rand(1, n_pts, 3, generator=g).to(dev)
     tgt = torch.randn(1, n_pts, 4, generator=g).to(dev)
-    return latent, pts, tgt
+    return crop, pts, tgt
+
+
+class _SumAcrossRanks(torch.autograd.Function):
+    """Identity in forward; sums the incoming gradient over all ranks in backward (RCCL all-reduce over xGMI)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.contiguous()
+        dist.all_reduce(g)
+        return g
 
 
 def cpu_baseline(act, chunk=4096, nchunks=3):
@@ -102,30 +119,39 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics
+    from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
 
     torch.manual_seed(1)
     net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
                              activation=nonlinearities.NONLINEARITIES[args.act]).to(dev)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(32, 128, 128), nf=16, mf=256).to(dev)
+    unet.train()
     params = [p for p in net.parameters()]
+    uparams = [p for p in unet.parameters()]
     if world > 1:
-        for p in params:
+        for p in params + uparams:
             dist.broadcast(p.data, 0)
-    latent0, pts_all, tgt_all = make_inputs(args.points, dev)
+    crop, pts_all, tgt_all = make_inputs(args.points, dev)
     n_local = args.points // world
     pts = pts_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
     tgt = tgt_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
     del pts_all, tgt_all
     layer = physics.get_rb2_pde_layer(**RB2)
     n_eq = layer.eqn_num
-    latent = latent0.clone().requires_grad_(True)
-    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, latent, p, 0., 1.))
     lig_jet.DEFAULT_CHUNK = args.chunk
+    uev = []
 
     def step():
-        for p in params:
+        for p in params + uparams:
             p.grad = None
-        latent.grad = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        latent = unet(crop).permute(0, 2, 3, 4, 1)          # train.py:58-60 (free view: channels-last output)
+        e1.record()
+        uev.append((e0, e1))
+        if world > 1:
+            latent = _SumAcrossRanks.apply(latent)
+        layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, latent, p, 0., 1.))
         pred, res = layer(pts, return_residue=True)
         # L1 losses normalised by the GLOBAL counts so that the sharded sum equals the single-GPU mean
         reg = (pred - tgt).abs().sum() / (args.points * 4)
@@ -134,8 +160,8 @@ def main():
         loss = ALPHA_REG * reg + ALPHA_PDE * pde_loss
         loss.backward()
         if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params] + [latent.grad.reshape(-1)])
-            dist.all_reduce(flat)
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)                           # IM-NET gradients (0.84 MB); UNet grads are replicated
         return loss
 
     def sync():
@@ -167,6 +193,7 @@ def main():
         fwd_flop_pt = 2 * 8 * (M + (5 if smooth else 3) * T)
         step_flop_pt = 3 * fwd_flop_pt
         kern = {}
+        prof["unet_fwd"] = uev[-args.steps:]
         for name, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             kern[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
@@ -195,10 +222,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: latent [1,32,128,128,32], 2^%d query points, RB2 "
-                                   "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + latent grid"
+                                   "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + UNet3d parameters"
                                    % (args.points.bit_length() - 1, args.act),
                        "points": args.points, "parallelism": "points sharded x%d" % world,
-                       "unet": "not in the timed step yet (latent grid is the leaf)", "loss": float(loss)},
+                       "unet": "UNet3d(igres=(32,128,128), nf=16, mf=256) fwd+bwd inside the timed step", "loss": float(loss.detach())},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

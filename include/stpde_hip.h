@@ -141,6 +141,19 @@ int stpde_interp_fwd(const stpde_interp_desc* d, const float* grid, const float*
 int stpde_interp_bwd_grid(const stpde_interp_desc* d, const float* pts, const float* out_bar,
                           const float* corner_bar, float* dgrid, void* stream);
 
+/* ---- a10: 3-D convolution of the U-Net encoder (src/unet3d.py:39-56: nn.Conv3d 1x1x1 and 3x3x3/pad 1, stride 1)
+ * Activations are channels-last: x [B][T][Z][X][Ci], y [B][T][Z][X][Co], Ci and Co multiples of 16.
+ * Implicit GEMM on v_mfma_f32_16x16x4_f32: y^T[Co x 16 voxels] = sum_tap W_tap[Co x Ci] * x_tap^T[Ci x 16 voxels].
+ * w_pack [taps][Ci/16][Co/16][64][4] (A-operand image of W[:, :, tap]); bias [Co] or NULL.
+ * The input-gradient is the same kernel called with the transposed, tap-flipped pack (no bias). */
+typedef struct {
+  int B, T, Z, X, Ci, Co, ksize; /* ksize 1 or 3 */
+} stpde_conv3d_desc;
+int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_pack, const float* bias, float* y,
+                     void* stream);
+/* dW[tap][Co][Ci] += sum_voxels ybar[v][co] * x[v + offset(tap)][ci]  (fp32 atomics; caller zero-fills dW). */
+int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

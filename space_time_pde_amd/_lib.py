@@ -39,6 +39,11 @@ class XbarDesc(C.Structure):
                 ("MT", C.c_int * 8), ("SP", C.c_int * 8)]
 
 
+class Conv3dDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Z", C.c_int), ("X", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
+                ("ksize", C.c_int)]
+
+
 class InterpDesc(C.Structure):
     _fields_ = [("P", C.c_int), ("N", C.c_int), ("B", C.c_int), ("dim", C.c_int), ("C", C.c_int),
                 ("n", C.c_int * 4), ("lo_c", C.c_float * 4), ("hi_c", C.c_float * 4), ("cube", C.c_float * 4)]
@@ -98,6 +103,8 @@ _SIGNATURES = {
     "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),
     "stpde_interp_fwd": ([C.POINTER(InterpDesc)] + [_VP] * 7, C.c_int),
     "stpde_interp_bwd_grid": ([C.POINTER(InterpDesc)] + [_VP] * 5, C.c_int),
+    "stpde_conv3d_fwd": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),
+    "stpde_conv3d_wgrad": ([C.POINTER(Conv3dDesc)] + [_VP] * 4, C.c_int),
 }
 
 

@@ -1,0 +1,208 @@
+// 3-D convolutions of the U-Net encoder (src/unet3d.py:39-56 of the reference: Conv3d 1x1x1 and 3x3x3, padding 1,
+// stride 1) as implicit GEMMs on v_mfma_f32_16x16x4_f32 over channels-last activations [B][T][Z][X][C].
+//
+// Forward / input-gradient: each wave owns 16 consecutive voxels and walks all output-channel tiles:
+//   y^T[16co x 16 vox] += W_tap[16co x 16ci] * x_tap^T[16ci x 16 vox]
+// A operand = packed weights (float4 per lane per (tap, ci-tile, co-tile)), B operand = one float4 per lane straight
+// from channels-last memory (lane 16g+j: channels 4g..4g+3 of voxel j, zero outside the volume), D = float4 store
+// back to channels-last memory.  No im2col buffer, no LDS.
+// Weight gradient: contraction over voxels, operands are dword loads (lane 16k+i: voxel 4s+k, channel i).
+#include "common.h"
+
+struct ConvArgs {
+  stpde_conv3d_desc d;
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  const float* ybar;
+  float* dW;
+  int nvox, gx;
+};
+
+struct Vox {
+  int b, t, z, x;
+};
+
+__device__ __forceinline__ Vox vox_coords(const stpde_conv3d_desc& d, int v) {
+  Vox c;
+  c.x = v % d.X;
+  int r = v / d.X;
+  c.z = r % d.Z;
+  r /= d.Z;
+  c.t = r % d.T;
+  c.b = r / d.T;
+  return c;
+}
+
+// flattened index of the tap neighbour of voxel c, or -1 outside the volume
+__device__ __forceinline__ int tap_neighbour(const stpde_conv3d_desc& d, const Vox& c, int tap) {
+  if (d.ksize == 1) return ((c.b * d.T + c.t) * d.Z + c.z) * d.X + c.x;
+  const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+  const int t = c.t + dt, z = c.z + dz, x = c.x + dx;
+  if (t < 0 || t >= d.T || z < 0 || z >= d.Z || x < 0 || x >= d.X) return -1;
+  return ((c.b * d.T + t) * d.Z + z) * d.X + x;
+}
+
+template <int MC>
+__global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile * 16 >= a.nvox) return;
+  const int g = lane >> 4, j = lane & 15;
+  const int lo = lane * 4;
+  const int Ci = a.d.Ci, Co = a.d.Co, KT = Ci / 16, MT = Co / 16;
+  const int ntap = a.d.ksize == 3 ? 27 : 1;
+  const int v = tile * 16 + j;
+  const bool vin = v < a.nvox;
+  const Vox c = vox_coords(a.d, vin ? v : 0);
+  for (int mt0 = 0; mt0 < MT; mt0 += MC) {
+    f32x4 acc[MC];
+#pragma unroll
+    for (int mi = 0; mi < MC; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < ntap; ++tap) {
+      const int nb = vin ? tap_neighbour(a.d, c, tap) : -1;
+      const float* src = a.x + (size_t)(nb < 0 ? 0 : nb) * Ci + 4 * g;
+      for (int kt = 0; kt < KT; ++kt) {
+        f32x4 B = ld4(src + 16 * kt);
+        if (nb < 0) B = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wp = a.w + ((size_t)(tap * KT + kt) * MT + mt0) * 256 + lo;
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          const int mic = mt0 + mi < MT ? mi : 0;
+          f32x4 w = ld4(wp + (size_t)mic * 256);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi] = mfma4(w[r], B[r], acc[mi]);
+        }
+      }
+    }
+    if (vin) {
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) {
+        const int mt = mt0 + mi;
+        if (mt >= MT) continue;
+        f32x4 o = acc[mi];
+        if (a.bias) o += ld4(a.bias + 16 * mt + 4 * g);
+        st4(a.y + (size_t)v * Co + 16 * mt + 4 * g, o);
+      }
+    }
+  }
+}
+
+// one wave per (tap, co-tile block, ci-tile block), striding over voxel tiles; dW[tap][co][ci]
+template <int MCW, int KCW>
+__global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int kk = lane >> 4, i = lane & 15;
+  const int Ci = a.d.Ci, Co = a.d.Co, KT = Ci / 16, MT = Co / 16;
+  const int nmb = (MT + MCW - 1) / MCW, nkb = (KT + KCW - 1) / KCW;
+  int id = blockIdx.y;
+  const int kb = id % nkb;
+  id /= nkb;
+  const int mb = id % nmb;
+  const int tap = id / nmb;
+  f32x4 acc[MCW][KCW];
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+    for (int ki = 0; ki < KCW; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (a.nvox + 15) / 16;
+  for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int v = tile * 16 + 4 * s + kk;
+      const bool vin = v < a.nvox;
+      const Vox c = vox_coords(a.d, vin ? v : 0);
+      const int nb = vin ? tap_neighbour(a.d, c, tap) : -1;
+      float pa[MCW], qb[KCW];
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) {
+        const int mt = mb * MCW + mi;
+        pa[mi] = (vin && mt < MT) ? a.ybar[(size_t)v * Co + 16 * mt + i] : 0.f;
+      }
+#pragma unroll
+      for (int ki = 0; ki < KCW; ++ki) {
+        const int kt = kb * KCW + ki;
+        qb[ki] = (nb >= 0 && kt < KT) ? a.x[(size_t)nb * Ci + 16 * kt + i] : 0.f;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+        for (int ki = 0; ki < KCW; ++ki) acc[mi][ki] = mfma4(pa[mi], qb[ki], acc[mi][ki]);
+    }
+  }
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi) {
+    const int mt = mb * MCW + mi;
+    if (mt >= MT) continue;
+#pragma unroll
+    for (int ki = 0; ki < KCW; ++ki) {
+      const int kt = kb * KCW + ki;
+      if (kt >= KT) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(a.dW + ((size_t)tap * Co + 16 * mt + 4 * g + r) * Ci + 16 * kt + c, acc[mi][ki][r]);
+    }
+  }
+}
+
+static int check_conv(const stpde_conv3d_desc* d) {
+  if (!d || d->B < 1 || d->T < 1 || d->Z < 1 || d->X < 1 || d->Ci < 16 || d->Co < 16 || (d->Ci & 15) || (d->Co & 15) ||
+      (d->ksize != 1 && d->ksize != 3)) {
+    stpde_set_error("conv3d: bad descriptor (channels must be multiples of 16, ksize 1 or 3)");
+    return STPDE_E_BADARG;
+  }
+  if ((size_t)d->B * d->T * d->Z * d->X >= (1u << 31) / 16) {
+    stpde_set_error("conv3d: volume too large for int32 voxel indices");
+    return STPDE_E_BADARG;
+  }
+  return STPDE_OK;
+}
+
+extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_pack, const float* bias,
+                                float* y, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!x || !w_pack || !y) {
+    stpde_set_error("conv3d_fwd: null pointer");
+    return STPDE_E_BADARG;
+  }
+  ConvArgs a{};
+  a.d = *d;
+  a.x = x;
+  a.w = w_pack;
+  a.bias = bias;
+  a.y = y;
+  a.nvox = d->B * d->T * d->Z * d->X;
+  const int ntiles = (a.nvox + 15) / 16;
+  hipLaunchKernelGGL(k_conv3d_fwd<4>, dim3((ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_conv3d_fwd");
+}
+
+extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW,
+                                  void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!x || !ybar || !dW) {
+    stpde_set_error("conv3d_wgrad: null pointer");
+    return STPDE_E_BADARG;
+  }
+  ConvArgs a{};
+  a.d = *d;
+  a.x = x;
+  a.ybar = ybar;
+  a.dW = dW;
+  a.nvox = d->B * d->T * d->Z * d->X;
+  constexpr int MCW = 2, KCW = 2;
+  const int ntap = d->ksize == 3 ? 27 : 1;
+  const int nmb = (d->Co / 16 + MCW - 1) / MCW, nkb = (d->Ci / 16 + KCW - 1) / KCW;
+  const int gy = ntap * nmb * nkb;
+  const int ntiles = (a.nvox + 15) / 16;
+  int gx = 2048 / gy;
+  if (gx < 1) gx = 1;
+  if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+  hipLaunchKernelGGL((k_conv3d_wgrad<MCW, KCW>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_conv3d_wgrad");
+}

@@ -1,0 +1,282 @@
+"""3-D U-Net latent-grid encoder (mirrors src/unet3d.py:12-240 of the reference: same constructor arguments,
+submodule names and state_dict keys, so reference checkpoints load).
+
+On CUDA tensors every convolution (1x1x1 and 3x3x3) runs in the HIP implicit-GEMM kernels of libstpde_hip
+(``stpde_conv3d_fwd`` for forward and input-gradient, ``stpde_conv3d_wgrad`` for the weight gradient) on
+channels-last activations [B, T, Z, X, C]; the network output is returned as a channels-last *view* of logical
+shape [B, C, T, Z, X], so the ``latent_grid.permute(0, 2, 3, 4, 1)`` of experiments/rb2d/train.py:60 is a free
+contiguous view that feeds the local-implicit-grid kernels directly.  BatchNorm / ReLU / pooling / nearest
+upsampling / concatenation are elementwise-or-copy plumbing done with torch ops on the same layout (they are
+<1% of the step; fusing them into the conv epilogues is listed as next work in DESIGN.md).
+``Encoder3d`` of the reference (src/unet3d.py:243-344) is dead code there and is not provided.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+# pylint: disable=invalid-name, too-many-instance-attributes, arguments-differ, too-many-arguments
+
+_idx_cache = {}
+
+
+def _pack_indices(co, ci, k, device):
+    """Index maps from a flattened Conv3d weight [co, ci, k, k, k] (+ one trailing zero) to the A-operand packs of
+    the forward conv and of the input-gradient conv (transposed, taps flipped)."""
+    key = (co, ci, k, str(device))
+    if key in _idx_cache:
+        return _idx_cache[key]
+    ntap = k ** 3
+    cip, cop = (ci + 15) // 16 * 16, (co + 15) // 16 * 16
+    zero = co * ci * ntap
+    lane = np.arange(64)
+    g, j = lane >> 4, lane & 15
+    r = np.arange(4)
+
+    def widx(o, i, t):
+        ok = (o < co) & (i < ci)
+        return np.where(ok, (np.minimum(o, co - 1) * ci + np.minimum(i, ci - 1)) * ntap + t, zero)
+
+    tap = np.arange(ntap)[:, None, None, None, None]
+    # forward: [tap][kt][mt][lane][r] = W[16mt + j][16kt + 4g + r][tap]
+    kt = np.arange(cip // 16)[None, :, None, None, None]
+    mt = np.arange(cop // 16)[None, None, :, None, None]
+    fwd = widx(16 * mt + j[None, None, None, :, None], 16 * kt + 4 * g[None, None, None, :, None] + r, tap)
+    # dgrad: out channels = ci, in channels = co: [tap'][kt'][mt'][lane][r] = W[16kt' + 4g + r][16mt' + j][ntap-1-tap']
+    ktd = np.arange(cop // 16)[None, :, None, None, None]
+    mtd = np.arange(cip // 16)[None, None, :, None, None]
+    bwd = widx(16 * ktd + 4 * g[None, None, None, :, None] + r, 16 * mtd + j[None, None, None, :, None] + 0 * r,
+               ntap - 1 - tap)
+    out = (torch.from_numpy(fwd.reshape(-1)).to(device), torch.from_numpy(bwd.reshape(-1)).to(device), cip, cop)
+    _idx_cache[key] = out
+    return out
+
+
+def _desc(x, ci, co, k):
+    d = _lib.Conv3dDesc()
+    d.B, d.T, d.Z, d.X = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+    d.Ci, d.Co, d.ksize = ci, co, k
+    return d
+
+
+class _Conv3dHip(torch.autograd.Function):
+    """y = conv3d(x, weight, bias), stride 1, padding (k-1)/2, on channels-last x [B,T,Z,X,Ci]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        L = _lib.lib()
+        co, ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        fidx, bidx, cip, cop = _pack_indices(co, ci, k, x.device)
+        if cop != co:
+            raise NotImplementedError("HIP conv3d needs out_channels to be a multiple of 16 (got %d)" % co)
+        wflat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
+        xin = x.detach()
+        if cip != ci:
+            xin = F.pad(xin, (0, cip - ci))
+        xin = xin.contiguous()
+        y = torch.empty(x.shape[:-1] + (co,), device=x.device, dtype=torch.float32)
+        d = _desc(xin, cip, co, k)
+        _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(xin), _lib.ptr(wflat[fidx]),
+                                      _lib.ptr(bias.detach().contiguous()) if bias is not None else None,
+                                      _lib.ptr(y), _lib.stream_ptr()))
+        ctx.save_for_backward(xin, wflat)
+        ctx.meta = (co, ci, k, cip, bidx, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xin, wflat = ctx.saved_tensors
+        co, ci, k, cip, bidx, has_bias = ctx.meta
+        gy = gy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.empty(xin.shape, device=gy.device, dtype=torch.float32)
+            d = _desc(gy, co, cip, k)
+            _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(gy), _lib.ptr(wflat[bidx]), None, _lib.ptr(dxp),
+                                          _lib.stream_ptr()))
+            dx = dxp[..., :ci] if cip != ci else dxp
+        if ctx.needs_input_grad[1]:
+            ntap = k ** 3
+            dwt = torch.zeros(ntap, co, cip, device=gy.device, dtype=torch.float32)
+            d = _desc(xin, cip, co, k)
+            _lib.check(L.stpde_conv3d_wgrad(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt), _lib.stream_ptr()))
+            dw = dwt[:, :, :ci].permute(1, 2, 0).reshape(co, ci, k, k, k)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = gy.reshape(-1, co).sum(0)
+        return dx, dw, db
+
+
+def _conv_cl(x, conv):
+    """Apply an nn.Conv3d (1x1x1 or 3x3x3/pad 1, stride 1) to a channels-last tensor [B,T,Z,X,C]."""
+    if x.is_cuda:
+        return _Conv3dHip.apply(x, conv.weight, conv.bias)
+    y = F.conv3d(x.permute(0, 4, 1, 2, 3), conv.weight, conv.bias, padding=conv.padding)
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _bn_cl(x, bn):
+    """nn.BatchNorm3d semantics (batch statistics in training, running-stat update) on channels-last data."""
+    shp = x.shape
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y = F.batch_norm(x.reshape(-1, shp[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
+    return y.reshape(shp)
+
+
+def _pool_cl(x, kernel):
+    if all(int(k) == 1 for k in kernel):
+        return x
+    y = F.max_pool3d(x.permute(0, 4, 1, 2, 3), tuple(int(k) for k in kernel))
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _upsample_cl(x, factors):
+    for dim, f in zip((1, 2, 3), factors):
+        if int(f) != 1:
+            x = x.repeat_interleave(int(f), dim=dim)
+    return x
+
+
+class ResBlock3D(nn.Module):
+    """3D convolutional residue block, keeps the resolution (reference :12-56)."""
+
+    def __init__(self, in_channels, neck_channels, out_channels, final_relu=True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.neck_channels = neck_channels
+        self.out_channels = out_channels
+        self.conv1 = nn.Conv3d(in_channels, neck_channels, kernel_size=1, stride=1)
+        self.conv2 = nn.Conv3d(neck_channels, neck_channels, kernel_size=3, stride=1, padding=1)
+        self.conv3 = nn.Conv3d(neck_channels, out_channels, kernel_size=1, stride=1)
+        self.bn1 = nn.BatchNorm3d(num_features=neck_channels)
+        self.bn2 = nn.BatchNorm3d(num_features=neck_channels)
+        self.bn3 = nn.BatchNorm3d(num_features=out_channels)
+        self.shortcut = nn.Conv3d(in_channels, out_channels, kernel_size=1, stride=1)
+        self.final_relu = final_relu
+
+    def forward_cl(self, x):
+        """Channels-last in, channels-last out: conv1-bn1-relu-conv2-bn2-relu-conv3-bn3 + shortcut (+relu)."""
+        h = F.relu(_bn_cl(_conv_cl(x, self.conv1), self.bn1))
+        h = F.relu(_bn_cl(_conv_cl(h, self.conv2), self.bn2))
+        h = _bn_cl(_conv_cl(h, self.conv3), self.bn3)
+        h = h + _conv_cl(x, self.shortcut)
+        return F.relu(h) if self.final_relu else h
+
+    def forward(self, x):  # [B, C, T, Z, X] -> [B, C', T, Z, X] (channels-last view)
+        return self.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous()).permute(0, 4, 1, 2, 3)
+
+
+class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
+    """3D U-Net with residual blocks (reference :59-240)."""
+
+    def __init__(self, in_features=4, out_features=32, igres=(4, 32, 32), ogres=None, nf=16, mf=512):
+        super().__init__()
+        self.igres = igres
+        self.nf = nf
+        self.mf = mf
+        self.in_features = in_features
+        self.out_features = out_features
+        self.ogres = self.igres if ogres is None else ogres
+        if isinstance(self.igres, int):
+            self.igres = tuple([self.igres] * 3)
+        if isinstance(self.ogres, int):
+            self.ogres = tuple([self.ogres] * 3)
+        self._check_grid_res()
+        fac = np.log2(np.array(self.ogres) / np.array(self.igres))
+        if not np.allclose(fac % 1, 0):
+            raise ValueError("ogres must be 2^k times greater than igres where k >= 0. "
+                             "Instead igres: {}, ogres: {}".format(igres, ogres))
+        if not np.all(fac >= 0):
+            raise ValueError("ogres must be greater or equal to igres. "
+                             "Instead igres: {}, ogres: {}".format(igres, ogres))
+        self.exp_fac = fac.astype(np.int32)
+        self.expand = bool(np.any(self.exp_fac != 0))
+        self.li = int(round(math.log2(max(self.igres))))   # number of input levels
+        self.lo = int(round(math.log2(max(self.ogres))))   # number of output levels
+        self._create_layers()
+
+    def _check_grid_res(self):
+        if not (hasattr(self.igres, '__len__') and hasattr(self.ogres, '__len__')):
+            raise TypeError('igres and ogres must be tuples for grid dimensions')
+        if not (len(self.igres) == 3 and len(self.ogres) == 3):
+            raise ValueError('igres and ogres must have len = 3, however detected to be'
+                             '{} and {}'.format(len(self.igres), len(self.ogres)))
+        for d in list(self.igres) + list(self.ogres):
+            if not (np.issubdtype(type(d), np.integer) and d > 0 and (int(d) & (int(d) - 1)) == 0):
+                raise ValueError('dimensions in igres and ogres must be  integer powers of 2.'
+                                 'instead they are {} and {}.'.format(self.igres, self.ogres))
+
+    @staticmethod
+    def _get_pool_kernel_size(prev_layer_dims):
+        """Halve every dimension that is not already the smallest one (all of them once they are equal)."""
+        dims = [int(d) for d in prev_layer_dims]
+        lo = min(dims)
+        kernel = [2, 2, 2] if all(d == lo for d in dims) else [1 if d == lo else 2 for d in dims]
+        return kernel, np.array([d // k for d, k in zip(dims, kernel)])
+
+    @staticmethod
+    def _get_exp_kernel_size(prev_exp_fac):
+        next_exp_fac = np.clip(prev_exp_fac - 1, 0, None)
+        return prev_exp_fac - next_exp_fac + 1, next_exp_fac
+
+    def _create_layers(self):
+        down_out = [min(self.nf * (2 ** (i + 1)), self.mf) for i in range(self.li)]
+        down_in = [self.nf] + down_out[:-1]
+        up_in = [int(n * 2) for n in down_in[::-1][:-1]]
+        up_out = down_in[::-1][1:]
+        self.conv_in = ResBlock3D(self.in_features, self.nf, self.nf)
+        self.conv_out = ResBlock3D(down_in[0] * 2, down_in[0] * 2, self.out_features, final_relu=False)
+        self.conv_mid = ResBlock3D(down_out[-1], down_out[-2], down_out[-2])
+        down_modules = [ResBlock3D(n_in, int(n / 2), n) for n_in, n in zip(down_in, down_out)]
+        up_modules = [ResBlock3D(n_in, n, n) for n_in, n in zip(up_in, up_out)]
+        down_pools, up_interps = [], []
+        self._pool_kernels = []
+        dims = np.array(self.igres)
+        for _ in range(len(down_out)):
+            kernel, dims = self._get_pool_kernel_size(dims)
+            self._pool_kernels.append(kernel)
+            down_pools.append(nn.MaxPool3d(kernel))
+            up_interps.insert(0, nn.Upsample(scale_factor=tuple(kernel)))   # mirrored order on the way up
+        self._up_factors = self._pool_kernels[::-1]
+        if self.expand:
+            n_exp = int(np.max(self.exp_fac))
+            self.exp_modules = nn.ModuleList([ResBlock3D(2 * self.nf, 2 * self.nf, 2 * self.nf) for _ in range(n_exp)])
+            interps, self._exp_factors = [], []
+            fac = self.exp_fac
+            for _ in range(n_exp):
+                kernel, fac = self._get_exp_kernel_size(fac)
+                self._exp_factors.append([int(k) for k in kernel])
+                interps.append(nn.Upsample(scale_factor=tuple(kernel)))
+            self.exp_fac = fac
+            self.exp_interps = nn.ModuleList(interps)
+        self.down_modules = nn.ModuleList(down_modules)
+        self.up_modules = nn.ModuleList(up_modules)
+        self.down_pools = nn.ModuleList(down_pools)
+        self.up_interps = nn.ModuleList(up_interps)
+
+    def forward(self, x):
+        """x [batch, in_features, *igres] -> [batch, out_features, *ogres] (channels-last strides; reference :208-240)."""
+        h = self.conv_in.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous())
+        skips = [h]
+        for mod, kernel in zip(self.down_modules, self._pool_kernels):
+            h = _pool_cl(mod.forward_cl(skips[-1]), kernel)
+            skips.append(h)
+        h = skips.pop(-1)
+        h = self.conv_mid.forward_cl(_upsample_cl(h, self._up_factors[0]))
+        for mod, factors in zip(self.up_modules, self._up_factors[1:]):
+            h = torch.cat([h, skips.pop(-1)], dim=-1)
+            h = _upsample_cl(mod.forward_cl(h), factors)
+        h = torch.cat([h, skips.pop(-1)], dim=-1)
+        if self.expand:
+            for mod, factors in zip(self.exp_modules, self._exp_factors):
+                h = _upsample_cl(mod.forward_cl(h), factors)
+        h = self.conv_out.forward_cl(h)
+        return h.permute(0, 4, 1, 2, 3)

@@ -31,7 +31,7 @@ STD = (0.05, 0.3, 0.15, 0.12)
 
 
 def t2n(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()
 
 
 def make_net(act, dim=3, cin=32, cout=4, nf=16, seed=0):
@@ -204,6 +204,31 @@ def g1_interp():
     np.savez_compressed(os.path.join(OUT, "g1_interp.npz"), **d)
 
 
+def g7_unet():
+    """UNet3d(igres=(4,8,8), nf=16, mf=32): train-mode output + running stats + gradients, eval-mode output."""
+    import unet3d  # the reference's (needs the numpy.int shim above)
+    torch.manual_seed(3)
+    net = unet3d.UNet3d(in_features=4, out_features=32, igres=(4, 8, 8), nf=16, mf=32)
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(2, 4, 4, 8, 8, generator=g).requires_grad_(True)
+    cot = torch.randn(2, 32, 4, 8, 8, generator=g)
+    d = {"state/" + k: t2n(v) for k, v in net.state_dict().items()}
+    net.train()
+    y = net(x)
+    (y * cot).sum().backward()
+    d.update(x=t2n(x), cot=t2n(cot), y_train=t2n(y), dx=t2n(x.grad))
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            d["after/" + k] = t2n(v)
+    for name in ("conv_in.conv2.weight", "conv_in.bn1.weight", "conv_mid.conv2.weight", "conv_out.shortcut.weight",
+                 "conv_out.shortcut.bias", "down_modules.1.conv2.weight", "up_modules.0.conv1.weight"):
+        d["grad/" + name] = t2n(dict(net.named_parameters())[name].grad)
+    net.eval()
+    with torch.no_grad():
+        d["y_eval"] = t2n(net(x))
+    np.savez_compressed(os.path.join(OUT, "g7_unet.npz"), **d)
+
+
 if __name__ == "__main__":
     g1_interp()
     g3_corners()
@@ -212,6 +237,7 @@ if __name__ == "__main__":
     g6_cell_index()
     g9_generic()
     g10_lig4d()
+    g7_unet()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
