@@ -127,6 +127,9 @@ def lib():
                     raise RuntimeError(
                         "libstpde_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "-- this package has no CPU/eager fallback for its HIP operators." % LIB_PATH)
+                # PyTorch-ROCm ships its own libamdhip64; import torch FIRST so that this library binds to the same,
+                # already initialised HIP runtime (a second runtime instance in the process sees no device)
+                import torch  # noqa: F401
                 h = C.CDLL(LIB_PATH)
                 for name, (argtypes, restype) in _SIGNATURES.items():
                     fn = getattr(h, name)          # AttributeError if the symbol is missing

@@ -170,6 +170,14 @@ __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x
   }
 }
 
+// Launch with a clean error slot: hipGetLastError() is sticky per thread, a stale error from an unrelated earlier
+// runtime call must not be attributed to this launch.
+#define STPDE_LAUNCH(...)      \
+  do {                         \
+    (void)hipGetLastError();   \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 // Host-side helpers (api.cpp)
 void stpde_set_error(const char* fmt, ...);
 int stpde_check_launch(const char* what);

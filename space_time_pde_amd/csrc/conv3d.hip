@@ -177,7 +177,7 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
   a.y = y;
   a.nvox = d->B * d->T * d->Z * d->X;
   const int ntiles = (a.nvox + 15) / 16;
-  hipLaunchKernelGGL(k_conv3d_fwd<4>, dim3((ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_conv3d_fwd<4>, dim3((ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_conv3d_fwd");
 }
 
@@ -203,6 +203,6 @@ extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, co
   int gx = 2048 / gy;
   if (gx < 1) gx = 1;
   if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
-  hipLaunchKernelGGL((k_conv3d_wgrad<MCW, KCW>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH((k_conv3d_wgrad<MCW, KCW>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_conv3d_wgrad");
 }

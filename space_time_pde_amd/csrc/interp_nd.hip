@@ -122,7 +122,7 @@ extern "C" int stpde_interp_fwd(const stpde_interp_desc* d, const float* grid, c
   a.wts = weights;
   a.rel = x_relative;
   const size_t n = (size_t)d->P * d->C;
-  hipLaunchKernelGGL(k_interp<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_interp<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_interp_fwd");
 }
 
@@ -141,6 +141,6 @@ extern "C" int stpde_interp_bwd_grid(const stpde_interp_desc* d, const float* pt
   a.cv_bar = corner_bar;
   a.dgrid = dgrid;
   const size_t n = (size_t)d->P * d->C;
-  hipLaunchKernelGGL(k_interp<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_interp<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_interp_bwd");
 }

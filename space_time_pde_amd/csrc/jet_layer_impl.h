@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
 static int launch_layer(const LayerArgs& a, hipStream_t stream) {
   dim3 grid((a.ntiles + 3) / 4);
-  hipLaunchKernelGGL((k_layer<S1, S2, MC, PRO, EPI, ACT, GUARD>), grid, dim3(256), 0, stream, a);
+  STPDE_LAUNCH((k_layer<S1, S2, MC, PRO, EPI, ACT, GUARD>), grid, dim3(256), 0, stream, a);
   return stpde_check_launch("k_layer");
 }
 

@@ -209,7 +209,7 @@ static int launch_wgrad(const WgradArgs& a0, hipStream_t stream) {
   gx = (gx + 7) / 8 * 8;  // one slice per XCD
   if (gx < 8) gx = 8;
   a.gx = gx;
-  hipLaunchKernelGGL((k_wgrad<S1, S2, MODE, ACT, MCW, KCW>), dim3(gx * a.gy * a.gz), dim3(256), 0, stream, a);
+  STPDE_LAUNCH((k_wgrad<S1, S2, MODE, ACT, MCW, KCW>), dim3(gx * a.gy * a.gz), dim3(256), 0, stream, a);
   return stpde_check_launch("k_wgrad");
 }
 

@@ -126,7 +126,7 @@ extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, co
   }
   GatherArgs a{*d, pts, latent, X, XR, coef, cell};
   const size_t nthreads = (size_t)(d->P / 2) * XT * 64;
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_gather");
 }
 
@@ -302,7 +302,7 @@ extern "C" int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, 
   }
   ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets, nullptr};
   const size_t n = (size_t)P * n_out;
-  hipLaunchKernelGGL(k_reduce_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_reduce_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_fwd");
 }
 
@@ -320,7 +320,7 @@ extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, 
   }
   ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out, abar_out_R};
   const size_t n = (size_t)P * 128;
-  hipLaunchKernelGGL(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_bwd");
 }
 
@@ -391,6 +391,6 @@ extern "C" int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* con
   }
   a.cell = cell;
   a.dlatent = dlatent;
-  hipLaunchKernelGGL(k_xbar, dim3((d->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_xbar, dim3((d->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_xbar");
 }
