@@ -48,9 +48,12 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
 __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   constexpr int S = 1 + S1 + S2;
+  __shared__ __attribute__((aligned(16))) float rpatch[EPI == EPI_FWD ? 1 : 4][2][256];
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= a.ntiles) return;
+  float* patch0 = rpatch[EPI == EPI_FWD ? 0 : (threadIdx.x >> 6)][0];
+  float* patch1 = rpatch[EPI == EPI_FWD ? 0 : (threadIdx.x >> 6)][1];
   const int KT = a.KT, MT = a.MT;
   const int lo = lane * 4;
 
@@ -167,12 +170,14 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
         f32x4 H[S];
         act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
 #pragma unroll
-        for (int st = 0; st < S; ++st) st_R(a.HR + (((size_t)tile * S + st) * MT + mt) * 256, lane, H[st]);
+        for (int st = 0; st < S; ++st)
+          st_R_lds(a.HR + (((size_t)tile * S + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, H[st]);
       } else {
         st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
       }
 #pragma unroll
-      for (int st = 0; st < SO; ++st) st_R(a.OutR + (((size_t)tile * SO + st) * MT + mt) * 256, lane, ab[st]);
+      for (int st = 0; st < SO; ++st)
+        st_R_lds(a.OutR + (((size_t)tile * SO + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, ab[st]);
     }
   }
   }  // chunk loop

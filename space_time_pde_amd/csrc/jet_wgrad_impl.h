@@ -27,7 +27,7 @@ struct WgradArgs {
 };
 
 template <int S1, int S2, int MODE, int ACT, int MCW, int KCW>
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(256, (MODE == 0 && KCW == 8 && S1 + S2 <= 5) ? 2 : 1) void k_wgrad(WgradArgs a) {
   constexpr int S = 1 + S1 + S2;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
