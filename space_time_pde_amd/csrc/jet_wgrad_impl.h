@@ -197,6 +197,180 @@ __global__ __launch_bounds__(256, (MODE == 0 && KCW == 8 && S1 + S2 <= 5) ? 2 : 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// First hidden layer (its activated input is regenerated from the raw input): workgroup-cooperative variant.
+// The 4 waves of a workgroup own the 4 m-blocks (16 output tiles) of ONE k-block and walk the same row tiles in
+// lock step.  The regenerated + activated input blocks of a tile (KCW k-tiles x S streams, R image) are produced
+// ONCE per workgroup -- wave w produces k-tiles w, w+4, .. -- into LDS and consumed by all four waves, so the
+// activation VALU work and the layer-0 MFMAs are paid once per 16 output tiles instead of once per 4.  Production
+// for tile t+1 is issued in the same basic block as the MFMAs of tile t (double-buffered LDS, one barrier per tile).
+// ------------------------------------------------------------------------------------------------------------
+template <int S1, int S2, int ACT, int KCW>
+__global__ __launch_bounds__(256) void k_wgrad_first(WgradArgs a) {
+  constexpr int S = 1 + S1 + S2, MCW = 4;
+  constexpr int NBUF = (2 * KCW * S * 1024 <= 112 * 1024) ? 2 : 1;
+  constexpr int NP = (KCW + 3) / 4;  // k-tiles produced per wave per row tile
+  __shared__ __attribute__((aligned(16))) float hl[NBUF][KCW][S][256];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int lo = lane * 4;
+  const int KT = a.KT, MT = a.MT, SP = a.SP;
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int kz = slot % a.gz, tq = slot / a.gz;
+  const int mg = tq % a.gy, bx = (tq / a.gy) * 8 + xcd;
+  const int mt0 = (mg * 4 + wv) * MCW;
+  const int kq0 = kz * KCW;
+  const int g = lane >> 4, c = lane & 15;
+  const bool has_x = kq0 + KCW > KT;  // block-uniform: this k-block contains raw-input tiles
+
+  f32x4 acc[MCW][KCW];
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+    for (int ki = 0; ki < KCW; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* w0s = a.W0s;
+  const float* tcr = a.tancR;
+
+  // produce this wave's share of the activated input blocks of `tile` into buffer `buf`
+  auto produce = [&](int tile, int buf) {
+    f32x4 xd[XT];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) xd[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      const int ki = wv + 4 * pi;
+      if (KCW % 4 != 0 && ki >= KCW) continue;
+      const int kq = kq0 + ki;
+      f32x4 H[S];
+      if (!has_x || kq < KT) {
+        f32x4 pre[S], part[XT];
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+          f32x4 w = ld4(w0s + ((size_t)xt * KT + kq) * 256 + lo);
+          f32x4 cc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cc = mfma4(xd[xt][r], w[r], cc);   // rows x features: R image
+          part[xt] = cc;
+        }
+        pre[0] = (part[0] + part[1]) + part[2];
+        if (S1 == 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(tcr + ((size_t)d * KT + kq) * 256 + lo);
+#pragma unroll
+          for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
+      } else {
+        const int xt = kq - KT;
+#pragma unroll
+        for (int st = 0; st < S; ++st) H[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xt < XT) {
+          H[0] = ld4(a.XR + ((size_t)tile * XT + xt) * 256 + lo);
+          if (S1 == 3 && xt == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const float v = c == d ? 1.f : 0.f;
+              H[1 + d] = f32x4{v, v, v, v};
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < S; ++st) st4(&hl[buf][ki][st][lo], H[st]);
+    }
+  };
+  auto load_p = [&](int tile, f32x4 (*pa)[MCW]) {
+    const float* pbase = a.P + (size_t)tile * SP * MT * 256 + lo;
+#pragma unroll
+    for (int st = 0; st < S; ++st)
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) {
+        const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
+        pa[st][mi] = st < SP ? ld4(pbase + ((size_t)st * MT + mt) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+
+  const int stride = a.gx;
+  int tile = bx;
+  f32x4 pa[S][MCW];
+  if (tile < a.ntiles) {
+    produce(tile, 0);
+    load_p(tile, pa);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < a.ntiles; tile += stride) {
+    const int next = tile + stride;
+    const bool more = next < a.ntiles;
+    // consume: all k-tiles of this row tile from LDS against the resident abar blocks
+#pragma unroll
+    for (int ki = 0; ki < KCW; ++ki) {
+      f32x4 H[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) H[st] = ld4(&hl[buf][ki][st][lo]);
+      if (!has_x || kq0 + ki < KT) {
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int st = 0; st < S; ++st) acc[mi][ki] = mfma4(pa[st][mi][r], H[st][r], acc[mi][ki]);
+      } else {
+        constexpr int SX = S1 == 3 ? 4 : 1;   // raw-input tiles only feed the value and tangent streams
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int st = 0; st < SX; ++st) acc[mi][ki] = mfma4(pa[st][mi][r], H[st][r], acc[mi][ki]);
+      }
+    }
+    if (more) load_p(next, pa);   // the next tile's abar blocks land while the produce stage below runs
+    if (NBUF == 2) {
+      if (more) produce(next, buf ^ 1);   // independent of the MFMAs above: the scheduler interleaves its VALU work
+      __syncthreads();
+      buf ^= 1;
+    } else {
+      __syncthreads();
+      if (more) produce(next, 0);
+      __syncthreads();
+    }
+  }
+
+  const int ldw = 16 * (KT + XT);
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi) {
+    const int mt = mt0 + mi;
+    if (mt >= MT) continue;
+#pragma unroll
+    for (int ki = 0; ki < KCW; ++ki) {
+      const int kq = kq0 + ki;
+      if (kq >= KT + XT) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * kq + c, acc[mi][ki][r]);
+    }
+  }
+}
+
+template <int S1, int S2, int ACT>
+static int launch_wgrad_first(const WgradArgs& a0, hipStream_t stream) {
+  constexpr int KCW = (1 + S1 + S2) > 6 ? 4 : 8;   // LDS: KCW * S KiB per buffer
+  WgradArgs a = a0;
+  a.gy = (a.MT + 15) / 16;                 // groups of 4 m-blocks (one per wave)
+  a.gz = (a.KT + XT + KCW - 1) / KCW;
+  int gx = 1024 / (a.gy * a.gz);           // ~4 rounds of one workgroup per CU
+  const int maxx = a.ntiles;
+  if (gx > maxx) gx = maxx;
+  gx = (gx + 7) / 8 * 8;
+  if (gx < 8) gx = 8;
+  a.gx = gx;
+  STPDE_LAUNCH((k_wgrad_first<S1, S2, ACT, KCW>), dim3(gx * a.gy * a.gz), dim3(256), 0, stream, a);
+  return stpde_check_launch("k_wgrad_first");
+}
+
 template <int S1, int S2, int MODE, int ACT, int KCW>
 static int launch_wgrad(const WgradArgs& a0, hipStream_t stream) {
   constexpr int MCW = 4;
@@ -228,7 +402,6 @@ static inline int pick_kcw(int ktot) {
 
 template <int S1, int S2, int MODE, int ACT>
 static int launch_kcw(const WgradArgs& a, hipStream_t stream) {
-  if (MODE == 1) return launch_wgrad<S1, S2, MODE, ACT, 8>(a, stream);   // wider blocks spill (all P streams resident)
   switch (pick_kcw(a.KT + XT)) {
     case 8: return launch_wgrad<S1, S2, MODE, ACT, 8>(a, stream);
     case 9: return launch_wgrad<S1, S2, MODE, ACT, 9>(a, stream);
@@ -240,12 +413,12 @@ template <int S1, int S2>
 static int launch_mode(const WgradArgs& a, int mode, hipStream_t stream) {
   if (mode == 0) return launch_kcw<S1, S2, 0, -1>(a, stream);
   switch (a.cfg.act) {
-    case STPDE_ACT_TANH: return launch_kcw<S1, S2, 1, STPDE_ACT_TANH>(a, stream);
-    case STPDE_ACT_RELU: return launch_kcw<S1, S2, 1, STPDE_ACT_RELU>(a, stream);
-    case STPDE_ACT_SOFTPLUS: return launch_kcw<S1, S2, 1, STPDE_ACT_SOFTPLUS>(a, stream);
-    case STPDE_ACT_ELU: return launch_kcw<S1, S2, 1, STPDE_ACT_ELU>(a, stream);
-    case STPDE_ACT_LEAKYRELU: return launch_kcw<S1, S2, 1, STPDE_ACT_LEAKYRELU>(a, stream);
-    default: return launch_kcw<S1, S2, 1, STPDE_ACT_SWISH>(a, stream);
+    case STPDE_ACT_TANH: return launch_wgrad_first<S1, S2, STPDE_ACT_TANH>(a, stream);
+    case STPDE_ACT_RELU: return launch_wgrad_first<S1, S2, STPDE_ACT_RELU>(a, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_wgrad_first<S1, S2, STPDE_ACT_SOFTPLUS>(a, stream);
+    case STPDE_ACT_ELU: return launch_wgrad_first<S1, S2, STPDE_ACT_ELU>(a, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_wgrad_first<S1, S2, STPDE_ACT_LEAKYRELU>(a, stream);
+    default: return launch_wgrad_first<S1, S2, STPDE_ACT_SWISH>(a, stream);
   }
 }
 
