@@ -45,6 +45,61 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
   return (part[0] + part[1]) + part[2];
 }
 
+// Epilogue of one output tile `mt` held in acc[S] (D image): forward = skip GEMM + tangent constants + store of the
+// pre-activations; dgrad = activation-jet adjoint against the stored / regenerated pre-activations + R-image copies.
+template <int S1, int S2, int EPI, int ACT>
+__device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
+                                               const f32x4* xb, float* patch0, float* patch1) {
+  constexpr int S = 1 + S1 + S2;
+  const int lo = lane * 4;
+  f32x4 (&acc)[1][S] = *reinterpret_cast<f32x4 (*)[1][S]>(accm);
+  constexpr int mi = 0;
+    if (EPI == EPI_FWD) {
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+        f32x4 w = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][0] = mfma4(w[r], xb[xt][r], acc[mi][0]);
+      }
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[mi][1 + d] += ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
+      }
+#pragma unroll
+      for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[mi][st]);
+    } else {
+      f32x4 pre[S], ab[S];
+      if (EPI == EPI_ADJ) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+      } else {
+        pre[0] = layer0_block(a.W0s, MT, mt, lo, xb);
+        if (S1 == 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
+#pragma unroll
+          for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab);
+      constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
+      if (EPI == EPI_ADJ) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
+        f32x4 H[S];
+        act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+          st_R_lds(a.HR + (((size_t)tile * S + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, H[st]);
+      } else {
+        st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
+      }
+#pragma unroll
+      for (int st = 0; st < SO; ++st)
+        st_R_lds(a.OutR + (((size_t)tile * SO + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, ab[st]);
+    }
+}
+
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
 __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   constexpr int S = 1 + S1 + S2;
@@ -135,52 +190,120 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   for (int mi = 0; mi < MC; ++mi) {
     const int mt = mt0 + mi;
     if (GUARD && mt >= MT) continue;
-    if (EPI == EPI_FWD) {
-#pragma unroll
-      for (int xt = 0; xt < XT; ++xt) {
-        f32x4 w = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mi][0] = mfma4(w[r], xb[xt][r], acc[mi][0]);
-      }
-      if (S1 == 3) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) acc[mi][1 + d] += ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
-      }
-#pragma unroll
-      for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[mi][st]);
-    } else {
-      f32x4 pre[S], ab[S];
-      if (EPI == EPI_ADJ) {
-#pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
-      } else {
-        pre[0] = layer0_block(a.W0s, MT, mt, lo, xb);
-        if (S1 == 3) {
-#pragma unroll
-          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
-#pragma unroll
-          for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab);
-      constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
-      if (EPI == EPI_ADJ) {
-#pragma unroll
-        for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
-        f32x4 H[S];
-        act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
-#pragma unroll
-        for (int st = 0; st < S; ++st)
-          st_R_lds(a.HR + (((size_t)tile * S + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, H[st]);
-      } else {
-        st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
-      }
-#pragma unroll
-      for (int st = 0; st < SO; ++st)
-        st_R_lds(a.OutR + (((size_t)tile * SO + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, ab[st]);
-    }
+    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb, patch0, patch1);
   }
   }  // chunk loop
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Workgroup-cooperative variant: the 4 waves of a workgroup share ONE row tile and split its output tiles
+// (MCg per wave per pass).  The B operand of every k-tile (S blocks) is produced ONCE per workgroup -- wave kt%4
+// loads / regenerates / activates block kt -- into a double-buffered LDS ring of 2 x 4 k-tiles and is consumed by
+// all four waves, so the stash reads, the layer-0 regeneration MFMAs and the activation-jet VALU work are shared
+// 4 ways.  One barrier per 4 k-tiles; production of group g+1 sits in the same basic block as the MFMAs of group g.
+// Requires KT % 4 == 0 and MT % (4*MCg) == 0 (otherwise the per-wave kernel above is used).
+// ------------------------------------------------------------------------------------------------------------
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT>
+__global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
+  constexpr int S = 1 + S1 + S2;
+  __shared__ __attribute__((aligned(16))) float hb[2][4][S][256];
+  __shared__ __attribute__((aligned(16))) float rpatch[EPI == EPI_FWD ? 1 : 4][2][256];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int KT = a.KT, MT = a.MT;
+  const int lo = lane * 4;
+  float* patch0 = rpatch[EPI == EPI_FWD ? 0 : wv][0];
+  float* patch1 = rpatch[EPI == EPI_FWD ? 0 : wv][1];
+
+  f32x4 xb[XT];
+  if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+  }
+  const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
+
+  // produce the B block of k-tile kt (this wave's turn) into ring slot (buf, wv)
+  auto produce = [&](int kt, int buf) {
+    f32x4 raw[S], B[S];
+    if (PRO == PRO_L0) {
+      raw[0] = layer0_block(a.W0s, KT, kt, lo, xb);
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
+#pragma unroll
+        for (int p = 0; p < S2; ++p) raw[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT + kt) * 256);
+    }
+    if (PRO == PRO_NONE) {
+#pragma unroll
+      for (int st = 0; st < S; ++st) B[st] = raw[st];
+    } else {
+      act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B);
+    }
+#pragma unroll
+    for (int st = 0; st < S; ++st) st4(&hb[buf][wv][st][lo], B[st]);
+  };
+
+  const int ngroups = KT / 4;
+  for (int mt0 = wv * MCg; mt0 < MT; mt0 += 4 * MCg) {
+    f32x4 acc[MCg][S];
+#pragma unroll
+    for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+      for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
+    __syncthreads();              // ring free (previous pass fully consumed)
+    produce(wv, 0);
+    __syncthreads();
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int buf = gi & 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kt = 4 * gi + q;
+        f32x4 B[S], w[MCg];
+#pragma unroll
+        for (int st = 0; st < S; ++st) B[st] = ld4(&hb[buf][q][st][lo]);
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi) w[mi] = ld4(wp + ((size_t)kt * MT + mi) * 256);
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int st = 0; st < S; ++st) acc[mi][st] = mfma4(w[mi][r], B[st][r], acc[mi][st]);
+      }
+      // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
+      // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
+      produce(gi + 1 < ngroups ? 4 * (gi + 1) + wv : 4 * gi + wv, buf ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MCg; ++mi)
+      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, patch0, patch1);
+  }
+}
+
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT>
+static int launch_layer_coop(const LayerArgs& a, hipStream_t stream) {
+  STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT>), dim3(a.ntiles), dim3(256), 0, stream, a);
+  return stpde_check_launch("k_layer_coop");
+}
+
+template <int S1, int S2, int PRO, int EPI, int MCg>
+static int launch_coop_act(const LayerArgs& a, hipStream_t stream) {
+  switch (a.cfg.act) {
+    case STPDE_ACT_TANH: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_TANH>(a, stream);
+    case STPDE_ACT_RELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_RELU>(a, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_SOFTPLUS>(a, stream);
+    case STPDE_ACT_ELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_ELU>(a, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_LEAKYRELU>(a, stream);
+    default: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_SWISH>(a, stream);
+  }
 }
 
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
@@ -205,6 +328,12 @@ static int launch_fwd_act_mc(const LayerArgs& a, hipStream_t stream) {
 template <int S1, int S2, int PRO, int EPI>
 static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
   if (a.MT % 4 != 0) return launch_layer<S1, S2, 4, PRO, EPI, -1, true>(a, stream);
+  // workgroup-cooperative variant: B operand produced once per 4 waves (S = 10 would not fit two workgroups of LDS)
+  if (a.KT % 4 == 0 && a.KT >= 8 && S1 + S2 <= 5) {
+    // dgrad epilogues are VALU heavy: 2 tiles per wave keeps two workgroups per CU so they overlap with MFMAs
+    if (EPI == EPI_FWD && a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4>(a, stream);
+    if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2>(a, stream);
+  }
   // kernels that stream their B operand from memory (everything except the layer-0-on-the-fly forward) halve that
   // traffic with 8 output tiles per pass; S=10 would not fit the register file
   if (PRO != PRO_L0 && S1 + S2 <= 5 && a.MT % 8 == 0) return launch_fwd_act_mc<S1, S2, PRO, EPI, 8>(a, stream);

@@ -327,14 +327,17 @@ __global__ __launch_bounds__(256) void k_wgrad_first(WgradArgs a) {
             for (int st = 0; st < SX; ++st) acc[mi][ki] = mfma4(pa[st][mi][r], H[st][r], acc[mi][ki]);
       }
     }
-    if (more) load_p(next, pa);   // the next tile's abar blocks land while the produce stage below runs
+    // Branch-free tail (the last iteration harmlessly re-produces its own tile): keeping the whole iteration in ONE
+    // basic block lets the scheduler interleave the produce stage's VALU work with the MFMAs above.
+    const int nx = more ? next : tile;
+    load_p(nx, pa);   // the next tile's abar blocks land while the produce stage below runs
     if (NBUF == 2) {
-      if (more) produce(next, buf ^ 1);   // independent of the MFMAs above: the scheduler interleaves its VALU work
+      produce(nx, buf ^ 1);
       __syncthreads();
       buf ^= 1;
     } else {
       __syncthreads();
-      if (more) produce(next, 0);
+      produce(nx, 0);
       __syncthreads();
     }
   }
