@@ -23,6 +23,7 @@ struct WgradArgs {
   float* dW;           // [16*MT][16*(KT+XT)]
   int SP, KT, MT, ntiles;
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-blocks, k-blocks
+  int kz0;             // first k-block of this launch (k_wgrad_first is launched per k-block class)
   stpde_jet_cfg cfg;
 };
 
@@ -206,23 +207,24 @@ __global__ __launch_bounds__(256, (MODE == 0 && KCW == 8 && S1 + S2 <= 5) ? 2 : 
 // activation VALU work and the layer-0 MFMAs are paid once per 16 output tiles instead of once per 4.  Production
 // for tile t+1 is issued in the same basic block as the MFMAs of tile t (double-buffered LDS, one barrier per tile).
 // ------------------------------------------------------------------------------------------------------------
-template <int S1, int S2, int ACT, int KCW>
-__global__ __launch_bounds__(256) void k_wgrad_first(WgradArgs a) {
-  constexpr int S = 1 + S1 + S2, MCW = 4;
+template <int S1, int S2, int ACT, int KCW, bool HASX>
+__global__ __launch_bounds__(512, 2) void k_wgrad_first(WgradArgs a) {
+  // 8 waves (2 per SIMD) x 2 output tiles each = the 16 output tiles of one k-block
+  constexpr int S = 1 + S1 + S2, MCW = 2, NW = 8;
   constexpr int NBUF = (2 * KCW * S * 1024 <= 112 * 1024) ? 2 : 1;
-  constexpr int NP = (KCW + 3) / 4;  // k-tiles produced per wave per row tile
+  constexpr int NP = (KCW + NW - 1) / NW;  // k-tiles produced per wave per row tile
   __shared__ __attribute__((aligned(16))) float hl[NBUF][KCW][S][256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int lo = lane * 4;
   const int KT = a.KT, MT = a.MT, SP = a.SP;
   const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-  const int kz = slot % a.gz, tq = slot / a.gz;
+  const int kz = (slot % a.gz) + a.kz0, tq = slot / a.gz;
   const int mg = tq % a.gy, bx = (tq / a.gy) * 8 + xcd;
-  const int mt0 = (mg * 4 + wv) * MCW;
+  const int mt0 = (mg * NW + wv) * MCW;
   const int kq0 = kz * KCW;
   const int g = lane >> 4, c = lane & 15;
-  const bool has_x = kq0 + KCW > KT;  // block-uniform: this k-block contains raw-input tiles
+  constexpr bool has_x = HASX;  // this k-block contains raw-input tiles (the launcher splits the grid)
 
   f32x4 acc[MCW][KCW];
 #pragma unroll
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256) void k_wgrad_first(WgradArgs a) {
     for (int xt = 0; xt < XT; ++xt) xd[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
-      const int ki = wv + 4 * pi;
-      if (KCW % 4 != 0 && ki >= KCW) continue;
+      const int ki = wv + NW * pi;
+      if (KCW % NW != 0 && ki >= KCW) continue;
       const int kq = kq0 + ki;
       f32x4 H[S];
       if (!has_x || kq < KT) {
@@ -362,16 +364,26 @@ template <int S1, int S2, int ACT>
 static int launch_wgrad_first(const WgradArgs& a0, hipStream_t stream) {
   constexpr int KCW = (1 + S1 + S2) > 6 ? 4 : 8;   // LDS: KCW * S KiB per buffer
   WgradArgs a = a0;
-  a.gy = (a.MT + 15) / 16;                 // groups of 4 m-blocks (one per wave)
-  a.gz = (a.KT + XT + KCW - 1) / KCW;
-  int gx = 1024 / (a.gy * a.gz);           // ~4 rounds of one workgroup per CU
-  const int maxx = a.ntiles;
-  if (gx > maxx) gx = maxx;
-  gx = (gx + 7) / 8 * 8;
-  if (gx < 8) gx = 8;
-  a.gx = gx;
-  STPDE_LAUNCH((k_wgrad_first<S1, S2, ACT, KCW>), dim3(gx * a.gy * a.gz), dim3(256), 0, stream, a);
-  return stpde_check_launch("k_wgrad_first");
+  a.gy = (a.MT + 15) / 16;                 // groups of 16 output tiles (2 per wave)
+  const int nkb = (a.KT + XT + KCW - 1) / KCW;
+  const int nhid = a.KT / KCW;             // k-blocks made of hidden tiles only
+  for (int part = 0; part < 2; ++part) {
+    a.kz0 = part == 0 ? 0 : nhid;
+    a.gz = part == 0 ? nhid : nkb - nhid;
+    if (a.gz <= 0) continue;
+    int gx = 512 / (a.gy * a.gz);          // ~2 rounds of two workgroups per CU
+    if (gx > a.ntiles) gx = a.ntiles;
+    gx = (gx + 7) / 8 * 8;
+    if (gx < 8) gx = 8;
+    a.gx = gx;
+    if (part == 0)
+      STPDE_LAUNCH((k_wgrad_first<S1, S2, ACT, KCW, false>), dim3(gx * a.gy * a.gz), dim3(512), 0, stream, a);
+    else
+      STPDE_LAUNCH((k_wgrad_first<S1, S2, ACT, KCW, true>), dim3(gx * a.gy * a.gz), dim3(512), 0, stream, a);
+    int rc = stpde_check_launch("k_wgrad_first");
+    if (rc) return rc;
+  }
+  return STPDE_OK;
 }
 
 template <int S1, int S2, int MODE, int ACT, int KCW>
