@@ -69,7 +69,8 @@ typedef struct {
   int p_base; /* global index of pts[0]: batch of point p is min((p_base + p) / N, B - 1) */
   float lo_c[3], hi_c[3], cube[3];
 } stpde_gather_desc;
-/* XR (optional, may be NULL): the same augmented input in the row-major fragment image (see stpde_jet_wgrad). */
+/* XR (optional, may be NULL): the same augmented input in the row-major fragment image (lane 16g+c holds rows
+ * 4g..4g+3 of feature c), consumed by stpde_jet_wgrad. */
 int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X, float* XR,
                      float* coef, int* cell, void* stream);
 
@@ -90,20 +91,17 @@ int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const fl
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when
- * first_hidden == 0, or (value stream only) into abar0[tile][1][KT] (layer 0, pre-activations regenerated from X)
- * otherwise.  Also emits the operands of the weight-gradient kernel in the ROW-MAJOR fragment image ("R layout":
- * lane 16g+c holds rows 4g..4g+3 of feature c): abar_in_R [tile][S or 1+S1][KT] and, when first_hidden == 0,
- * hin_R = act_jet(in_pre) [tile][S][KT]. */
+ * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise. */
 int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
-                        const float* X, const float* W0s_pack, const float* tanc0, float* abar0, float* abar_in_R,
-                        float* hin_R, void* stream);
+                        const float* X, const float* W0s_pack, const float* tanc0, float* abar0, void* stream);
 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
- * (columns: hidden inputs, then r(3), latent(c), bias, pad).  Both operands are the R-layout images written by
- * stpde_jet_layer_bwd / stpde_lig_reduce_bwd / stpde_lig_gather: abar_out_R [tile][SP][MT] (SP = S, or 1+S1 for
- * layer 0), hin_R [tile][S][KT] (ignored when first_hidden: the activated layer-0 output is regenerated from X with
- * W0s_pack and tanc0R = layer-0 tangent constants in R layout), XR.  fp32 atomics; caller zero-fills dW_aug. */
-int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out_R, const float* hin_R, const float* X,
+ * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
+ * and in_pre [tile][S][KT] are the ordinary (column-major) layer buffers -- call it BEFORE stpde_jet_layer_bwd of the
+ * same layer overwrites in_pre.  first_hidden: in_pre is ignored, the activated layer-0 output is regenerated from X
+ * with W0s_pack and tanc0R (layer-0 tangent constants in the row-major image).  XR = row-major augmented input from
+ * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug. */
+int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* X,
                     const float* XR, const float* W0s_pack, const float* tanc0R, float* dW_aug, void* stream);
 
 /* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
@@ -112,7 +110,7 @@ int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out_R, 
 int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* out_pre, const float* coef,
                          float* jets, long ldp, void* stream);
 int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
-                         const float* coef, float* abar_out, float* abar_out_R, void* stream);
+                         const float* coef, float* abar_out, void* stream);
 
 /* ---- backward of the gather: d latent (index_put accumulate, backward of :65-66) --------------------
  * xbar = sum_l W_s,l^T * abar_l(value stream); latent channels are scatter-added into dlatent

@@ -66,7 +66,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
 
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
-                                   float* abar0, float* abar_in_R, float* hin_R, void* stream) {
+                                   float* abar0, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -80,9 +80,7 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
   a.MT = d->KT;
   a.ntiles = d->ntiles;
   a.cfg = d->cfg;
-  a.OutR = abar_in_R;
-  a.HR = hin_R;
-  if (!abar_out || !WhT_pack || d->KT <= 0 || !abar_in_R) {
+  if (!abar_out || !WhT_pack || d->KT <= 0) {
     stpde_set_error("jet_layer_bwd: null pointer / no hidden input");
     return STPDE_E_BADARG;
   }
@@ -94,8 +92,8 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
     a.Out = abar0;
     return dispatch_streams(a, 3, (hipStream_t)stream);
   }
-  if (!in_pre || !hin_R) {
-    stpde_set_error("jet_layer_bwd: null in_pre / hin_R");
+  if (!in_pre) {
+    stpde_set_error("jet_layer_bwd: null in_pre");
     return STPDE_E_BADARG;
   }
   a.Out = in_pre;

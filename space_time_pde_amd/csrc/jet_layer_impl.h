@@ -24,9 +24,7 @@ struct LayerArgs {
   const float* tanc0;  // [3][KT or MT][256]   layer-0 tangent constants W0[:, d]
   const float* Wsp;    // [XT][MT][256] packed skip weights (EPI_FWD)
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
-  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1][MT][256] (value stream)
-  float* OutR;         // EPI_ADJ*: R-layout copy of the adjoint [tile][S or 1+S1][MT][256] (operand of the weight gradient)
-  float* HR;           // EPI_ADJ: R-layout activated input act_jet(pre) [tile][S][MT][256] (operand of the weight gradient)
+  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
   int KT, MT, ntiles;
   stpde_jet_cfg cfg;
 };
@@ -49,7 +47,7 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 // pre-activations; dgrad = activation-jet adjoint against the stored / regenerated pre-activations + R-image copies.
 template <int S1, int S2, int EPI, int ACT>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
-                                               const f32x4* xb, float* patch0, float* patch1) {
+                                               const f32x4* xb) {
   constexpr int S = 1 + S1 + S2;
   const int lo = lane * 4;
   f32x4 (&acc)[1][S] = *reinterpret_cast<f32x4 (*)[1][S]>(accm);
@@ -83,32 +81,17 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
       }
       act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab);
       constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
-      if (EPI == EPI_ADJ) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
-        f32x4 H[S];
-        act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
-#pragma unroll
-        for (int st = 0; st < S; ++st)
-          st_R_lds(a.HR + (((size_t)tile * S + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, H[st]);
-      } else {
-        st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
-      }
-#pragma unroll
-      for (int st = 0; st < SO; ++st)
-        st_R_lds(a.OutR + (((size_t)tile * SO + st) * MT + mt) * 256, (st & 1) ? patch1 : patch0, lane, ab[st]);
+      for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
     }
 }
 
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
 __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   constexpr int S = 1 + S1 + S2;
-  __shared__ __attribute__((aligned(16))) float rpatch[EPI == EPI_FWD ? 1 : 4][2][256];
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= a.ntiles) return;
-  float* patch0 = rpatch[EPI == EPI_FWD ? 0 : (threadIdx.x >> 6)][0];
-  float* patch1 = rpatch[EPI == EPI_FWD ? 0 : (threadIdx.x >> 6)][1];
   const int KT = a.KT, MT = a.MT;
   const int lo = lane * 4;
 
@@ -190,7 +173,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   for (int mi = 0; mi < MC; ++mi) {
     const int mt = mt0 + mi;
     if (GUARD && mt >= MT) continue;
-    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb, patch0, patch1);
+    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb);
   }
   }  // chunk loop
 }
@@ -208,14 +191,11 @@ template <int S1, int S2, int MCg, int PRO, int EPI, int ACT>
 __global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2;
   __shared__ __attribute__((aligned(16))) float hb[2][4][S][256];
-  __shared__ __attribute__((aligned(16))) float rpatch[EPI == EPI_FWD ? 1 : 4][2][256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int KT = a.KT, MT = a.MT;
   const int lo = lane * 4;
-  float* patch0 = rpatch[EPI == EPI_FWD ? 0 : wv][0];
-  float* patch1 = rpatch[EPI == EPI_FWD ? 0 : wv][1];
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
@@ -284,7 +264,7 @@ __global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
     }
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
-      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, patch0, patch1);
+      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb);
   }
 }
 

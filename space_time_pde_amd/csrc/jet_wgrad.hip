@@ -11,17 +11,17 @@ static int dispatch_streams(const WgradArgs& a, int mode, hipStream_t stream) {
   return STPDE_E_UNSUPPORTED;
 }
 
-extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out_R, const float* hin_R,
+extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre,
                                const float* X, const float* XR, const float* W0s_pack, const float* tanc0R,
                                float* dW_aug, void* stream) {
-  if (!d || d->ntiles <= 0 || d->MT <= 0 || d->KT < 0 || !abar_out_R || !XR || !dW_aug || SP < 1 ||
+  if (!d || d->ntiles <= 0 || d->MT <= 0 || d->KT < 0 || !abar_out || !XR || !dW_aug || SP < 1 ||
       SP > 1 + d->cfg.S1 + d->cfg.S2) {
     stpde_set_error("jet_wgrad: bad argument");
     return STPDE_E_BADARG;
   }
   WgradArgs a{};
-  a.P = abar_out_R;
-  a.Q = hin_R;
+  a.P = abar_out;
+  a.Q = in_pre;
   a.X = X;
   a.XR = XR;
   a.W0s = W0s_pack;
@@ -39,8 +39,8 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
     }
     return dispatch_streams(a, 1, (hipStream_t)stream);
   }
-  if (d->KT > 0 && !hin_R) {
-    stpde_set_error("jet_wgrad: null hin_R");
+  if (d->KT > 0 && !in_pre) {
+    stpde_set_error("jet_wgrad: null in_pre");
     return STPDE_E_BADARG;
   }
   return dispatch_streams(a, 0, (hipStream_t)stream);

@@ -169,7 +169,6 @@ struct ReduceArgs {
   const float* src;  // fwd: out_pre [tile][S][1][256]; bwd: jets_bar [S][n_out][P]
   const float* coef;
   float* dst;  // fwd: jets [S][n_out][P]; bwd: abar_out [tile][S][1][256]
-  float* dstR; // bwd: R-layout copy of abar_out
 };
 
 // one thread per (point, channel)
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   const int j = ((p & 1) << 3) | corner;
   const int lane = ((ch >> 2) << 4) | j;
   float* base = a.dst + (size_t)tile * S * 256 + lane * 4 + (ch & 3);
-  float* baseR = a.dstR + (size_t)tile * S * 256 + 64 * (j >> 2) + 4 * ch + (j & 3);
   float fb[10];
 #pragma unroll
   for (int s = 0; s < 10; ++s) fb[s] = 0.f;
@@ -277,10 +275,7 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   }
 #pragma unroll
   for (int s = 0; s < 10; ++s)
-    if (s < S) {
-      base[(size_t)s * 256] = fb[s];
-      baseR[(size_t)s * 256] = fb[s];
-    }
+    if (s < S) base[(size_t)s * 256] = fb[s];
 }
 
 static int check_reduce(const stpde_jet_cfg* cfg, int P, int n_out, const void* a, const void* b, const void* c) {
@@ -300,25 +295,21 @@ extern "C" int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, 
     stpde_set_error("lig_reduce_fwd: ldp < P");
     return STPDE_E_BADARG;
   }
-  ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets, nullptr};
+  ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets};
   const size_t n = (size_t)P * n_out;
   STPDE_LAUNCH(k_reduce_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_fwd");
 }
 
 extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
-                                    const float* coef, float* abar_out, float* abar_out_R, void* stream) {
+                                    const float* coef, float* abar_out, void* stream) {
   int rc = check_reduce(cfg, P, n_out, jets_bar, coef, abar_out);
   if (rc) return rc;
-  if (!abar_out_R) {
-    stpde_set_error("lig_reduce_bwd: null abar_out_R");
-    return STPDE_E_BADARG;
-  }
   if (ldp < P) {
     stpde_set_error("lig_reduce_bwd: ldp < P");
     return STPDE_E_BADARG;
   }
-  ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out, abar_out_R};
+  ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out};
   const size_t n = (size_t)P * 128;
   STPDE_LAUNCH(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_bwd");

@@ -300,7 +300,8 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
 
 
 def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
-    """reduce_bwd -> for l = 5..1: dgrad_l (emits the R-layout operands) then wgrad_l -> wgrad_0 -> xbar/scatter."""
+    """reduce_bwd -> for l = 5..1: wgrad_l (reads abar_l and the still intact pre-activations of layer l-1), then
+    dgrad_l (overwrites them with abar_{l-1}) -> wgrad_0 -> xbar/scatter."""
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()
@@ -310,38 +311,30 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
     dev = X.device
     pv = plan.pack_view
     SP0 = 1 + cfg.S1
-
-    def new(nblocks):
-        return torch.empty(nt * nblocks * _FRAG, device=dev)
-
-    # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer) + its R-layout copy
-    abarR = new(S * plan.layers[5]["MT"])
+    # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer)
     with _timed("reduce_bwd"):
         check(L.stpde_lig_reduce_bwd(C.byref(cfg), Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
-                                     jets_bar.shape[2], ptr(coef), ptr(bufs[5]), ptr(abarR), st))
-    abar0 = new(plan.layers[0]["MT"])          # value stream of layer 0's adjoint (column-major), for xbar
+                                     jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
+    abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         d = _layer_desc(nt, lay, cfg, l == 1)
         off, mp, ka = plan.dw_off[l]
-        nextR = new((S if l > 1 else SP0) * lay["KT"])
-        hinR = new(S * lay["KT"]) if l > 1 else None
+        if meta.need_wgrad:
+            with _timed("layer%d_wgrad" % l):
+                check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
+                                        ptr(XR), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
+                                        ptr(dw_flat[off:off + mp * ka]), st))
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(nextR), ptr(hinR), st))
-        if meta.need_wgrad:
-            with _timed("layer%d_wgrad" % l):
-                check(L.stpde_jet_wgrad(C.byref(d), S, ptr(abarR), ptr(hinR), ptr(X), ptr(XR),
-                                        ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
-                                        ptr(dw_flat[off:off + mp * ka]), st))
-        abarR = nextR
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
         off, mp, ka = plan.dw_off[0]
         with _timed("layer0_wgrad"):
-            check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abarR), None, ptr(X), ptr(XR), None, None,
+            check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), ptr(XR), None, None,
                                     ptr(dw_flat[off:off + mp * ka]), st))
     if dlatent is not None:
         xd = XbarDesc()
@@ -351,7 +344,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
         wt = (C.c_void_p * 5)()
         for l in range(5):
             xd.MT[l] = plan.layers[l]["MT"]
-            xd.SP[l] = 1 if l == 0 else S
+            xd.SP[l] = SP0 if l == 0 else S
             ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
             wt[l] = pv(packs, l, "WsT").data_ptr()
         with _timed("xbar_scatter"):
