@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
   const int v = tile * 16 + j;
   const bool vin = v < a.nvox;
   const Vox c = vox_coords(a.d, vin ? v : 0);
-  for (int mt0 = 0; mt0 < MT; mt0 += MC) {
+  // large volumes: one wave walks all output-channel chunks of its 16 voxels (inputs stay hot in L1);
+  // small volumes (deep U-Net levels): the chunks are spread over blockIdx.y so that the chip is not idle
+  for (int mt0 = blockIdx.y * MC; mt0 < MT; mt0 += gridDim.y * MC) {
     f32x4 acc[MC];
 #pragma unroll
     for (int mi = 0; mi < MC; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -177,7 +179,9 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
   a.y = y;
   a.nvox = d->B * d->T * d->Z * d->X;
   const int ntiles = (a.nvox + 15) / 16;
-  STPDE_LAUNCH(k_conv3d_fwd<4>, dim3((ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  const int nchunks = (d->Co / 16 + 3) / 4;
+  const int gy = (ntiles + 3) / 4 >= 1024 ? 1 : nchunks;
+  STPDE_LAUNCH(k_conv3d_fwd<4>, dim3((ntiles + 3) / 4, gy), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_conv3d_fwd");
 }
 
