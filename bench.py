@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=1 << 20)
     ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
-    ap.add_argument("--chunk", type=int, default=1 << 17, help="points per launch chunk")
+    ap.add_argument("--chunk", type=int, default=1 << 18, help="points per launch chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

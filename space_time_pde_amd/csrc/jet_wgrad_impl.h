@@ -269,7 +269,18 @@ static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
 
 template <int S1, int S2>
 static int launch_mode(const WgradArgs& a, int mode, hipStream_t stream) {
-  if (mode == 0) return launch_wgrad_act<S1, S2, 0, -1>(a, stream);
+  if (mode == 0) {
+    // the produce stage (one activation jet per ring slot) is the VALU-heavy part of the narrow layers:
+    // compile-time activation (branch-free) there as well
+    switch (a.cfg.act) {
+      case STPDE_ACT_TANH: return launch_wgrad_act<S1, S2, 0, STPDE_ACT_TANH>(a, stream);
+      case STPDE_ACT_RELU: return launch_wgrad_act<S1, S2, 0, STPDE_ACT_RELU>(a, stream);
+      case STPDE_ACT_SOFTPLUS: return launch_wgrad_act<S1, S2, 0, STPDE_ACT_SOFTPLUS>(a, stream);
+      case STPDE_ACT_ELU: return launch_wgrad_act<S1, S2, 0, STPDE_ACT_ELU>(a, stream);
+      case STPDE_ACT_LEAKYRELU: return launch_wgrad_act<S1, S2, 0, STPDE_ACT_LEAKYRELU>(a, stream);
+      default: return launch_wgrad_act<S1, S2, 0, STPDE_ACT_SWISH>(a, stream);
+    }
+  }
   switch (a.cfg.act) {
     case STPDE_ACT_TANH: return launch_wgrad_act<S1, S2, 1, STPDE_ACT_TANH>(a, stream);
     case STPDE_ACT_RELU: return launch_wgrad_act<S1, S2, 1, STPDE_ACT_RELU>(a, stream);
