@@ -187,10 +187,10 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // 4 ways.  One barrier per 4 k-tiles; production of group g+1 sits in the same basic block as the MFMAs of group g.
 // Requires KT % 4 == 0 and MT % (4*MCg) == 0 (otherwise the per-wave kernel above is used).
 // ------------------------------------------------------------------------------------------------------------
-template <int S1, int S2, int MCg, int PRO, int EPI, int ACT>
-__global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2;
-  __shared__ __attribute__((aligned(16))) float hb[2][4][S][256];
+  __shared__ __attribute__((aligned(16))) float hb[2][NW][S][256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int tile = blockIdx.x;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
     for (int st = 0; st < S; ++st) st4(&hb[buf][wv][st][lo], B[st]);
   };
 
-  const int ngroups = KT / 4;
-  for (int mt0 = wv * MCg; mt0 < MT; mt0 += 4 * MCg) {
+  const int ngroups = KT / NW;
+  for (int mt0 = wv * MCg; mt0 < MT; mt0 += NW * MCg) {
     f32x4 acc[MCg][S];
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
     for (int gi = 0; gi < ngroups; ++gi) {
       const int buf = gi & 1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kt = 4 * gi + q;
+      for (int q = 0; q < NW; ++q) {
+        const int kt = NW * gi + q;
         f32x4 B[S], w[MCg];
 #pragma unroll
         for (int st = 0; st < S; ++st) B[st] = ld4(&hb[buf][q][st][lo]);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
       }
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
-      produce(gi + 1 < ngroups ? 4 * (gi + 1) + wv : 4 * gi + wv, buf ^ 1);
+      produce(gi + 1 < ngroups ? NW * (gi + 1) + wv : NW * gi + wv, buf ^ 1);
       __syncthreads();
     }
 #pragma unroll
@@ -268,21 +268,21 @@ __global__ __launch_bounds__(256) void k_layer_coop(LayerArgs a) {
   }
 }
 
-template <int S1, int S2, int MCg, int PRO, int EPI, int ACT>
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
 static int launch_layer_coop(const LayerArgs& a, hipStream_t stream) {
-  STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT>), dim3(a.ntiles), dim3(256), 0, stream, a);
+  STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW>), dim3(a.ntiles), dim3(64 * NW), 0, stream, a);
   return stpde_check_launch("k_layer_coop");
 }
 
-template <int S1, int S2, int PRO, int EPI, int MCg>
+template <int S1, int S2, int PRO, int EPI, int MCg, int NW>
 static int launch_coop_act(const LayerArgs& a, hipStream_t stream) {
   switch (a.cfg.act) {
-    case STPDE_ACT_TANH: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_TANH>(a, stream);
-    case STPDE_ACT_RELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_RELU>(a, stream);
-    case STPDE_ACT_SOFTPLUS: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_SOFTPLUS>(a, stream);
-    case STPDE_ACT_ELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_ELU>(a, stream);
-    case STPDE_ACT_LEAKYRELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_LEAKYRELU>(a, stream);
-    default: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_SWISH>(a, stream);
+    case STPDE_ACT_TANH: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_TANH, NW>(a, stream);
+    case STPDE_ACT_RELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_RELU, NW>(a, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_SOFTPLUS, NW>(a, stream);
+    case STPDE_ACT_ELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_ELU, NW>(a, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_LEAKYRELU, NW>(a, stream);
+    default: return launch_layer_coop<S1, S2, MCg, PRO, EPI, STPDE_ACT_SWISH, NW>(a, stream);
   }
 }
 
@@ -310,9 +310,16 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
   if (a.MT % 4 != 0) return launch_layer<S1, S2, 4, PRO, EPI, -1, true>(a, stream);
   // workgroup-cooperative variant: B operand produced once per 4 waves (S = 10 would not fit two workgroups of LDS)
   if (a.KT % 4 == 0 && a.KT >= 8 && S1 + S2 <= 5) {
-    // dgrad epilogues are VALU heavy: 2 tiles per wave keeps two workgroups per CU so they overlap with MFMAs
-    if (EPI == EPI_FWD && a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4>(a, stream);
-    if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2>(a, stream);
+    if (EPI == EPI_FWD) {
+      if (a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4, 4>(a, stream);
+      if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
+    } else {
+      // dgrad epilogues are VALU heavy: 2 output tiles per wave keeps two waves per SIMD.  Measured on MI355X: the
+      // 8-wave workgroup (one pass over 16 output tiles) wins when it makes the kernel single-pass (MT == 16);
+      // for MT == 32 four passes of the 4-wave workgroup are faster than two passes of the 8-wave one.
+      if (a.KT % 8 == 0 && a.MT == 16) return launch_coop_act<S1, S2, PRO, EPI, 2, 8>(a, stream);
+      if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
+    }
   }
   // kernels that stream their B operand from memory (everything except the layer-0-on-the-fly forward) halve that
   // traffic with 8 output tiles per pass; S=10 would not fit the register file
