@@ -116,7 +116,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("STPDE_BENCH_FORCE_DIST") == "1"   # exercise the RCCL code path with a single rank
+    if world > 1 or (force_dist and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=dev)
 
     from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
@@ -153,7 +154,8 @@ def main():
     def step():
         for p in params + uparams:
             p.grad = None
-        loss, _, _ = sharded_step(unet, net, layer, crop, pts, tgt, args.points, ALPHA_REG, ALPHA_PDE, "l1")
+        loss, _, _ = sharded_step(unet, net, layer, crop, pts, tgt, args.points, ALPHA_REG, ALPHA_PDE, "l1",
+                                  distributed=True if (force_dist and dist.is_initialized()) else None)
         return loss
 
     def sync():
@@ -223,7 +225,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.act)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -152,6 +152,17 @@ int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_
 /* dW[tap][Co][Ci] += sum_voxels ybar[v][co] * x[v + offset(tap)][ci]  (fp32 atomics; caller zero-fills dW). */
 int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, void* stream);
 
+/* ---- N1: train-step tail -- gradient value clipping + Adam in one pass ---------------------------------
+ * Replaces torch.nn.utils.clip_grad_value_ + optim.Adam.step of experiments/rb2d/train.py:79-83 for one
+ * parameter tensor (fp32, 16-byte aligned).  g = clamp(grad, +-clip) (clip <= 0: off); m, v, p are updated in
+ * place with torch.optim.Adam's formulas: step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t). */
+typedef struct {
+  long n;
+  float clip, beta1, beta2, eps, weight_decay, step_size, bias2_sqrt;
+} stpde_adam_desc;
+int stpde_clip_adam(const stpde_adam_desc* d, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
@@ -42,6 +42,11 @@ class XbarDesc(C.Structure):
 class Conv3dDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("Z", C.c_int), ("X", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("ksize", C.c_int)]
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("n", C.c_long), ("clip", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step_size", C.c_float), ("bias2_sqrt", C.c_float)]
 
 
 class InterpDesc(C.Structure):
@@ -105,6 +110,7 @@ _SIGNATURES = {
     "stpde_interp_bwd_grid": ([C.POINTER(InterpDesc)] + [_VP] * 5, C.c_int),
     "stpde_conv3d_fwd": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),
     "stpde_conv3d_wgrad": ([C.POINTER(Conv3dDesc)] + [_VP] * 4, C.c_int),
+    "stpde_clip_adam": ([C.POINTER(AdamDesc)] + [_VP] * 5, C.c_int),
 }
 
 

@@ -28,22 +28,6 @@ __device__ __forceinline__ void st_R(float* block, int lane, f32x4 v) {
   p[12] = v[3];
 }
 
-// Same re-layout through a wave-private 1 KiB LDS patch, so that the global store is ONE coalesced float4 per lane
-// (lane-linear 1 KiB) instead of four scattered dwords: write patch[feature][row], read back 4 consecutive rows.
-// Two-way bank conflicts on the b32 writes are free on CDNA4; the b128 read is conflict-free.
-__device__ __forceinline__ void st_R_lds(float* block, float* patch, int lane, f32x4 v) {
-  const int g = lane >> 4, j = lane & 15;
-  float* w = patch + (4 * g) * 16 + j;
-  w[0] = v[0];
-  w[16] = v[1];
-  w[32] = v[2];
-  w[48] = v[3];
-  __builtin_amdgcn_wave_barrier();
-  const f32x4 t = *reinterpret_cast<const f32x4*>(patch + j * 16 + 4 * g);   // lane 16g'+c: rows 4g'.. of feature c
-  __builtin_amdgcn_wave_barrier();
-  st4(block + lane * 4, t);
-}
-
 // sigma and its first three derivatives; conventions at kinks follow torch (relu'(0)=0, softplus threshold 20).
 // Branch-free (selects only) so that the evaluation can be interleaved with MFMAs by the scheduler.
 struct ActD {

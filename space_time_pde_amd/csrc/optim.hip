@@ -1,0 +1,68 @@
+// Train-step tail: gradient value clipping + Adam update fused into one pass over a
+// parameter tensor.  Replaces torch.nn.utils.clip_grad_value_ + optimizer.step() of the reference
+// (experiments/rb2d/train.py:79-83, optim.Adam at :330-333).  Pure HBM streaming: 16 B read (p, g, m, v) and 12 B
+// written (p, m, v) per element, float4 accesses, grid-stride.
+#include "common.h"
+
+struct AdamArgs {
+  stpde_adam_desc d;
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+};
+
+__device__ __forceinline__ void adam_elem(const stpde_adam_desc& d, float& p, float g, float& m, float& v) {
+  if (d.clip > 0.f) g = fminf(fmaxf(g, -d.clip), d.clip);        // clip_grad_value_
+  if (d.weight_decay != 0.f) g = g + d.weight_decay * p;
+  m = m + (1.f - d.beta1) * (g - m);                             // torch: exp_avg.lerp_(grad, 1 - beta1)
+  v = d.beta2 * v + (1.f - d.beta2) * g * g;                     // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+  const float denom = sqrtf(v) / d.bias2_sqrt + d.eps;
+  p = p - d.step_size * (m / denom);                             // addcdiv_(exp_avg, denom, value=-lr/bias1)
+}
+
+__global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
+  const long n4 = a.d.n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 p = ld4(a.p + 4 * i), g = ld4(a.g + 4 * i), m = ld4(a.m + 4 * i), v = ld4(a.v + 4 * i);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pp = p[r], mm = m[r], vv = v[r];
+      adam_elem(a.d, pp, g[r], mm, vv);
+      p[r] = pp;
+      m[r] = mm;
+      v[r] = vv;
+    }
+    st4(a.p + 4 * i, p);
+    st4(a.m + 4 * i, m);
+    st4(a.v + 4 * i, v);
+  }
+  if (blockIdx.x == 0) {  // tail (n not a multiple of 4)
+    const long i = n4 * 4 + threadIdx.x;
+    if (i < a.d.n) {
+      float pp = a.p[i], mm = a.m[i], vv = a.v[i];
+      adam_elem(a.d, pp, a.g[i], mm, vv);
+      a.p[i] = pp;
+      a.m[i] = mm;
+      a.v[i] = vv;
+    }
+  }
+}
+
+extern "C" int stpde_clip_adam(const stpde_adam_desc* d, float* param, const float* grad, float* exp_avg,
+                               float* exp_avg_sq, void* stream) {
+  if (!d || d->n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !(d->bias2_sqrt > 0.f)) {
+    stpde_set_error("clip_adam: bad argument");
+    return STPDE_E_BADARG;
+  }
+  if (((size_t)param | (size_t)grad | (size_t)exp_avg | (size_t)exp_avg_sq) & 15) {
+    stpde_set_error("clip_adam: pointers must be 16-byte aligned");
+    return STPDE_E_BADARG;
+  }
+  AdamArgs a{*d, param, grad, exp_avg, exp_avg_sq};
+  long blocks = (d->n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  STPDE_LAUNCH(k_clip_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_clip_adam");
+}

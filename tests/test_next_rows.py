@@ -1,0 +1,95 @@
+"""Section-8(f) "next" rows: fused clip+Adam (N1), dense-lattice inference (N2), reference checkpoint format (N4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from space_time_pde_amd import implicit_net, inference, local_implicit_grid as lig, physics, train_utils, unet3d
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """Dict keys / file naming of src/train_utils.py:13-30 + experiments/rb2d/train.py:390-397; resume as :339-350."""
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(4, 8, 8), nf=4, mf=8)
+    imnet = implicit_net.ImNet(nf=4)
+    opt = torch.optim.Adam(list(unet.parameters()) + list(imnet.parameters()), lr=1e-3)
+    state = {"epoch": 2, "unet_state_dict": unet.state_dict(), "imnet_state_dict": imnet.state_dict(),
+             "optim_state_dict": opt.state_dict(), "tracked_stats": 0.5, "global_step": np.zeros(1, dtype=np.uint32)}
+    folder = str(tmp_path / "checkpoint_latest.pth.tar")
+    open(folder + "_pdenet_001.pth.tar", "w").close()
+    path = train_utils.save_checkpoint(state, True, 2, folder, "_pdenet")
+    assert os.path.basename(path) == "checkpoint_latest.pth.tar_pdenet_002.pth.tar"      # reference naming quirk
+    assert not os.path.exists(folder + "_pdenet_001.pth.tar")
+    assert os.path.exists(folder + "_pdenet_best.pth.tar")
+    unet2 = unet3d.UNet3d(in_features=4, out_features=32, igres=(4, 8, 8), nf=4, mf=8)
+    imnet2 = implicit_net.ImNet(nf=4)
+    # also accept DataParallel-prefixed dicts
+    ck = torch.load(path, weights_only=False)
+    ck["imnet_state_dict"] = {"module." + k: v for k, v in ck["imnet_state_dict"].items()}
+    torch.save(ck, path)
+    info = train_utils.load_checkpoint(path, unet2, imnet2)
+    assert info["epoch"] == 2 and info["tracked_stats"] == 0.5
+    for a, b in zip(unet.state_dict().values(), unet2.state_dict().values()):
+        assert torch.equal(a, b)
+    for a, b in zip(imnet.state_dict().values(), imnet2.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+def test_evaluate_feat_grid_generic_cpu():
+    """evaluation.py:26-74 result layout on the generic strategy (CPU)."""
+    net = implicit_net.ImNet(nf=4, activation=torch.nn.Softplus)
+    lat = torch.rand(1, 4, 5, 6, 32)
+    layer = physics.get_rb2_pde_layer(use_continuity=True)
+    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, lat, p, 0., 1.))
+    t, z, x = torch.linspace(0.1, 0.9, 3), torch.linspace(0.1, 0.9, 4), torch.linspace(0.1, 0.9, 5)
+    res = inference.evaluate_feat_grid(layer, lat, t, z, x, None, None, pseudo_batch_size=16)
+    assert set(res) == {"p", "b", "u", "w", "transport_eqn_b", "transport_eqn_u", "transport_eqn_w", "continuity"}
+    assert all(v.shape == (3, 4, 5) for v in res.values())
+
+
+@pytest.mark.gpu
+def test_evaluate_feat_grid_hip_matches_generic(hiplib):
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = implicit_net.ImNet(nf=16, activation=torch.nn.Softplus).to(dev)
+    lat = torch.rand(1, 4, 8, 8, 32, device=dev)
+    mean, std = (0.01, 0.0, 0.02, -0.01), (0.05, 0.3, 0.15, 0.12)
+    layer = physics.get_rb2_pde_layer(mean=mean, std=std, t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
+    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, lat, p, 0., 1.))
+    t, z, x = torch.linspace(0.05, 0.95, 7), torch.linspace(0.05, 0.95, 9), torch.linspace(0.05, 0.95, 11)
+    n0 = lig.stats["hip_jet_calls"]
+    res = inference.evaluate_feat_grid(layer, lat, t, z, x, None, None, pseudo_batch_size=300)
+    assert lig.stats["hip_jet_calls"] > n0
+    netc, latc = implicit_net.ImNet(nf=16, activation=torch.nn.Softplus), lat.cpu()
+    netc.load_state_dict(net.state_dict())
+    layer_c = physics.get_rb2_pde_layer(mean=mean, std=std, t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
+    layer_c.update_forward_method(lambda p: lig.query_local_implicit_grid(netc, latc, p, 0., 1.))
+    ref = inference.evaluate_feat_grid(layer_c, latc, t, z, x, None, None, pseudo_batch_size=300)
+    for k in ref:
+        assert np.abs(res[k] - ref[k]).max() < 5e-5 * np.abs(ref[k]).max(), k
+
+
+@pytest.mark.gpu
+def test_fused_clip_adam_matches_torch(hiplib):
+    """N1: stpde_clip_adam == clip_grad_value_ + torch.optim.Adam over several steps, incl. a non-multiple-of-4 size."""
+    from space_time_pde_amd.optim import FusedClipAdam
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    shapes = [(128, 291), (37,), (5, 3, 3, 3, 3)]
+    pa = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedClipAdam(pa, lr=1e-2, clip_grad=0.5)
+    ob = torch.optim.Adam(pb, lr=1e-2)
+    for it in range(4):
+        grads = [torch.randn(s, generator=g).to(dev) * 2 for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        torch.nn.utils.clip_grad_value_(pb, 0.5)
+        oa.step()
+        ob.step()
+        for p, q in zip(pa, pb):
+            assert (p - q).abs().max().item() < 2e-6
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"][0].keys() == sb["state"][0].keys()        # checkpoint-compatible state layout
+    ob.load_state_dict(sa)
