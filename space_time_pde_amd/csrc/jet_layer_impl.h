@@ -26,6 +26,7 @@ struct LayerArgs {
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
   float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
   int KT, MT, ntiles;
+  int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   stpde_jet_cfg cfg;
 };
 
@@ -193,9 +194,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   __shared__ __attribute__((aligned(16))) float hb[2][NW][S][256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
   const int KT = a.KT, MT = a.MT;
   const int lo = lane * 4;
+  // Pass splitting (dgrad of wide layers): the output passes of one row tile are run by different workgroups that
+  // sit in consecutive slots of the SAME XCD (block b runs on XCD b % 8), i.e. at the same time on the same L2, so
+  // the tile's B operand is fetched from HBM once instead of once per pass.
+  int tile = blockIdx.x, pass0 = 0, pstep = 1;
+  if (a.split > 0) {
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    pass0 = slot % a.split;
+    pstep = a.split;
+    tile = (slot / a.split) * 8 + xcd;
+    if (tile >= a.ntiles) return;
+  }
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   };
 
   const int ngroups = KT / NW;
-  for (int mt0 = wv * MCg; mt0 < MT; mt0 += NW * MCg) {
+  for (int mt0 = (pass0 * NW + wv) * MCg; mt0 < MT; mt0 += pstep * NW * MCg) {
     f32x4 acc[MCg][S];
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
@@ -269,8 +280,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 }
 
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
-static int launch_layer_coop(const LayerArgs& a, hipStream_t stream) {
-  STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW>), dim3(a.ntiles), dim3(64 * NW), 0, stream, a);
+static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
+  LayerArgs a = a0;
+  const int npass = a.MT / (NW * MCg);
+  // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
+  a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
+  const int nblocks = a.split ? (a.ntiles + 7) / 8 * 8 * a.split : a.ntiles;
+  STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   return stpde_check_launch("k_layer_coop");
 }
 

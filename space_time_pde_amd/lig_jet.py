@@ -230,15 +230,32 @@ def box_constants(shape3, xmin, xmax):
 
 
 _box_cache = {}
+_box_tensor_cache = None   # WeakKeyDictionary: tensor object -> (version, {shape: constants})
 _box_lock = threading.Lock()
 
 
 def cached_box_constants(shape3, xmin, xmax):
-    """Avoid a device sync per call when xmin/xmax are device tensors that do not change."""
+    """box_constants with a cache, so that device-tensor bounds (train.py:48-49 passes CUDA tensors) do not cost a
+    device sync per call.  Tensor entries are keyed on the tensor OBJECTS through weak references plus their version
+    counters (an id()/data_ptr key could alias a freed tensor); python scalars / sequences are keyed by value."""
+    global _box_tensor_cache
+    shape3 = tuple(shape3)
+    if torch.is_tensor(xmin) and torch.is_tensor(xmax):
+        import weakref
+        with _box_lock:
+            if _box_tensor_cache is None:
+                _box_tensor_cache = weakref.WeakKeyDictionary()
+            ent = _box_tensor_cache.get(xmin)
+            key = (shape3, id(xmax), xmin._version, xmax._version)
+            if ent is not None and ent[0] == key and ent[1]() is xmax:
+                return ent[2]
+        val = box_constants(shape3, xmin, xmax)
+        with _box_lock:
+            _box_tensor_cache[xmin] = (key, weakref.ref(xmax), val)
+        return val
     if torch.is_tensor(xmin) or torch.is_tensor(xmax):
-        key = (tuple(shape3), id(xmin), id(xmax), getattr(xmin, "_version", 0), getattr(xmax, "_version", 0))
-    else:
-        key = (tuple(shape3), repr(xmin), repr(xmax))
+        return box_constants(shape3, xmin, xmax)
+    key = (shape3, repr(xmin), repr(xmax))
     with _box_lock:
         if key not in _box_cache:
             if len(_box_cache) > 64:

@@ -147,6 +147,8 @@ class PDELayer(object):
             return None
         if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 3 and self.n_in == 3):
             return None
+        if x.requires_grad and torch.is_grad_enabled():
+            return None   # the caller wants autograd through the coordinates: only the generic strategy provides it
         first, pairs = False, set()
         for prog in self.eqns_jet.values():
             for _, mi in prog.atoms:
