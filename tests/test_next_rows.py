@@ -93,3 +93,44 @@ def test_fused_clip_adam_matches_torch(hiplib):
     sa, sb = oa.state_dict(), ob.state_dict()
     assert sa["state"][0].keys() == sb["state"][0].keys()        # checkpoint-compatible state layout
     ob.load_state_dict(sa)
+
+
+def _synthetic_dataset(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(4, 12, 40, 24, generator=g)      # [c, t, z, x]
+
+
+def _check_loader_against_scipy(dev):
+    """N3: crop + linear down-sampling + target interpolation == dataloader_spacetime.py:133-156 (scipy)."""
+    from scipy.interpolate import RegularGridInterpolator
+    from space_time_pde_amd.dataloader_spacetime import RB2DeviceLoader
+    data = _synthetic_dataset()
+    ld = RB2DeviceLoader(data, nx=16, nz=16, nt=8, n_samp_pts_per_crop=64, downsamp_xz=4, downsamp_t=2,
+                         normalize_output=True, device=dev)
+    assert len(ld) == (12 - 8 + 1) * (40 - 16 + 1) * (24 - 16 + 1)
+    idx = [0, 57, len(ld) - 1]
+    g = torch.Generator().manual_seed(1)
+    pc = torch.rand(3, 64, 3, generator=g)
+    lres, pcoord, pval = ld.get(idx, point_coord=pc.to(dev))
+    assert lres.shape == (3, 4, 4, 4, 4) and pval.shape == (3, 64, 4)
+    mean, std = data.mean(dim=(1, 2, 3)).numpy(), data.std(dim=(1, 2, 3), unbiased=False).numpy()
+    nzr, nxr = 40 - 16 + 1, 24 - 16 + 1
+    for b, i in enumerate(idx):
+        t0, z0, x0 = i // (nzr * nxr), (i // nxr) % nzr, i % nxr
+        crop = data[:, t0:t0 + 8, z0:z0 + 16, x0:x0 + 16].numpy()
+        interp = RegularGridInterpolator((np.arange(8), np.arange(16), np.arange(16)), crop.transpose(1, 2, 3, 0))
+        lc = np.stack(np.meshgrid(np.linspace(0, 7, 4), np.linspace(0, 15, 4), np.linspace(0, 15, 4), indexing='ij'), -1)
+        want_l = (interp(lc).transpose(3, 0, 1, 2) - mean[:, None, None, None]) / std[:, None, None, None]
+        want_p = (interp(pc[b].numpy() * np.array([7, 15, 15])) - mean) / std
+        # end points of the lattice are clipped by eps = 1e-6 * extent like every call of the reference interpolation routine
+        np.testing.assert_allclose(lres[b].cpu().numpy(), want_l, rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(pval[b].cpu().numpy(), want_p, rtol=1e-4, atol=2e-4)
+
+
+def test_device_loader_generic_cpu():
+    _check_loader_against_scipy("cpu")
+
+
+@pytest.mark.gpu
+def test_device_loader_hip(hiplib):
+    _check_loader_against_scipy("cuda:0")
