@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
     ap.add_argument("--chunk", type=int, default=1 << 18, help="points per launch chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,8 +197,15 @@ def main():
         rows_per_launch = 8 * min(args.chunk, n_local)
         flop_launch = 2.0 * macs.get(dom, 0) * rows_per_launch
         ach = flop_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:    # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (same chunk size)
+            tj = json.load(open(args.traffic_json))
+            if tj.get("chunk") == min(args.chunk, n_local) and tj.get("act") == args.act and dom in tj["kernels"]:
+                traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], tj.get("source")
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=None,
+                        frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3),
                         step_algorithmic_tflops=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world, 2),
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
