@@ -107,9 +107,12 @@ int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, co
 /* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
  * jets[(s*n_out + ch)*ldp + p] (ldp >= P lets a chunk of points write into a larger [S][n_out][Ptotal] array)
  * from out_pre[tile][S][1][64][4] (fc5 output) and coef; and its adjoint. */
-int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* out_pre, const float* coef,
-                         float* jets, long ldp, void* stream);
-int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
+/* S_mlp = number of streams held by the layer buffers: 1 + S1 + S2, or 1 + S1 for piecewise-linear activations
+ * (relu / leaky-relu: sigma'' = 0, so every second-order MLP stream is identically zero and is not carried; the
+ * second derivatives of y then come from the weight-derivative cross terms alone). */
+int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, const float* out_pre,
+                         const float* coef, float* jets, long ldp, void* stream);
+int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, const float* jets_bar, long ldp,
                          const float* coef, float* abar_out, void* stream);
 
 /* ---- backward of the gather: d latent (index_put accumulate, backward of :65-66) --------------------

@@ -103,8 +103,8 @@ _SIGNATURES = {
     "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 9, C.c_int),
     "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 8, C.c_int),
     "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 8, C.c_int),
-    "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
-    "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),
+    "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
+    "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),
     "stpde_interp_fwd": ([C.POINTER(InterpDesc)] + [_VP] * 7, C.c_int),
     "stpde_interp_bwd_grid": ([C.POINTER(InterpDesc)] + [_VP] * 5, C.c_int),

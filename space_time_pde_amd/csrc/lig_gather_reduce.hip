@@ -165,6 +165,7 @@ __device__ __forceinline__ float pair_ddw(const CornerW& c, int d, int e) {
 struct ReduceArgs {
   stpde_jet_cfg cfg;
   int P, n_out;
+  int S_mlp;   // streams present in the layer buffers (piecewise-linear activations carry no second-order streams)
   long ldp;
   const float* src;  // fwd: out_pre [tile][S][1][256]; bwd: jets_bar [S][n_out][P]
   const float* coef;
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(256) void k_reduce_fwd(ReduceArgs a) {
   for (int corner = 0; corner < 8; ++corner) {
     const int j = ((p & 1) << 3) | corner;
     const int lane = ((ch >> 2) << 4) | j;
-    const float* base = a.src + (size_t)tile * S * 256 + lane * 4 + (ch & 3);
+    const float* base = a.src + (size_t)tile * a.S_mlp * 256 + lane * 4 + (ch & 3);
     float f[10];
 #pragma unroll
-    for (int s = 0; s < 10; ++s) f[s] = s < S ? base[(size_t)s * 256] : 0.f;
+    for (int s = 0; s < 10; ++s) f[s] = s < a.S_mlp ? base[(size_t)s * 256] : 0.f;
     CornerW c = corner_weights(cf, corner);
     y[0] += c.w * f[0];
     if (S1 == 3) {
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   const int tile = p >> 1;
   const int j = ((p & 1) << 3) | corner;
   const int lane = ((ch >> 2) << 4) | j;
-  float* base = a.dst + (size_t)tile * S * 256 + lane * 4 + (ch & 3);
+  float* base = a.dst + (size_t)tile * a.S_mlp * 256 + lane * 4 + (ch & 3);
   float fb[10];
 #pragma unroll
   for (int s = 0; s < 10; ++s) fb[s] = 0.f;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   }
 #pragma unroll
   for (int s = 0; s < 10; ++s)
-    if (s < S) base[(size_t)s * 256] = fb[s];
+    if (s < a.S_mlp) base[(size_t)s * 256] = fb[s];
 }
 
 static int check_reduce(const stpde_jet_cfg* cfg, int P, int n_out, const void* a, const void* b, const void* c) {
@@ -287,29 +288,29 @@ static int check_reduce(const stpde_jet_cfg* cfg, int P, int n_out, const void* 
   return STPDE_OK;
 }
 
-extern "C" int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* out_pre,
+extern "C" int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, const float* out_pre,
                                     const float* coef, float* jets, long ldp, void* stream) {
   int rc = check_reduce(cfg, P, n_out, out_pre, coef, jets);
   if (rc) return rc;
-  if (ldp < P) {
-    stpde_set_error("lig_reduce_fwd: ldp < P");
+  if (ldp < P || S_mlp < 1 || S_mlp > 1 + cfg->S1 + cfg->S2) {
+    stpde_set_error("lig_reduce_fwd: ldp < P or bad S_mlp");
     return STPDE_E_BADARG;
   }
-  ReduceArgs a{*cfg, P, n_out, ldp, out_pre, coef, jets};
+  ReduceArgs a{*cfg, P, n_out, S_mlp, ldp, out_pre, coef, jets};
   const size_t n = (size_t)P * n_out;
   STPDE_LAUNCH(k_reduce_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_fwd");
 }
 
-extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int P, int n_out, const float* jets_bar, long ldp,
-                                    const float* coef, float* abar_out, void* stream) {
+extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, const float* jets_bar,
+                                    long ldp, const float* coef, float* abar_out, void* stream) {
   int rc = check_reduce(cfg, P, n_out, jets_bar, coef, abar_out);
   if (rc) return rc;
-  if (ldp < P) {
-    stpde_set_error("lig_reduce_bwd: ldp < P");
+  if (ldp < P || S_mlp < 1 || S_mlp > 1 + cfg->S1 + cfg->S2) {
+    stpde_set_error("lig_reduce_bwd: ldp < P or bad S_mlp");
     return STPDE_E_BADARG;
   }
-  ReduceArgs a{*cfg, P, n_out, ldp, jets_bar, coef, abar_out};
+  ReduceArgs a{*cfg, P, n_out, S_mlp, ldp, jets_bar, coef, abar_out};
   const size_t n = (size_t)P * 128;
   STPDE_LAUNCH(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_bwd");

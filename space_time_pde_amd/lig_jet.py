@@ -311,7 +311,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         bufs.append(out)
         prev = out
     with _timed("reduce_fwd"):
-        check(L.stpde_lig_reduce_fwd(C.byref(cfg), Pc, plan.cout, ptr(bufs[5]), ptr(coef),
+        check(L.stpde_lig_reduce_fwd(C.byref(meta.cfg_out), S, Pc, plan.cout, ptr(bufs[5]), ptr(coef),
                                      C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
     return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc)
 
@@ -330,7 +330,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
     SP0 = 1 + cfg.S1
     # adjoint of the fc5 output rows (overwrites the forward's out_pre buffer)
     with _timed("reduce_bwd"):
-        check(L.stpde_lig_reduce_bwd(C.byref(cfg), Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
+        check(L.stpde_lig_reduce_bwd(C.byref(meta.cfg_out), S, Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
                                      jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
     abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
     for l in range(5, 0, -1):
@@ -375,7 +375,7 @@ class LigJetFunction(torch.autograd.Function):
     def forward(ctx, meta, latent, pts, *params):
         packs = meta.plan.pack(params)
         P = pts.shape[0]
-        jets = torch.empty(meta.S, meta.plan.cout, P, device=pts.device)
+        jets = torch.empty(meta.S_out, meta.plan.cout, P, device=pts.device)
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         saved = []
         chunk = meta.chunk
@@ -466,7 +466,14 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
         raise ValueError("latent channels != imnet.in_features")
     meta = _Meta()
     meta.plan = plan
-    meta.cfg, meta.S, ppairs = make_cfg(act, prm, first, list(pairs))
+    # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
+    # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams
+    # go through the network and the reduction supplies the second derivatives from the weight cross terms
+    meta.cfg_out, meta.S_out, ppairs = make_cfg(act, prm, first, list(pairs))
+    if act in ("relu", "leakyrelu") and ppairs:
+        meta.cfg, meta.S, _ = make_cfg(act, prm, True, [])
+    else:
+        meta.cfg, meta.S = meta.cfg_out, meta.S_out
     meta.B, meta.N = B, N
     meta.grid_shape = tuple(latent_grid.shape[1:4])
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)
