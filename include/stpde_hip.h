@@ -45,11 +45,18 @@ extern "C" {
 /* Derivative-stream configuration shared by the jet kernels. */
 typedef struct {
   int S1;        /* 0 (value only) or 3 (value + d/dr_0..2)                         */
-  int S2;        /* number of second-order streams: 0, 2 or 6 compiled in           */
+  int S2;        /* number of second-order streams: 0, 1 (combined, see below), 2 or 6 compiled in */
   int pair0[6];  /* second-order stream k is d2/dr_pair0[k] dr_pair1[k]             */
   int pair1[6];
   int act;       /* STPDE_ACT_*  (src/nonlinearities.py:15-22)                       */
   float act_param; /* swish beta; leaky-relu slope is fixed at 0.01 (torch default) */
+  /* Combined second-order stream (S2 == 1): when every equation uses the second derivatives only through ONE linear
+   * combination  L y = sum_k alpha[k] d2y/dq_a dq_b  over the canonical pairs (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+   * (e.g. the anisotropic Laplacian of the Rayleigh-Benard equations), the MLP carries that single stream instead of
+   * one per pair: F' = sigma''(a) * sum_k c_k adot_a adot_b + sigma'(a) * (W F), with per-point weights
+   * c_k = alpha[k] * kappa_a * kappa_b written by stpde_lig_gather into cw[P][8]. */
+  int combo;     /* 1: S2 must be 1 and the stream is the combination above          */
+  float alpha[6];
 } stpde_jet_cfg;
 
 int stpde_version(void);
@@ -68,11 +75,12 @@ typedef struct {
   int P, N, B, n0, n1, n2, C;
   int p_base; /* global index of pts[0]: batch of point p is min((p_base + p) / N, B - 1) */
   float lo_c[3], hi_c[3], cube[3];
+  float alpha[6]; /* combined second-order stream weights (only read when cw != NULL) */
 } stpde_gather_desc;
 /* XR (optional, may be NULL): the same augmented input in the row-major fragment image (lane 16g+c holds rows
  * 4g..4g+3 of feature c), consumed by stpde_jet_wgrad. */
 int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X, float* XR,
-                     float* coef, int* cell, void* stream);
+                     float* coef, int* cell, float* cw /* [P][8] or NULL */, void* stream);
 
 /* ---- a4/a5/a6/a7: one IM-NET layer on all derivative streams --------------------------------------
  * Replaces the addmm + activation + cat of src/implicit_net.py:48-54 evaluated on the
@@ -86,14 +94,15 @@ typedef struct {
 } stpde_layer_desc;
 int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X, const float* Wh_pack,
                         const float* Ws_pack, const float* tanc, const float* W0s_pack, const float* tanc0,
-                        float* out_pre, void* stream);
+                        float* out_pre, const float* cw /* combined-stream weights or NULL */, void* stream);
 
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when
  * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise. */
 int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
-                        const float* X, const float* W0s_pack, const float* tanc0, float* abar0, void* stream);
+                        const float* X, const float* W0s_pack, const float* tanc0, float* abar0, const float* cw,
+                        void* stream);
 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
@@ -102,7 +111,8 @@ int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const 
  * with W0s_pack and tanc0R (layer-0 tangent constants in the row-major image).  XR = row-major augmented input from
  * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug. */
 int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* X,
-                    const float* XR, const float* W0s_pack, const float* tanc0R, float* dW_aug, void* stream);
+                    const float* XR, const float* W0s_pack, const float* tanc0R, float* dW_aug, const float* cw,
+                    void* stream);
 
 /* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
  * jets[(s*n_out + ch)*ldp + p] (ldp >= P lets a chunk of points write into a larger [S][n_out][Ptotal] array)

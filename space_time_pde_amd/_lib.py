@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
@@ -21,13 +21,13 @@ XT = 3
 
 class JetCfg(C.Structure):
     _fields_ = [("S1", C.c_int), ("S2", C.c_int), ("pair0", C.c_int * 6), ("pair1", C.c_int * 6),
-                ("act", C.c_int), ("act_param", C.c_float)]
+                ("act", C.c_int), ("act_param", C.c_float), ("combo", C.c_int), ("alpha", C.c_float * 6)]
 
 
 class GatherDesc(C.Structure):
     _fields_ = [("P", C.c_int), ("N", C.c_int), ("B", C.c_int), ("n0", C.c_int), ("n1", C.c_int), ("n2", C.c_int),
                 ("C", C.c_int), ("p_base", C.c_int), ("lo_c", C.c_float * 3), ("hi_c", C.c_float * 3),
-                ("cube", C.c_float * 3)]
+                ("cube", C.c_float * 3), ("alpha", C.c_float * 6)]
 
 
 class LayerDesc(C.Structure):
@@ -99,10 +99,10 @@ _VP = C.c_void_p
 _SIGNATURES = {
     "stpde_version": ([], C.c_int),
     "stpde_last_error": ([C.c_char_p, C.c_ulong], C.c_int),
-    "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
-    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 9, C.c_int),
-    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 8, C.c_int),
-    "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 8, C.c_int),
+    "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
+    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 10, C.c_int),
+    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 9, C.c_int),
+    "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 9, C.c_int),
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
     "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),

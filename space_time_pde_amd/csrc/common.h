@@ -117,8 +117,11 @@ __device__ __forceinline__ ActD act_eval(int act, float prm, float a) {
 __device__ __forceinline__ float sel3(int d, float a0, float a1, float a2) { return d == 0 ? a0 : (d == 1 ? a1 : a2); }
 
 // Forward jet of the activation on one fragment block: pre[S] (a, adot_d, addot_p) -> h[S].
+// S2 == 1 is the COMBINED second-order stream: cq[0..5] = per-row weights of adot_a*adot_b over the canonical pairs
+// (0,0) (0,1) (0,2) (1,1) (1,2) (2,2); otherwise cq is unused.
 template <int S1, int S2, int ACT>
-__device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h) {
+__device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h,
+                                            const float* cq = nullptr) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
@@ -128,6 +131,11 @@ __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x
       h[1][r] = s.s1 * a0;
       h[2][r] = s.s1 * a1;
       h[3][r] = s.s1 * a2;
+      if (S2 == 1) {
+        const float q = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
+        h[4][r] = s.s2 * q + s.s1 * pre[4][r];
+        continue;
+      }
 #pragma unroll
       for (int p = 0; p < S2; ++p) {
         float u = sel3(cfg.pair0[p], a0, a1, a2), v = sel3(cfg.pair1[p], a0, a1, a2);
@@ -140,7 +148,7 @@ __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x
 // Adjoint: given pre[S] and hbar[S], produce abar[S] (adjoint of the pre-activation streams).
 template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
-                                            f32x4* abar) {
+                                            f32x4* abar, const float* cq = nullptr) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
@@ -149,8 +157,18 @@ __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x
       float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
       float d0 = s.s1 * hbar[1][r], d1 = s.s1 * hbar[2][r], d2 = s.s1 * hbar[3][r];
       ab += s.s2 * (a0 * hbar[1][r] + a1 * hbar[2][r] + a2 * hbar[3][r]);
+      if (S2 == 1) {
+        const float hb = hbar[4][r];
+        const float q = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
+        ab += (s.s3 * q + s.s2 * pre[4][r]) * hb;
+        const float t = s.s2 * hb;
+        d0 += t * (2.f * cq[0] * a0 + cq[1] * a1 + cq[2] * a2);
+        d1 += t * (cq[1] * a0 + 2.f * cq[3] * a1 + cq[4] * a2);
+        d2 += t * (cq[2] * a0 + cq[4] * a1 + 2.f * cq[5] * a2);
+        abar[4][r] = s.s1 * hb;
+      }
 #pragma unroll
-      for (int p = 0; p < S2; ++p) {
+      for (int p = 0; p < (S2 == 1 ? 0 : S2); ++p) {
         int e0 = cfg.pair0[p], e1 = cfg.pair1[p];
         float u = sel3(e0, a0, a1, a2), v = sel3(e1, a0, a1, a2);
         float hb = hbar[4 + p][r];
@@ -177,6 +195,20 @@ __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x
     (void)hipGetLastError();   \
     hipLaunchKernelGGL(__VA_ARGS__); \
   } while (0)
+
+// per-row weights of the combined second-order stream: cw[P][8], point of row j of a tile = 2*tile + (j >> 3)
+template <int S2>
+__device__ __forceinline__ void load_cq(const float* cw, int point, float* cq) {
+  if (S2 == 1) {
+    const f32x4 v0 = ld4(cw + (size_t)point * 8), v1 = ld4(cw + (size_t)point * 8 + 4);
+    cq[0] = v0[0];
+    cq[1] = v0[1];
+    cq[2] = v0[2];
+    cq[3] = v0[3];
+    cq[4] = v1[0];
+    cq[5] = v1[1];
+  }
+}
 
 // Host-side helpers (api.cpp)
 void stpde_set_error(const char* fmt, ...);

@@ -5,9 +5,10 @@ static int dispatch_streams(const LayerArgs& a, int mode, hipStream_t stream) {
   const int S1 = a.cfg.S1, S2 = a.cfg.S2;
   if (S1 == 0 && S2 == 0) return stpde_layer_launch_0_0(a, mode, stream);
   if (S1 == 3 && S2 == 0) return stpde_layer_launch_3_0(a, mode, stream);
+  if (S1 == 3 && S2 == 1 && a.cfg.combo && a.cw) return stpde_layer_launch_3_1(a, mode, stream);
   if (S1 == 3 && S2 == 2) return stpde_layer_launch_3_2(a, mode, stream);
   if (S1 == 3 && S2 == 6) return stpde_layer_launch_3_6(a, mode, stream);
-  stpde_set_error("stream configuration S1=%d S2=%d not compiled (supported: (0,0) (3,0) (3,2) (3,6))", S1, S2);
+  stpde_set_error("stream configuration S1=%d S2=%d not compiled (supported: (0,0) (3,0) (3,1 combined, needs cw) (3,2) (3,6))", S1, S2);
   return STPDE_E_UNSUPPORTED;
 }
 
@@ -30,7 +31,8 @@ static int check_cfg(const stpde_layer_desc* d) {
 
 extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X,
                                    const float* Wh_pack, const float* Ws_pack, const float* tanc,
-                                   const float* W0s_pack, const float* tanc0, float* out_pre, void* stream) {
+                                   const float* W0s_pack, const float* tanc0, float* out_pre, const float* cw,
+                                   void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   LayerArgs a{};
@@ -42,6 +44,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
   a.Wsp = Ws_pack;
   a.tanc = tanc;
   a.Out = out_pre;
+  a.cw = cw;
   a.KT = d->KT;
   a.MT = d->MT;
   a.ntiles = d->ntiles;
@@ -66,7 +69,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
 
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
-                                   float* abar0, void* stream) {
+                                   float* abar0, const float* cw, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -76,6 +79,7 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
   a.X = X;
   a.W0s = W0s_pack;
   a.tanc0 = tanc0;
+  a.cw = cw;
   a.KT = d->MT;
   a.MT = d->KT;
   a.ntiles = d->ntiles;

@@ -25,6 +25,7 @@ struct LayerArgs {
   const float* Wsp;    // [XT][MT][256] packed skip weights (EPI_FWD)
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
   float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
+  const float* cw;     // [P][8] per-point weights of the combined second-order stream (S2 == 1), else unused
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   stpde_jet_cfg cfg;
@@ -48,7 +49,7 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 // pre-activations; dgrad = activation-jet adjoint against the stored / regenerated pre-activations + R-image copies.
 template <int S1, int S2, int EPI, int ACT>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
-                                               const f32x4* xb) {
+                                               const f32x4* xb, const float* cq) {
   constexpr int S = 1 + S1 + S2;
   const int lo = lane * 4;
   f32x4 (&acc)[1][S] = *reinterpret_cast<f32x4 (*)[1][S]>(accm);
@@ -80,7 +81,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
           for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab);
+      act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab, cq);
       constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
 #pragma unroll
       for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   if (tile >= a.ntiles) return;
   const int KT = a.KT, MT = a.MT;
   const int lo = lane * 4;
+  float cq[6];
+  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 #pragma unroll
         for (int st = 0; st < S; ++st) Bc[st] = raw[st];
       } else {
-        act_jet_fwd<S1, S2, ACT>(a.cfg, raw, Bc);
+        act_jet_fwd<S1, S2, ACT>(a.cfg, raw, Bc, cq);
       }
       load_w(0, wc);
     }
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 #pragma unroll
         for (int st = 0; st < S; ++st) Bc[st] = rawn[st];
       } else {
-        act_jet_fwd<S1, S2, ACT>(a.cfg, rawn, Bc);
+        act_jet_fwd<S1, S2, ACT>(a.cfg, rawn, Bc, cq);
       }
 #pragma unroll
       for (int mi = 0; mi < MC; ++mi) wc[mi] = wn[mi];
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   for (int mi = 0; mi < MC; ++mi) {
     const int mt = mt0 + mi;
     if (GUARD && mt >= MT) continue;
-    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb);
+    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb, cq);
   }
   }  // chunk loop
 }
@@ -207,6 +210,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     tile = (slot / a.split) * 8 + xcd;
     if (tile >= a.ntiles) return;
   }
+  float cq[6];
+  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
       for (int st = 0; st < S; ++st) B[st] = raw[st];
     } else {
-      act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B);
+      act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
     }
 #pragma unroll
     for (int st = 0; st < S; ++st) st4(&hb[buf][wv][st][lo], B[st]);
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     }
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
-      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb);
+      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq);
   }
 }
 
@@ -359,5 +364,6 @@ static int launch_mode(const LayerArgs& a, int mode, hipStream_t stream) {
 
 int stpde_layer_launch_0_0(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_0(const LayerArgs& a, int mode, hipStream_t stream);
+int stpde_layer_launch_3_1(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_2(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_6(const LayerArgs& a, int mode, hipStream_t stream);

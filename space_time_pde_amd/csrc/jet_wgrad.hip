@@ -5,6 +5,7 @@ static int dispatch_streams(const WgradArgs& a, int mode, hipStream_t stream) {
   const int S1 = a.cfg.S1, S2 = a.cfg.S2;
   if (S1 == 0 && S2 == 0) return stpde_wgrad_launch_0_0(a, mode, stream);
   if (S1 == 3 && S2 == 0) return stpde_wgrad_launch_3_0(a, mode, stream);
+  if (S1 == 3 && S2 == 1 && a.cfg.combo && a.cw) return stpde_wgrad_launch_3_1(a, mode, stream);
   if (S1 == 3 && S2 == 2) return stpde_wgrad_launch_3_2(a, mode, stream);
   if (S1 == 3 && S2 == 6) return stpde_wgrad_launch_3_6(a, mode, stream);
   stpde_set_error("stream configuration S1=%d S2=%d not compiled", S1, S2);
@@ -13,7 +14,7 @@ static int dispatch_streams(const WgradArgs& a, int mode, hipStream_t stream) {
 
 extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre,
                                const float* X, const float* XR, const float* W0s_pack, const float* tanc0R,
-                               float* dW_aug, void* stream) {
+                               float* dW_aug, const float* cw, void* stream) {
   if (!d || d->ntiles <= 0 || d->MT <= 0 || d->KT < 0 || !abar_out || !XR || !dW_aug || SP < 1 ||
       SP > 1 + d->cfg.S1 + d->cfg.S2) {
     stpde_set_error("jet_wgrad: bad argument");
@@ -27,6 +28,7 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   a.W0s = W0s_pack;
   a.tancR = tanc0R;
   a.dW = dW_aug;
+  a.cw = cw;
   a.SP = SP;
   a.KT = d->KT;
   a.MT = d->MT;

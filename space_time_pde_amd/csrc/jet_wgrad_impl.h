@@ -27,6 +27,7 @@ struct WgradArgs {
   const float* W0s;    // [XT][KT][256]  (MODE 1)
   const float* tancR;  // [3][KT][256] layer-0 tangent constants, row-major image (MODE 1)
   float* dW;           // [16*MT][16*(KT+XT)]
+  const float* cw;     // [P][8] weights of the combined second-order stream (S2 == 1)
   int SP, KT, MT, ntiles;
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
@@ -98,6 +99,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     f32x4 H[S];
     if (!HASX || kq < KT) {
       f32x4 pre[S];
+      float cq[6];
+      // rows of this lane: column-major image (MODE 0) row = lane & 15; row-major image (MODE 1) rows 4g..4g+3
+      load_cq<S2>(a.cw, tile * 2 + (MODE == 1 ? (g >> 1) : (c >> 3)), cq);
       if (MODE == 1) {
         f32x4 part[XT];
 #pragma unroll
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
         for (int st = 0; st < S; ++st) pre[st] = ld4(a.Q + (((size_t)tile * S + st) * KT + kq) * 256 + lo);
       }
-      act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H);
+      act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) put(&hl[buf][wv][st][0], H[st], false);
     } else if (kq < KT + XT) {
@@ -296,5 +300,6 @@ static int launch_mode(const WgradArgs& a, int mode, hipStream_t stream) {
 
 int stpde_wgrad_launch_0_0(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_0(const WgradArgs& a, int mode, hipStream_t stream);
+int stpde_wgrad_launch_3_1(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_2(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_6(const WgradArgs& a, int mode, hipStream_t stream);

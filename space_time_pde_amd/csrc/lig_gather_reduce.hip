@@ -58,6 +58,7 @@ struct GatherArgs {
   float* XR;
   float* coef;
   int* cell;
+  float* cw;
 };
 
 // one thread per (tile, xt, lane): writes one float4 of X
@@ -110,11 +111,23 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
     }
     cf[15] = 0.f;
     a.cell[p] = (int)node0;
+    if (a.cw) {  // weights of the combined second-order stream: alpha_k * kappa_a * kappa_b over the canonical pairs
+      float* cwp = a.cw + (size_t)p * 8;
+      const float k0 = gm.kap[0], k1 = gm.kap[1], k2 = gm.kap[2];
+      cwp[0] = a.d.alpha[0] * k0 * k0;
+      cwp[1] = a.d.alpha[1] * k0 * k1;
+      cwp[2] = a.d.alpha[2] * k0 * k2;
+      cwp[3] = a.d.alpha[3] * k1 * k1;
+      cwp[4] = a.d.alpha[4] * k1 * k2;
+      cwp[5] = a.d.alpha[5] * k2 * k2;
+      cwp[6] = 0.f;
+      cwp[7] = 0.f;
+    }
   }
 }
 
 extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X,
-                                float* XR, float* coef, int* cell, void* stream) {
+                                float* XR, float* coef, int* cell, float* cw, void* stream) {
   if (!d || d->P <= 0 || (d->P & 1) || d->N <= 0 || d->p_base < 0 || d->B <= 0 || d->n0 < 2 || d->n1 < 2 || d->n2 < 2 || d->C < 1 ||
       3 + d->C + 1 > 16 * XT || !pts || !latent || !X || !coef || !cell) {
     stpde_set_error("lig_gather: bad argument (P even, grid >= 2 per dim, C <= %d)", 16 * XT - 4);
@@ -124,7 +137,7 @@ extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, co
     stpde_set_error("lig_gather: latent grid too large for int32 node index");
     return STPDE_E_BADARG;
   }
-  GatherArgs a{*d, pts, latent, X, XR, coef, cell};
+  GatherArgs a{*d, pts, latent, X, XR, coef, cell, cw};
   const size_t nthreads = (size_t)(d->P / 2) * XT * 64;
   STPDE_LAUNCH(k_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_gather");
@@ -204,6 +217,18 @@ __global__ __launch_bounds__(256) void k_reduce_fwd(ReduceArgs a) {
     if (S1 == 3) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) y[1 + d] += c.dw[d] * f[0] + c.w * kap[d] * f[1 + d];
+      if (a.cfg.combo) {
+        // combined stream: L y = sum_k alpha_k d2y/dq_a dq_b ; the MLP stream f[4] already carries
+        // sum_k alpha_k kappa_a kappa_b d2f/dr_a dr_b
+        const float* al = a.cfg.alpha;
+        float acc = c.w * f[4];
+        acc += (al[1] * c.ddw[0] + al[2] * c.ddw[1] + al[4] * c.ddw[2]) * f[0];
+        acc += 2.f * (al[0] * c.dw[0] * kap[0] * f[1] + al[3] * c.dw[1] * kap[1] * f[2] + al[5] * c.dw[2] * kap[2] * f[3]);
+        acc += al[1] * (c.dw[0] * kap[1] * f[2] + c.dw[1] * kap[0] * f[1]);
+        acc += al[2] * (c.dw[0] * kap[2] * f[3] + c.dw[2] * kap[0] * f[1]);
+        acc += al[4] * (c.dw[1] * kap[2] * f[3] + c.dw[2] * kap[1] * f[2]);
+        y[4] += acc;
+      } else {
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         if (k < S2) {
@@ -213,6 +238,7 @@ __global__ __launch_bounds__(256) void k_reduce_fwd(ReduceArgs a) {
           const float fd = sel3(d, f[1], f[2], f[3]), fe = sel3(e, f[1], f[2], f[3]);
           y[4 + k] += pair_ddw(c, d, e) * f[0] + dwd * ke * fe + dwe * kd * fd + c.w * kd * ke * f[4 + k];
         }
+      }
       }
     }
   }
@@ -256,9 +282,18 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
         fb[0] += c.dw[d] * yb[1 + d];
         fb[1 + d] = c.w * kap[d] * yb[1 + d];
       }
+      if (a.cfg.combo) {
+        const float* al = a.cfg.alpha;
+        const float g = yb[4];
+        fb[0] += (al[1] * c.ddw[0] + al[2] * c.ddw[1] + al[4] * c.ddw[2]) * g;
+        fb[1] += (2.f * al[0] * c.dw[0] * kap[0] + al[1] * c.dw[1] * kap[0] + al[2] * c.dw[2] * kap[0]) * g;
+        fb[2] += (2.f * al[3] * c.dw[1] * kap[1] + al[1] * c.dw[0] * kap[1] + al[4] * c.dw[2] * kap[1]) * g;
+        fb[3] += (2.f * al[5] * c.dw[2] * kap[2] + al[2] * c.dw[0] * kap[2] + al[4] * c.dw[1] * kap[2]) * g;
+        fb[4] = c.w * g;
+      }
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        if (k < S2) {
+        if (k < S2 && !a.cfg.combo) {
           const int d = a.cfg.pair0[k], e = a.cfg.pair1[k];
           const float kd = sel3(d, kap[0], kap[1], kap[2]), ke = sel3(e, kap[0], kap[1], kap[2]);
           const float dwd = sel3(d, c.dw[0], c.dw[1], c.dw[2]), dwe = sel3(e, c.dw[0], c.dw[1], c.dw[2]);

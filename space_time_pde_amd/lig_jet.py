@@ -180,8 +180,21 @@ class ImNetPlan:
 # ------------------------------------------------------------------------------------------------------------
 # stream configuration
 # ------------------------------------------------------------------------------------------------------------
-def make_cfg(act, act_param, first, pairs):
-    """Map a derivative request onto a compiled stream configuration; returns (JetCfg, S, padded_pairs)."""
+CANON_PAIRS = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+
+
+def make_cfg(act, act_param, first, pairs, combo=None):
+    """Map a derivative request onto a compiled stream configuration; returns (JetCfg, S, padded_pairs).
+
+    combo = {pair: alpha}: ONE combined second-order stream sum_k alpha_k d2/dq_a dq_b instead of one per pair."""
+    if combo:
+        cfg = JetCfg()
+        cfg.S1, cfg.S2, cfg.combo = 3, 1, 1
+        for k, pr in enumerate(CANON_PAIRS):
+            cfg.alpha[k] = float(combo.get(pr, 0.0))
+        cfg.act = _lib.ACT_CODES[act]
+        cfg.act_param = float(act_param)
+        return cfg, 5, ["combo"]
     pairs = [tuple(sorted(p)) for p in pairs]
     if pairs and not first:
         first = True
@@ -287,6 +300,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     dev = pts_c.device
     X = torch.empty(nt * XT * _FRAG, device=dev)
     XR = torch.empty(nt * XT * _FRAG, device=dev) if need_grad else None
+    cw = torch.empty(Pc * 8, device=dev) if meta.cfg_out.combo else None
     coef = torch.empty(Pc * 16, device=dev)
     cell = torch.empty(Pc, device=dev, dtype=torch.int32)
     gd = GatherDesc()
@@ -295,8 +309,11 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     for k in range(3):
         gd.lo_c[k], gd.hi_c[k], gd.cube[k] = meta.lo_c[k], meta.hi_c[k], meta.cube[k]
     gd.p_base = p0
+    for k in range(6):
+        gd.alpha[k] = meta.cfg_out.alpha[k]
     with _timed("gather"):
-        check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(XR), ptr(coef), ptr(cell), st))
+        check(L.stpde_lig_gather(C.byref(gd), ptr(pts_c), ptr(latent), ptr(X), ptr(XR), ptr(coef), ptr(cell),
+                                 ptr(cw), st))
     bufs = [None]
     pv = plan.pack_view
     prev = None
@@ -307,13 +324,13 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         with _timed("layer%d_fwd" % l):
             check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")),
                                         ptr(pv(packs, l, "Ws")), ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(out), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(out), ptr(cw), st))
         bufs.append(out)
         prev = out
     with _timed("reduce_fwd"):
         check(L.stpde_lig_reduce_fwd(C.byref(meta.cfg_out), S, Pc, plan.cout, ptr(bufs[5]), ptr(coef),
                                      C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
-    return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc)
+    return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw)
 
 
 def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
@@ -325,6 +342,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
     Pc, p0 = saved["Pc"], saved["p0"]
     nt = Pc // 2
     X, XR, coef, cell, bufs = saved["X"], saved["XR"], saved["coef"], saved["cell"], saved["bufs"]
+    cw = saved["cw"]
     dev = X.device
     pv = plan.pack_view
     SP0 = 1 + cfg.S1
@@ -341,18 +359,18 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
             with _timed("layer%d_wgrad" % l):
                 check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
                                         ptr(XR), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
-                                        ptr(dw_flat[off:off + mp * ka]), st))
+                                        ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
         off, mp, ka = plan.dw_off[0]
         with _timed("layer0_wgrad"):
             check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), ptr(XR), None, None,
-                                    ptr(dw_flat[off:off + mp * ka]), st))
+                                    ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
     if dlatent is not None:
         xd = XbarDesc()
         xd.ntiles, xd.nlayers, xd.C = nt, 5, plan.cin
@@ -437,12 +455,14 @@ def activation_name(module):
 DEFAULT_CHUNK = 1 << 16   # query points per launch chunk (bounds the per-chunk backward scratch)
 
 
-def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=None):
+def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=None, combo=None):
     """HIP evaluation of y and its coordinate derivatives.
 
     imnet: implicit_net.ImNet (dim=3); latent_grid [b, n0, n1, n2, c]; query_pts [b, p, 3].
     Returns (jets [S, n_out, b*p] with S = 1 + 3*first + len(padded pairs), padded_pairs).
     Stream order: value, d/dq_0, d/dq_1, d/dq_2, then d2/dq_a dq_b per pair.
+    combo = {(a, b): alpha}: instead of one stream per pair, ONE combined second-order stream
+    sum alpha_ab d2y/dq_a dq_b is carried through the network (S = 5); returned pairs = ["combo"].
     """
     if not (latent_grid.is_cuda and query_pts.is_cuda):
         raise RuntimeError("the HIP jet path needs CUDA/HIP tensors (no CPU fallback)")
@@ -469,7 +489,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
     # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams
     # go through the network and the reduction supplies the second derivatives from the weight cross terms
-    meta.cfg_out, meta.S_out, ppairs = make_cfg(act, prm, first, list(pairs))
+    meta.cfg_out, meta.S_out, ppairs = make_cfg(act, prm, first, list(pairs), combo)
     if act in ("relu", "leakyrelu") and ppairs:
         meta.cfg, meta.S, _ = make_cfg(act, prm, True, [])
     else:

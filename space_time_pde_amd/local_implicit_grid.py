@@ -22,8 +22,9 @@ stats = {"hip_jet_calls": 0, "hip_value_calls": 0, "generic_calls": 0}
 class JetRequest:
     """Set by PDELayer around ``forward_method``: which derivatives of y w.r.t. the points it will need."""
 
-    def __init__(self, x, first, pairs):
+    def __init__(self, x, first, pairs, combo=None):
         self.x, self.first, self.pairs = x, first, list(pairs)
+        self.combo = combo     # {pair: alpha}: the equations use second derivatives only through this combination
         self.y = None          # the tensor handed back to the caller
         self.jets = None       # [S, n_out, P]
         self.pairs_out = None  # second-order pairs in stream order (after padding)
@@ -72,7 +73,8 @@ def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
     if _fast_eligible(model, latent_grid, query_pts) and _xmin_is_zero(xmin) is not False:
         wants_point_grad = query_pts.requires_grad and torch.is_grad_enabled()
         if req is not None and req.x is query_pts:
-            jets, pairs = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, req.first, req.pairs)
+            jets, pairs = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, req.first, req.pairs,
+                                           combo=req.combo)
             stats["hip_jet_calls"] += 1
             y = jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], -1)
             req.y, req.jets, req.pairs_out = y, jets, pairs

@@ -37,9 +37,11 @@ _TORCH_FUNCS = {"sin": torch.sin, "cos": torch.cos, "tan": torch.tan, "exp": tor
 class _JetProgram:
     """Residual as a function of input columns and jet atoms."""
 
-    def __init__(self, fn, atoms):
+    def __init__(self, fn, atoms, expr=None, syms=None):
         self.fn = fn          # callable(*in_cols, *atom_tensors)
         self.atoms = atoms    # list of (out_index, multi_index tuple sorted)  e.g. (2, ()) / (2, (1,)) / (2, (1, 1))
+        self.expr = expr      # sympy expression in the atom symbols (kept for the combined-stream rewrite)
+        self.syms = syms      # {atom key: sympy Dummy}
 
 
 class PDELayer(object):
@@ -59,6 +61,7 @@ class PDELayer(object):
         self.eqns_raw = {}   # raw string equations
         self.eqns_fn = {}    # lambda functions (generic autograd strategy)
         self.eqns_jet = {}   # _JetProgram or None per equation
+        self._combo = False  # lazily built combined-second-order plan (False = not built yet)
         self.forward_method = None
 
     # ------------------------------------------------------------------------------------------------
@@ -84,6 +87,68 @@ class PDELayer(object):
         self.eqns_raw.update({eqn_name: eqn_str})
         self.eqns_fn.update({eqn_name: fn})
         self.eqns_jet.update({eqn_name: self._compile_jet(expr)})
+        self._combo = False   # combined-second-order plan is rebuilt lazily
+
+    def _combo_plan(self):
+        """If every equation is LINEAR in the second derivatives and uses them only through one common combination
+        L y_c = sum_p alpha_p d2y_c/dq_a dq_b (same alpha for all channels and equations, e.g. the anisotropic Laplacian
+        nu_x^2 d_xx + nu_z^2 d_zz of the Rayleigh-Benard set), the network only has to carry ONE second-order stream.
+        Returns dict(alpha={pair: float}, progs={name: _JetProgram}) or None."""
+        if self._combo is not False:
+            return self._combo
+        self._combo = None
+        progs = self.eqns_jet
+        if not progs or any(p is None for p in progs.values()):
+            return None
+        try:
+            groups = {}
+            for name, prog in progs.items():
+                s2 = {k: v for k, v in prog.syms.items() if len(k[1]) == 2}
+                for key, sym in s2.items():
+                    coeff = sympy.diff(prog.expr, sym)
+                    if any(coeff.has(t) for t in s2.values()):
+                        return None                        # non-linear in the second derivatives
+                    groups.setdefault((name, key[0]), {})[key[1]] = coeff
+            if not groups:
+                return None
+            pairs = sorted({p for g in groups.values() for p in g})
+            if len(pairs) < 2:
+                return None                                # a single pair is already one stream
+            ref = pairs[0]
+            alpha = {ref: 1.0}
+            for g in groups.values():
+                if ref not in g or g[ref] == 0:
+                    return None
+                for p in pairs[1:]:
+                    ratio = sympy.simplify(g.get(p, sympy.Integer(0)) / g[ref])
+                    if not ratio.is_number:
+                        return None
+                    r = float(ratio)
+                    if p in alpha:
+                        if abs(alpha[p] - r) > 1e-9 * max(1.0, abs(r)):
+                            return None
+                    else:
+                        alpha[p] = r
+            new = {}
+            for name, prog in progs.items():
+                repl, lam = {}, {}
+                for key, sym in prog.syms.items():
+                    if len(key[1]) == 2:
+                        if key[1] == ref:
+                            lam[key[0]] = sympy.Dummy("L%d" % key[0])
+                            repl[sym] = lam[key[0]]
+                        else:
+                            repl[sym] = sympy.Integer(0)
+                e = prog.expr.xreplace(repl)
+                atoms = [(k, v) for k, v in prog.syms.items() if len(k[1]) < 2] + \
+                        [((c, ("L",)), v) for c, v in lam.items()]
+                atoms.sort(key=lambda a: (a[0][0], len(a[0][1]), str(a[0][1])))
+                fn = sympy.lambdify(list(self.in_vars) + [a[1] for a in atoms], e, [_TORCH_FUNCS])
+                new[name] = _JetProgram(fn, [a[0] for a in atoms])
+            self._combo = dict(alpha=alpha, progs=new)
+        except Exception:   # any sympy corner case -> one stream per pair (never wrong, only slower)
+            self._combo = None
+        return self._combo
 
     def _compile_jet(self, expr):
         """Expand nested ``dif`` symbolically; returns a _JetProgram or None (not expressible with order<=2 jets)."""
@@ -122,7 +187,7 @@ class PDELayer(object):
                 return None
             atoms.sort(key=lambda a: (a[0][0], len(a[0][1]), a[0][1]))
             fn = sympy.lambdify(list(self.in_vars) + [a[1] for a in atoms], e, [_TORCH_FUNCS])
-            return _JetProgram(fn, [a[0] for a in atoms])
+            return _JetProgram(fn, [a[0] for a in atoms], e, {a[0]: a[1] for a in atoms})
         except Exception:  # any sympy corner case -> generic strategy (never wrong, only slower)
             return None
 
@@ -149,6 +214,9 @@ class PDELayer(object):
             return None
         if x.requires_grad and torch.is_grad_enabled():
             return None   # the caller wants autograd through the coordinates: only the generic strategy provides it
+        plan = self._combo_plan()
+        if plan is not None:
+            return _lig.JetRequest(x, True, [], combo=plan["alpha"])
         first, pairs = False, set()
         for prog in self.eqns_jet.values():
             for _, mi in prog.atoms:
@@ -164,8 +232,13 @@ class PDELayer(object):
         stream_of = {(): 0}
         for d in range(3):
             stream_of[(d,)] = 1 + d
-        for k, p in enumerate(pairs):
-            stream_of.setdefault(tuple(p), 4 + k)
+        progs = self.eqns_jet
+        if pairs == ["combo"]:
+            stream_of[("L",)] = 4
+            progs = self._combo_plan()["progs"]
+        else:
+            for k, p in enumerate(pairs):
+                stream_of.setdefault(tuple(p), 4 + k)
         cols = [x[..., i:i + 1] for i in range(self.n_in)]
         cache = {}
 
@@ -174,7 +247,7 @@ class PDELayer(object):
                 cache[key] = jets[stream_of[key[1]], key[0]].reshape(shape)
             return cache[key]
 
-        return {name: prog.fn(*(cols + [atom(k) for k in prog.atoms])) for name, prog in self.eqns_jet.items()}
+        return {name: prog.fn(*(cols + [atom(k) for k in prog.atoms])) for name, prog in progs.items()}
 
     def __call__(self, x, return_residue=True):
         """y = forward(x) and, optionally, the residue of every equation (reference :115-143)."""

@@ -73,7 +73,7 @@ def test_cell_index_bit_exact_in_gather_kernel(hiplib, golden_dir, tag):
     coef = torch.empty(P * 16, device=DEV)
     cell = torch.empty(P, device=DEV, dtype=torch.int32)
     _lib.check(hiplib.stpde_lig_gather(C.byref(gd), _lib.ptr(pts.to(DEV)), _lib.ptr(latent), _lib.ptr(X), None,
-                                       _lib.ptr(coef), _lib.ptr(cell), _lib.stream_ptr()))
+                                       _lib.ptr(coef), _lib.ptr(cell), None, _lib.stream_ptr()))
     ind0 = torch.from_numpy(d[tag + "_ind0"].astype(np.int64)).reshape(-1, 3)
     want = (ind0[:, 0] * size[1] + ind0[:, 1]) * size[2] + ind0[:, 2]
     got = cell.cpu().long()[:want.shape[0]]

@@ -155,3 +155,38 @@ def test_golden_composite_g5(hiplib, golden_dir, act):
 def test_smoke_entry(hiplib):
     import __graft_entry__ as ge
     ge.smoke()
+
+
+@pytest.mark.parametrize("act", ["softplus", "tanh", "leakyrelu", "swish"])
+def test_combined_second_order_stream(hiplib, act):
+    """The single combined stream  L y = sum_k alpha_k d2y/dq_a dq_b  (S = 5) equals the same combination of the
+    per-pair oracle jets, forward and backward (incl. a clipped / out-of-box point where kappa is 0 or 0.5)."""
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, 32, generator=g)
+    pts = torch.rand(2, 101, 3, generator=g)
+    pts[0, 0] = torch.tensor([1.5, 0.3, -0.2])          # outside the box: clip derivative 0 in two dims
+    combo = {(0, 0): 0.3, (1, 1): 1.0, (1, 2): -0.7, (2, 2): 0.25}
+    pairs = tuple(sorted(combo))
+    net = _net(act).to(dev)
+    latd = lat.to(dev).requires_grad_(True)
+    jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, (), chunk_points=64, combo=combo)
+    assert pp == ["combo"] and jets.shape[0] == 5
+    cot = torch.randn(jets.shape, generator=g)
+    (jets * cot.to(dev)).sum().backward()
+    beta = torch.tensor(1.3, dtype=torch.float64)
+    p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
+    lat64 = lat.double().requires_grad_(True)
+    full = J.lig_jets(p64, act, lat64, pts.double(), 0., 1., second=pairs, beta=beta)
+    full = full.permute(0, 3, 1, 2).reshape(full.shape[0], 4, -1)
+    L = sum(combo[p] * full[4 + k] for k, p in enumerate(pairs))
+    ref = torch.cat([full[:4], L[None]], 0)
+    for s in range(5):
+        assert _relerr(jets[s], ref[s]) < 2e-5, "stream %d" % s
+    (ref * cot.double()).sum().backward()
+    err = _normerr if act == "leakyrelu" else _relerr
+    assert err(latd.grad, lat64.grad) < 5e-4
+    for k in range(6):
+        assert err(net.fc[k].weight.grad, p64[k][0].grad) < 5e-4, "dW%d" % k
+        assert err(net.fc[k].bias.grad, p64[k][1].grad) < 5e-4, "db%d" % k
