@@ -184,8 +184,9 @@ def main():
     assert lig.stats["hip_jet_calls"] >= args.steps, "HIP jet path was not taken"
 
     if rank == 0:
-        macs, M, T = algorithmic_macs()
         smooth = args.act not in ("relu", "leakyrelu")
+        # piecewise-linear activations have identically zero second-order MLP jets
+        macs, M, T = algorithmic_macs(n_second=2 if smooth else 0)
         fwd_flop_pt = 2 * 8 * (M + (5 if smooth else 3) * T)
         step_flop_pt = 3 * fwd_flop_pt
         kern = {}
@@ -197,6 +198,10 @@ def main():
         rows_per_launch = 8 * min(args.chunk, n_local)
         flop_launch = 2.0 * macs.get(dom, 0) * rows_per_launch
         ach = flop_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+        # what the kernels actually execute: the RB2 equations use d_xx and d_zz only through one common combination,
+        # so the network carries ONE second-order stream (none at all for piecewise-linear activations)
+        macs_x, _, _ = algorithmic_macs(n_second=1 if smooth else 0)
+        exe = 2.0 * macs_x.get(dom, 0) * rows_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (same chunk size)
             tj = json.load(open(args.traffic_json))
@@ -206,6 +211,9 @@ def main():
             pass
         roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                        note="achieved = SURVEY 8(d) algorithmic FLOPs (value + 3 first + 2 second-order streams) / "
+                             "launch time; executed_* = the MFMA work actually issued (combined second-order stream)",
+                        executed_tflops=round(exe, 2), executed_frac=round(exe / PEAK_F32_TFLOPS, 4),
                         flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3),
                         step_algorithmic_tflops=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world, 2),
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world

@@ -1,0 +1,46 @@
+"""Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries (tools/rocprof_summary.py pmc ...) into
+profiles/pmc_traffic.json: HBM bytes per launch of the first-layer kernels, keyed by bench.py's kernel names.
+
+FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of wide coalesced 16 B/lane reads);
+WRITE_SIZE is taken as reported.  Usage: make_traffic_json.py fetch.txt write.txt chunk act out.json
+"""
+import json
+import re
+import sys
+
+
+def parse(path):
+    out = {}
+    for ln in open(path).read().split("\n")[2:]:
+        m = re.match(r"(k_\w+<[^>]*>)\s+(\d+)\s+([\d.]+)\s+([\d.]+)", ln.strip())
+        if m:
+            out[m.group(1)] = float(m.group(4)) * 1024.0      # KiB per call -> bytes
+    return out
+
+
+def bench_name(sym):
+    m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)>", sym)
+    if m:
+        pro, epi = int(m.group(4)), int(m.group(5))
+        if pro == 2 and epi == 0:
+            return "layer1_fwd"
+        if epi == 2:
+            return "layer1_dgrad"
+        return "layer2_fwd" if epi == 0 else "layer2_dgrad"
+    m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+)>", sym)
+    if m and int(m.group(3)) == 1 and m.group(6) == "false":
+        return "layer1_wgrad"
+    return None
+
+
+if __name__ == "__main__":
+    fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
+    kernels = {}
+    for sym in set(fetch) | set(write):
+        name = bench_name(sym)
+        if name:
+            f, w = 2.0 * fetch.get(sym, 0.0), write.get(sym, 0.0)
+            kernels[name] = dict(symbol=sym, fetch_bytes_corrected=f, write_bytes=w, hbm_bytes_per_launch=f + w)
+    json.dump(dict(chunk=int(sys.argv[3]), act=sys.argv[4], kernels=kernels,
+                   source="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
+                          "profiles/r1_pmc_*.txt"), open(sys.argv[5], "w"), indent=1)
