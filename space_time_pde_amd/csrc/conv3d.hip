@@ -44,48 +44,70 @@ __device__ __forceinline__ int tap_neighbour(const stpde_conv3d_desc& d, const V
   return ((c.b * d.T + t) * d.Z + z) * d.X + x;
 }
 
-template <int MC>
+// VT voxel tiles (16 voxels each) per wave: every weight block that is loaded feeds VT*4 MFMAs per output tile.
+template <int MC, int VT>
 __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile * 16 >= a.nvox) return;
+  const int tile0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * VT;
+  if (tile0 * 16 >= a.nvox) return;
   const int g = lane >> 4, j = lane & 15;
   const int lo = lane * 4;
   const int Ci = a.d.Ci, Co = a.d.Co, KT = Ci / 16, MT = Co / 16;
   const int ntap = a.d.ksize == 3 ? 27 : 1;
-  const int v = tile * 16 + j;
-  const bool vin = v < a.nvox;
-  const Vox c = vox_coords(a.d, vin ? v : 0);
-  // large volumes: one wave walks all output-channel chunks of its 16 voxels (inputs stay hot in L1);
+  int v[VT];
+  bool vin[VT];
+  Vox c[VT];
+#pragma unroll
+  for (int t = 0; t < VT; ++t) {
+    v[t] = (tile0 + t) * 16 + j;
+    vin[t] = v[t] < a.nvox;
+    c[t] = vox_coords(a.d, vin[t] ? v[t] : 0);
+  }
+  // large volumes: one wave walks all output-channel chunks of its voxels (inputs stay hot in L1);
   // small volumes (deep U-Net levels): the chunks are spread over blockIdx.y so that the chip is not idle
   for (int mt0 = blockIdx.y * MC; mt0 < MT; mt0 += gridDim.y * MC) {
-    f32x4 acc[MC];
+    f32x4 acc[VT][MC];
 #pragma unroll
-    for (int mi = 0; mi < MC; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < VT; ++t)
+#pragma unroll
+      for (int mi = 0; mi < MC; ++mi) acc[t][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int tap = 0; tap < ntap; ++tap) {
-      const int nb = vin ? tap_neighbour(a.d, c, tap) : -1;
-      const float* src = a.x + (size_t)(nb < 0 ? 0 : nb) * Ci + 4 * g;
+      int nb[VT];
+      const float* src[VT];
+#pragma unroll
+      for (int t = 0; t < VT; ++t) {
+        nb[t] = vin[t] ? tap_neighbour(a.d, c[t], tap) : -1;
+        src[t] = a.x + (size_t)(nb[t] < 0 ? 0 : nb[t]) * Ci + 4 * g;
+      }
       for (int kt = 0; kt < KT; ++kt) {
-        f32x4 B = ld4(src + 16 * kt);
-        if (nb < 0) B = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 B[VT];
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+          B[t] = ld4(src[t] + 16 * kt);
+          if (nb[t] < 0) B[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const float* wp = a.w + ((size_t)(tap * KT + kt) * MT + mt0) * 256 + lo;
 #pragma unroll
         for (int mi = 0; mi < MC; ++mi) {
           const int mic = mt0 + mi < MT ? mi : 0;
           f32x4 w = ld4(wp + (size_t)mic * 256);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mi] = mfma4(w[r], B[r], acc[mi]);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < VT; ++t) acc[t][mi] = mfma4(w[r], B[t][r], acc[t][mi]);
         }
       }
     }
-    if (vin) {
+#pragma unroll
+    for (int t = 0; t < VT; ++t) {
+      if (!vin[t]) continue;
 #pragma unroll
       for (int mi = 0; mi < MC; ++mi) {
         const int mt = mt0 + mi;
         if (mt >= MT) continue;
-        f32x4 o = acc[mi];
+        f32x4 o = acc[t][mi];
         if (a.bias) o += ld4(a.bias + 16 * mt + 4 * g);
-        st4(a.y + (size_t)v * Co + 16 * mt + 4 * g, o);
+        st4(a.y + (size_t)v[t] * Co + 16 * mt + 4 * g, o);
       }
     }
   }
@@ -180,8 +202,12 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
   a.nvox = d->B * d->T * d->Z * d->X;
   const int ntiles = (a.nvox + 15) / 16;
   const int nchunks = (d->Co / 16 + 3) / 4;
-  const int gy = (ntiles + 3) / 4 >= 1024 ? 1 : nchunks;
-  STPDE_LAUNCH(k_conv3d_fwd<4>, dim3((ntiles + 3) / 4, gy), dim3(256), 0, (hipStream_t)stream, a);
+  if (ntiles >= 16384) {   // big volumes: 4 voxel tiles per wave (4x weight reuse), one wave walks all chunks
+    STPDE_LAUNCH((k_conv3d_fwd<4, 4>), dim3((ntiles + 15) / 16, 1), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    const int gy = (ntiles + 3) / 4 >= 1024 ? 1 : nchunks;
+    STPDE_LAUNCH((k_conv3d_fwd<4, 1>), dim3((ntiles + 3) / 4, gy), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return stpde_check_launch("k_conv3d_fwd");
 }
 

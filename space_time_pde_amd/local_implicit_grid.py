@@ -70,6 +70,10 @@ def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
     xmin/xmax: float, sequence or tensor bounds of the grid.  Returns [b, num_pts, o].
     """
     req = getattr(_tls, "req", None)
+    # the reference wraps its networks in nn.DataParallel (experiments/rb2d/train.py:352-355); on one device that
+    # wrapper is the identity, so the HIP path reads the wrapped module's parameters directly
+    if isinstance(model, torch.nn.DataParallel) and len(model.device_ids or []) <= 1:
+        model = model.module
     if _fast_eligible(model, latent_grid, query_pts) and _xmin_is_zero(xmin) is not False:
         wants_point_grad = query_pts.requires_grad and torch.is_grad_enabled()
         if req is not None and req.x is query_pts:
