@@ -499,6 +499,8 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)
     meta.need_wgrad = True
     P = B * N
+    if P == 0:   # empty query set: nothing to launch (the reference returns an empty [b, 0, o] tensor as well)
+        return torch.zeros(meta.S_out, plan.cout, 0, device=query_pts.device), ppairs
     pts = query_pts.detach().reshape(P, 3).contiguous()
     pad = P & 1
     if pad:

@@ -80,13 +80,13 @@ def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
             jets, pairs = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, req.first, req.pairs,
                                            combo=req.combo)
             stats["hip_jet_calls"] += 1
-            y = jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], -1)
+            y = jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], jets.shape[1])
             req.y, req.jets, req.pairs_out = y, jets, pairs
             return y
         if not wants_point_grad:
             jets, _ = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, False, ())
             stats["hip_value_calls"] += 1
-            return jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], -1)
+            return jets[0].t().reshape(query_pts.shape[0], query_pts.shape[1], jets.shape[1])
     stats["generic_calls"] += 1
     corner_values, weights, x_relative = rgi._coefficients_autograd(latent_grid, query_pts, xmin, xmax) \
         if (query_pts.requires_grad and torch.is_grad_enabled()) else \

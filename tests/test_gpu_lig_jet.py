@@ -190,3 +190,31 @@ def test_combined_second_order_stream(hiplib, act):
     for k in range(6):
         assert err(net.fc[k].weight.grad, p64[k][0].grad) < 5e-4, "dW%d" % k
         assert err(net.fc[k].bias.grad, p64[k][1].grad) < 5e-4, "db%d" % k
+
+
+def test_edge_cases_empty_single_and_boundary_points(hiplib):
+    """Empty query set, a single point (odd count -> padded tile), points exactly on the box faces / grid nodes."""
+    from space_time_pde_amd import local_implicit_grid as lig, physics
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    lat = torch.randn(1, 3, 4, 5, 32, generator=g)
+    net = _net("softplus").to(dev)
+    with torch.no_grad():
+        y = lig.query_local_implicit_grid(net, lat.to(dev), torch.zeros(1, 0, 3, device=dev), 0., 1.)
+    assert y.shape == (1, 0, 4)
+    pts = torch.tensor([[[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 1.0 / 3.0, 0.25], [0.3, 0.9, 0.1], [2.0, -1.0, 0.5]]])
+    p32 = [(w.float(), b.float()) for w, b in _params64(net)]
+    for n in (1, 5):
+        with torch.no_grad():
+            y = lig.query_local_implicit_grid(net, lat.to(dev), pts[:, :n].to(dev), 0., 1.)
+        ref = O.query_lig(lambda f: O.imnet_forward(p32, f, O.activation_fn("softplus")), lat, pts[:, :n], 0., 1.)
+        assert _relerr(y, ref) < 2e-5
+    # residuals at those points (clip ties / abs'(0) quirks a-Q2, a-Q3) vs the reference-semantics oracle
+    kw = dict(t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
+    layer = physics.get_rb2_pde_layer(**kw)
+    latd = lat.to(dev)
+    layer.update_forward_method(lambda q: lig.query_local_implicit_grid(net, latd, q, 0., 1.))
+    pred, res = layer(pts.to(dev))
+    out = O.lig_pde_step(p32, "softplus", lat, pts, torch.zeros(1, 5, 4), O.rb2_oracle(**kw), backward=False)
+    for k, v in out["residues"].items():
+        assert (res[k].cpu() - v).abs().max().item() < 1e-4 * max(v.abs().max().item(), 1e-3), k
