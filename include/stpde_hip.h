@@ -41,6 +41,7 @@ extern "C" {
 #define STPDE_ACT_LEAKYRELU 5
 
 #define STPDE_XT 3 /* the augmented raw input [r(3) ; latent(c) ; 1 ; 0-pad] occupies 3 feature tiles: c <= 44 */
+#define STPDE_PBAR_SLOTS 64 /* accumulation slots of the swish-beta adjoint (stpde_jet_layer_bwd), summed by the caller */
 
 /* Derivative-stream configuration shared by the jet kernels. */
 typedef struct {
@@ -99,10 +100,12 @@ int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const fl
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when
- * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise. */
+ * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise.
+ * act_param_bar (swish only, may be NULL): STPDE_PBAR_SLOTS (64) floats that ACCUMULATE partial sums of the adjoint of
+ * the learnable beta (src/nonlinearities.py:5-12); the caller zero-fills them and adds the slots up. */
 int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
                         const float* X, const float* W0s_pack, const float* tanc0, float* abar0, const float* cw,
-                        void* stream);
+                        float* act_param_bar, void* stream);
 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)

@@ -16,6 +16,7 @@ _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_laye
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
+PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
 XT = 3
 
 
@@ -101,7 +102,7 @@ _SIGNATURES = {
     "stpde_last_error": ([C.c_char_p, C.c_ulong], C.c_int),
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
     "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 10, C.c_int),
-    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 9, C.c_int),
+    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 10, C.c_int),
     "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 9, C.c_int),
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
     "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),

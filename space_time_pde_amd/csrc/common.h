@@ -188,6 +188,48 @@ __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x
   }
 }
 
+// Adjoint of the learnable swish beta (reference nonlinearities.py:5-12): sum over the block of
+// hbar_s * d h_s / d beta, with z = beta a, s = sigmoid(z), q = s(1-s), c = 1-2s:
+//   d s0/d beta = a^2 q,  d s1/d beta = a q (2 + z c),  d s2/d beta = q (2 + z c) + z q (3c + z (c^2 - 2q)).
+template <int S1, int S2>
+__device__ __forceinline__ float swish_beta_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
+                                                const float* cq) {
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float a = pre[0][r], z = cfg.act_param * a;
+    const float e = fast_exp(-fabsf(z));
+    const float inv = fast_rcp(1.f + e);
+    const float s = z >= 0.f ? inv : e * inv;
+    const float q = e * inv * inv, c = 1.f - 2.f * s;
+    const float m = q * (2.f + z * c);
+    const float b0 = a * a * q, b1 = a * m, b2 = m + z * q * (3.f * c + z * (c * c - 2.f * q));
+    float t = b0 * hbar[0][r];
+    if (S1 == 3) {
+      const float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
+      t += b1 * (a0 * hbar[1][r] + a1 * hbar[2][r] + a2 * hbar[3][r]);
+      if (S2 == 1) {
+        const float qq = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
+        t += (b2 * qq + b1 * pre[4][r]) * hbar[4][r];
+      }
+#pragma unroll
+      for (int p = 0; p < (S2 == 1 ? 0 : S2); ++p) {
+        const float u = sel3(cfg.pair0[p], a0, a1, a2), v = sel3(cfg.pair1[p], a0, a1, a2);
+        t += (b2 * u * v + b1 * pre[4 + p][r]) * hbar[4 + p][r];
+      }
+    }
+    sum += t;
+  }
+  return sum;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+
 // Launch with a clean error slot: hipGetLastError() is sticky per thread, a stale error from an unrelated earlier
 // runtime call must not be attributed to this launch.
 #define STPDE_LAUNCH(...)      \

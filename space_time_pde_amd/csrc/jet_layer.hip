@@ -69,7 +69,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
 
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
-                                   float* abar0, const float* cw, void* stream) {
+                                   float* abar0, const float* cw, float* act_param_bar, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -80,6 +80,7 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
   a.W0s = W0s_pack;
   a.tanc0 = tanc0;
   a.cw = cw;
+  a.pbar = act_param_bar;
   a.KT = d->MT;
   a.MT = d->KT;
   a.ntiles = d->ntiles;

@@ -26,6 +26,7 @@ struct LayerArgs {
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
   float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
   const float* cw;     // [P][8] per-point weights of the combined second-order stream (S2 == 1), else unused
+  float* pbar;         // dgrad, swish only: [STPDE_PBAR_SLOTS] accumulators of the adjoint of beta (nullable)
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   stpde_jet_cfg cfg;
@@ -49,7 +50,7 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 // pre-activations; dgrad = activation-jet adjoint against the stored / regenerated pre-activations + R-image copies.
 template <int S1, int S2, int EPI, int ACT>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
-                                               const f32x4* xb, const float* cq) {
+                                               const f32x4* xb, const float* cq, float& pacc) {
   constexpr int S = 1 + S1 + S2;
   const int lo = lane * 4;
   f32x4 (&acc)[1][S] = *reinterpret_cast<f32x4 (*)[1][S]>(accm);
@@ -82,10 +83,21 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         }
       }
       act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[mi], ab, cq);
+      if ((ACT == STPDE_ACT_SWISH || (ACT < 0 && a.cfg.act == STPDE_ACT_SWISH)) && a.pbar)
+        pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc[mi], cq);
       constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
 #pragma unroll
       for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
     }
+}
+
+// one atomic per wave: the per-lane partial sums of the swish-beta adjoint go to slot (block % STPDE_PBAR_SLOTS)
+template <int EPI, int ACT>
+__device__ __forceinline__ void flush_pbar(const LayerArgs& a, float pacc, int lane) {
+  if (EPI != EPI_FWD && (ACT == STPDE_ACT_SWISH || (ACT < 0 && a.cfg.act == STPDE_ACT_SWISH)) && a.pbar) {
+    const float v = wave_sum(pacc);
+    if (lane == 0) atomicAdd(a.pbar + (blockIdx.x % STPDE_PBAR_SLOTS), v);
+  }
 }
 
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
@@ -98,6 +110,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   const int lo = lane * 4;
   float cq[6];
   load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  float pacc = 0.f;
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
@@ -177,9 +190,10 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   for (int mi = 0; mi < MC; ++mi) {
     const int mt = mt0 + mi;
     if (GUARD && mt >= MT) continue;
-    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb, cq);
+    layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt, MT, lane, acc[mi], xb, cq, pacc);
   }
   }  // chunk loop
+  flush_pbar<EPI, ACT>(a, pacc, lane);
 }
 
 
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   }
   float cq[6];
   load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  float pacc = 0.f;
 
   f32x4 xb[XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
@@ -280,8 +295,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     }
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
-      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq);
+      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc);
   }
+  flush_pbar<EPI, ACT>(a, pacc, lane);
 }
 
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>

@@ -333,7 +333,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw)
 
 
-def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
+def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     """reduce_bwd -> for l = 5..1: wgrad_l (reads abar_l and the still intact pre-activations of layer l-1), then
     dgrad_l (overwrites them with abar_{l-1}) -> wgrad_0 -> xbar/scatter."""
     plan, cfg, S = meta.plan, meta.cfg, meta.S
@@ -363,7 +363,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent):
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
@@ -390,7 +390,8 @@ class LigJetFunction(torch.autograd.Function):
     """jets[S, n_out, P] of the LIG+IM-NET composite; differentiable w.r.t. latent grid and IM-NET parameters."""
 
     @staticmethod
-    def forward(ctx, meta, latent, pts, *params):
+    def forward(ctx, meta, latent, pts, act_param, *params):
+        # act_param: the learnable swish beta (a tensor input so that autograd routes its gradient) or None
         packs = meta.plan.pack(params)
         P = pts.shape[0]
         jets = torch.empty(meta.S_out, meta.plan.cout, P, device=pts.device)
@@ -403,6 +404,7 @@ class LigJetFunction(torch.autograd.Function):
                 saved.append(s)
         ctx.meta, ctx.packs, ctx.saved = meta, packs, saved
         ctx.n_params = len(params)
+        ctx.prm_shape = act_param.shape if act_param is not None else None
         ctx.lat_shape = latent.shape
         ctx.params = params
         ctx.used = False
@@ -417,19 +419,21 @@ class LigJetFunction(torch.autograd.Function):
         meta = ctx.meta
         jets_bar = jets_bar.contiguous()
         dev = jets_bar.device
-        meta.need_wgrad = any(ctx.needs_input_grad[3:])
+        meta.need_wgrad = any(ctx.needs_input_grad[4:])
         need_lat = ctx.needs_input_grad[1]
         dw_flat = torch.zeros(meta.plan.n_dw, device=dev) if meta.need_wgrad else None
         dlatent = torch.zeros(ctx.lat_shape, device=dev) if need_lat else None
+        pbar = torch.zeros(_lib.PBAR_SLOTS, device=dev) if ctx.needs_input_grad[3] else None
         for s in ctx.saved:
-            _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent)
+            _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar)
             s["bufs"] = None  # release the stash chunk by chunk
         ctx.saved = []
         grads = [None] * ctx.n_params
         if meta.need_wgrad:
             g = meta.plan.unpack_grads(dw_flat, ctx.params)
-            grads = [gi if need else None for gi, need in zip(g, ctx.needs_input_grad[3:])]
-        return (None, dlatent, None) + tuple(grads)
+            grads = [gi if need else None for gi, need in zip(g, ctx.needs_input_grad[4:])]
+        dprm = pbar.sum().reshape(ctx.prm_shape) if pbar is not None else None
+        return (None, dlatent, None, dprm) + tuple(grads)
 
 
 def activation_name(module):
@@ -474,10 +478,10 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     if an is None:
         raise NotImplementedError("activation %r is not implemented in the HIP jet path" % (imnet.activ,))
     act, prm = an
+    prm_tensor = None
     if act == "swish":
-        if prm.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("gradient w.r.t. the learnable swish beta is not implemented in the HIP path")
-        prm = float(prm.detach())
+        prm_tensor = prm          # learnable beta: a tensor input of the autograd function (its adjoint comes from
+        prm = float(prm.detach())  # the dgrad epilogues); the kernels take the current value as a launch constant
     B, N = query_pts.shape[0], query_pts.shape[1]
     if latent_grid.shape[0] != B:
         raise ValueError("batch mismatch between latent_grid and query_pts")
@@ -511,7 +515,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     params = []
     for k in range(6):
         params += [imnet.fc[k].weight, imnet.fc[k].bias]
-    jets = LigJetFunction.apply(meta, lat, pts, *params)
+    jets = LigJetFunction.apply(meta, lat, pts, prm_tensor, *params)
     if pad:
         jets = jets[:, :, :P]
     return jets, ppairs

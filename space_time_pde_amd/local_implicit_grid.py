@@ -50,9 +50,7 @@ def _fast_eligible(model, latent_grid, query_pts):
             and latent_grid.dtype == torch.float32 and query_pts.dtype == torch.float32
             and model.nf % 16 == 0 and model.out_features <= 16 and model.in_features <= 44
             and latent_grid.shape[-1] == model.in_features
-            and lig_jet.activation_name(model.activ) is not None
-            and not (lig_jet.activation_name(model.activ)[0] == "swish" and model.activ.beta.requires_grad
-                     and torch.is_grad_enabled()))
+            and lig_jet.activation_name(model.activ) is not None)
 
 
 def _xmin_is_zero(xmin):
