@@ -51,9 +51,24 @@ def algorithmic_macs(nf=32, cin=32, cout=4, n_first=3, n_second=2):
     return macs, M, T
 
 
-def make_inputs(n_pts, dev, seed=0):
+def algorithmic_bytes(S, smooth_sp0=4, nf=32, cin=32, cout=4):
+    """Per CORNER ROW HBM bytes each layer kernel has to move (fp32 stash of S streams; X = augmented raw input):
+    used as the roofline numerator when the kernels are HBM-bound (bf16-MFMA mode)."""
+    widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf, 16]     # fc5 output padded to one 16-feature tile
+    xb = 3 * 16 * 4
+    by = {}
+    for l in range(1, 6):
+        out_b, in_b = 4 * S * widths[l], (4 * S * widths[l - 1] if l > 1 else 0)
+        by["layer%d_fwd" % l] = in_b + xb + out_b
+        by["layer%d_dgrad" % l] = out_b + (2 * in_b if l > 1 else xb + 4 * smooth_sp0 * widths[0])
+        by["layer%d_wgrad" % l] = out_b + in_b + 2 * xb
+    by["layer0_wgrad"] = 4 * smooth_sp0 * widths[0] + xb
+    return by
+
+
+def make_inputs(n_pts, dev, seed=0, igres=(32, 128, 128)):
     g = torch.Generator().manual_seed(seed)
-    crop = torch.randn(1, 4, 32, 128, 128, generator=g).to(dev)
+    crop = torch.randn(1, 4, *igres, generator=g).to(dev)
     pts = torch.rand(1, n_pts, 3, generator=g).to(dev)
     tgt = torch.randn(1, n_pts, 4, generator=g).to(dev)
     return crop, pts, tgt
@@ -104,6 +119,11 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20)
     ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
     ap.add_argument("--chunk", type=int, default=1 << 18, help="points per launch chunk")
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the headline / parity path; bf16 = BASELINE configs[3]: bf16 MFMA operands in the "
+                         "wide IM-NET layers, fp32 accumulation (NOT the headline metric)")
+    ap.add_argument("--igres", type=int, nargs=3, default=[32, 128, 128], metavar=("T", "Z", "X"),
+                    help="latent grid; 64 256 256 = BASELINE configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
@@ -127,14 +147,16 @@ def main():
     torch.manual_seed(1)
     net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
                              activation=nonlinearities.NONLINEARITIES[args.act]).to(dev)
-    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(32, 128, 128), nf=16, mf=256).to(dev)
+    igres = tuple(args.igres)
+    lig_jet.set_mlp_precision(args.mlp_precision)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256).to(dev)
     unet.train()
     params = [p for p in net.parameters()]
     uparams = [p for p in unet.parameters()]
     if world > 1:
         for p in params + uparams:
             dist.broadcast(p.data, 0)
-    crop, pts_all, tgt_all = make_inputs(args.points, dev)
+    crop, pts_all, tgt_all = make_inputs(args.points, dev, igres=igres)
     n_local = args.points // world
     pts = pts_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
     tgt = tgt_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
@@ -219,6 +241,18 @@ def main():
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
                                                 / PEAK_F32_TFLOPS, 4),
                         kernels={k: round(v["total_ms"] / args.steps, 2) for k, v in sorted(kern.items())})
+        bf16 = args.mlp_precision == "bf16"
+        if bf16:
+            # bf16 operands make the layer kernels HBM-bound on the fp32 stash: price them against HBM instead
+            by = algorithmic_bytes(1 + 3 + (1 if smooth else 0)).get(dom)
+            if by:
+                gbs = by * rows_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+                roofline.update(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
+                                traffic=None, traffic_source=None,
+                                note="bf16-MFMA mode: achieved = algorithmic stash bytes of the dominant kernel / launch "
+                                     "time; MFMA-side figures (executed_tflops vs the 2500 TFLOP/s bf16 peak) for reference",
+                                executed_frac=round(exe / 2500.0, 4), bytes_per_launch=by * rows_per_launch)
+                roofline.pop("step_frac_per_gpu", None)
         out = {
             "metric": "query-points/sec (fwd+PDE-residual bwd), rb2d 128^3 latent",
             "value": args.points * args.steps / dt,
@@ -230,13 +264,14 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 MFMA operands (wide IM-NET layers) / f32 accumulate, stash, epilogues, UNet" if bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: latent [1,32,128,128,32], 2^%d query points, RB2 "
+            "config": {"workload": "BASELINE configs[%d]: latent [1,%d,%d,%d,32], 2^%d query points, RB2 "
                                    "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + UNet3d parameters"
-                                   % (args.points.bit_length() - 1, args.act),
+                                   % ((3 if (bf16 and igres == (64, 256, 256)) else 1,) + igres + (args.points.bit_length() - 1, args.act)),
                        "points": args.points, "parallelism": "points sharded x%d" % world,
-                       "unet": "UNet3d(igres=(32,128,128), nf=16, mf=256) fwd+bwd inside the timed step", "loss": float(loss)},
+                       "unet": "UNet3d(igres=%s, nf=16, mf=256) fwd+bwd inside the timed step" % (igres,),
+                       "loss": float(loss)},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

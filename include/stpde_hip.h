@@ -92,10 +92,18 @@ int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* 
 typedef struct {
   int ntiles, KT, MT, first_hidden;
   stpde_jet_cfg cfg;
+  /* BASELINE config 4 ("bf16 MFMA MLP path"): != 0 runs the hidden-to-hidden GEMMs of the wide layers (those served
+   * by the workgroup-cooperative kernels: KT % 4 == 0, KT >= 8, MT % 8 == 0) on v_mfma_f32_16x16x32_bf16 -- operands
+   * rounded to bf16 (round-to-nearest-even), fp32 accumulation; layer-0 regeneration, skip/bias GEMM, activation
+   * jets, stash and epilogues stay fp32.  Narrow layers (HBM-bound) keep the fp32 kernels. */
+  int mfma_bf16;
 } stpde_layer_desc;
+/* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
+ * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16. */
 int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X, const float* Wh_pack,
                         const float* Ws_pack, const float* tanc, const float* W0s_pack, const float* tanc0,
-                        float* out_pre, const float* cw /* combined-stream weights or NULL */, void* stream);
+                        float* out_pre, const float* cw /* combined-stream weights or NULL */,
+                        const void* Wh_pack_bf16, void* stream);
 
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
@@ -105,14 +113,16 @@ int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const fl
  * the learnable beta (src/nonlinearities.py:5-12); the caller zero-fills them and adds the slots up. */
 int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
                         const float* X, const float* W0s_pack, const float* tanc0, float* abar0, const float* cw,
-                        float* act_param_bar, void* stream);
+                        float* act_param_bar, const void* WhT_pack_bf16 /* as Wh_pack_bf16, of WhT_pack */,
+                        void* stream);
 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
  * and in_pre [tile][S][KT] are the ordinary (column-major) layer buffers -- call it BEFORE stpde_jet_layer_bwd of the
  * same layer overwrites in_pre.  first_hidden: in_pre is ignored, the activated layer-0 output is regenerated from X
  * with W0s_pack and tanc0R (layer-0 tangent constants in the row-major image).  XR = row-major augmented input from
- * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug. */
+ * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug.  d->mfma_bf16: layers with MT >= 8 contract with
+ * bf16-rounded operands (two derivative streams per v_mfma_f32_16x16x32_bf16), fp32 accumulation. */
 int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* X,
                     const float* XR, const float* W0s_pack, const float* tanc0R, float* dW_aug, const float* cw,
                     void* stream);

@@ -59,11 +59,18 @@ def act_derivs(name, a, beta=None):
     raise KeyError(name)
 
 
-def mlp_jets(params, act_name, x, dim, second, beta=None):
+def round_bf16(t):
+    """Round-to-nearest-even to bfloat16, returned in the input dtype (emulates v_cvt_pk_bf16_f32 on fp32 data)."""
+    return t.float().to(torch.bfloat16).to(t.dtype)
+
+
+def mlp_jets(params, act_name, x, dim, second, beta=None, bf16_layers=()):
     """Jets of IM-NET w.r.t. its first ``dim`` inputs.
 
     x [rows, dim+c].  Returns list of streams, each [rows, out]: [value, d/dr_0..d/dr_{dim-1}, d2/dr_a dr_b for
     (a,b) in second].
+    bf16_layers: layer indices whose hidden-to-hidden product is taken on bf16-rounded operands (weights and input
+    streams), accumulated in the working precision -- the emulation of the library's config-4 "bf16 MFMA" mode.
     """
     rows = x.shape[0]
     nlayers = len(params)
@@ -79,6 +86,9 @@ def mlp_jets(params, act_name, x, dim, second, beta=None):
         else:
             kh = h.shape[1]
             wh = w[:, :kh]
+            if l in bf16_layers:
+                wh, h, hd, hdd = round_bf16(wh), round_bf16(h), [round_bf16(t) for t in hd], \
+                    [round_bf16(t) for t in hdd]
             a = h @ wh.t() + b
             ad = [t @ wh.t() for t in hd]
             add = [t @ wh.t() for t in hdd]
@@ -94,7 +104,8 @@ def mlp_jets(params, act_name, x, dim, second, beta=None):
         hdd = [s2 * ad[p] * ad[q] + s1 * add[k] for k, (p, q) in enumerate(second)]
 
 
-def lig_jets(params, act_name, latent_grid, pts, xmin=0.0, xmax=1.0, second=((1, 1), (2, 2)), beta=None):
+def lig_jets(params, act_name, latent_grid, pts, xmin=0.0, xmax=1.0, second=((1, 1), (2, 2)), beta=None,
+             bf16_layers=()):
     """Jets of y = query_local_implicit_grid(...) w.r.t. the query point coordinates.
 
     latent_grid [b, n1..nd, c], pts [b,p,d].  Returns tensor [S, b, p, out] with S = 1 + d + len(second):
@@ -131,7 +142,7 @@ def lig_jets(params, act_name, latent_grid, pts, xmin=0.0, xmax=1.0, second=((1,
         dom = torch.sign(t) / cube * s                            # d omega / d q (abs'(0)=0, quirk a-Q3)
         rel = (q - pos) / cube
         x = torch.cat([rel, lat], dim=-1).reshape(b * p, -1)
-        f = [t_.reshape(b, p, -1) for t_ in mlp_jets(params, act_name, x, dim, list(second), beta)]
+        f = [t_.reshape(b, p, -1) for t_ in mlp_jets(params, act_name, x, dim, list(second), beta, bf16_layers)]
         w = torch.prod(om, dim=-1, keepdim=True)
 
         def dw(d):

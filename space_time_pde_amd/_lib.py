@@ -32,7 +32,8 @@ class GatherDesc(C.Structure):
 
 
 class LayerDesc(C.Structure):
-    _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg)]
+    _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg),
+                ("mfma_bf16", C.c_int)]
 
 
 class XbarDesc(C.Structure):
@@ -101,8 +102,8 @@ _SIGNATURES = {
     "stpde_version": ([], C.c_int),
     "stpde_last_error": ([C.c_char_p, C.c_ulong], C.c_int),
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
-    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 10, C.c_int),
-    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 10, C.c_int),
+    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
+    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
     "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 9, C.c_int),
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
     "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),

@@ -14,6 +14,24 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16-operand MFMA (config-4 path): v_mfma_f32_16x16x32_bf16, lane l holds A[l&15][8*(l>>4)+e], B[8*(l>>4)+e][l&15]
+// (e = 0..7), D as above; operands are rounded to nearest-even (v_cvt_pk_bf16_f32), accumulation stays fp32.
+// The 8 k-slots of a lane carry TWO of the fp32 path's 4-element fragments (two k-tiles, or two streams).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x4 to_bf4(f32x4 v) {
+  bf16x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
+  return r;
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

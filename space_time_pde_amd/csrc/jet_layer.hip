@@ -32,7 +32,7 @@ static int check_cfg(const stpde_layer_desc* d) {
 extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X,
                                    const float* Wh_pack, const float* Ws_pack, const float* tanc,
                                    const float* W0s_pack, const float* tanc0, float* out_pre, const float* cw,
-                                   void* stream) {
+                                   const void* Wh_pack_bf16, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   LayerArgs a{};
@@ -45,6 +45,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
   a.tanc = tanc;
   a.Out = out_pre;
   a.cw = cw;
+  a.Wp16 = d->mfma_bf16 ? Wh_pack_bf16 : nullptr;
   a.KT = d->KT;
   a.MT = d->MT;
   a.ntiles = d->ntiles;
@@ -69,7 +70,8 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
 
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
-                                   float* abar0, const float* cw, float* act_param_bar, void* stream) {
+                                   float* abar0, const float* cw, float* act_param_bar,
+                                   const void* WhT_pack_bf16, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -81,6 +83,7 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
   a.tanc0 = tanc0;
   a.cw = cw;
   a.pbar = act_param_bar;
+  a.Wp16 = d->mfma_bf16 ? WhT_pack_bf16 : nullptr;
   a.KT = d->MT;
   a.MT = d->KT;
   a.ntiles = d->ntiles;

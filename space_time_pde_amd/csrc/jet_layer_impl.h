@@ -26,6 +26,7 @@ struct LayerArgs {
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
   float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
   const float* cw;     // [P][8] per-point weights of the combined second-order stream (S2 == 1), else unused
+  const void* Wp16;    // [KT/2][MT][64] x 8 bf16: A operand of the bf16-MFMA variant (two k-tiles per block), or null
   float* pbar;         // dgrad, swish only: [STPDE_PBAR_SLOTS] accumulators of the adjoint of beta (nullable)
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
@@ -205,10 +206,13 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // 4 ways.  One barrier per 4 k-tiles; production of group g+1 sits in the same basic block as the MFMAs of group g.
 // Requires KT % 4 == 0 and MT % (4*MCg) == 0 (otherwise the per-wave kernel above is used).
 // ------------------------------------------------------------------------------------------------------------
-template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
+// BF: the hidden-to-hidden GEMM runs on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 in the produce stage /
+// the bf16 weight pack, fp32 accumulation); the ring then holds 8-byte bf16 fragments and one MFMA contracts over TWO
+// k-tiles.  Layer-0 regeneration, skip GEMM, activation jets and epilogues stay fp32.
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2;
-  __shared__ __attribute__((aligned(16))) float hb[2][NW][S][256];
+  __shared__ __attribute__((aligned(16))) float hb[2][NW][S][BF ? 128 : 256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int KT = a.KT, MT = a.MT;
@@ -257,7 +261,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
     }
 #pragma unroll
-    for (int st = 0; st < S; ++st) st4(&hb[buf][wv][st][lo], B[st]);
+    for (int st = 0; st < S; ++st) {
+      if constexpr (BF)
+        *reinterpret_cast<bf16x4*>(&hb[buf][wv][st][lane * 2]) = to_bf4(B[st]);
+      else
+        st4(&hb[buf][wv][st][lo], B[st]);
+    }
   };
 
   const int ngroups = KT / NW;
@@ -273,6 +282,24 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     __syncthreads();
     for (int gi = 0; gi < ngroups; ++gi) {
       const int buf = gi & 1;
+      if constexpr (BF) {
+        const bf16x8* wp16 = reinterpret_cast<const bf16x8*>(a.Wp16) + (size_t)mt0 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NW / 2; ++q) {
+          const int kp = NW / 2 * gi + q;       // pair of k-tiles (2 kp, 2 kp + 1)
+          bf16x8 B8[S], w8[MCg];
+#pragma unroll
+          for (int st = 0; st < S; ++st)
+            B8[st] = cat8(*reinterpret_cast<const bf16x4*>(&hb[buf][2 * q][st][lane * 2]),
+                          *reinterpret_cast<const bf16x4*>(&hb[buf][2 * q + 1][st][lane * 2]));
+#pragma unroll
+          for (int mi = 0; mi < MCg; ++mi) w8[mi] = wp16[((size_t)kp * MT + mi) * 64];
+#pragma unroll
+          for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+            for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(w8[mi], B8[st], acc[mi][st]);
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
         const int kt = NW * gi + q;
@@ -287,6 +314,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int st = 0; st < S; ++st) acc[mi][st] = mfma4(w[mi][r], B[st][r], acc[mi][st]);
+      }
       }
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
@@ -307,7 +335,10 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
   a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
   const int nblocks = a.split ? (a.ntiles + 7) / 8 * 8 * a.split : a.ntiles;
-  STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+  if (a.Wp16)
+    STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+  else
+    STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   return stpde_check_launch("k_layer_coop");
 }
 

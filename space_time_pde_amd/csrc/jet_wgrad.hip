@@ -34,6 +34,7 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   a.MT = d->MT;
   a.ntiles = d->ntiles;
   a.cfg = d->cfg;
+  a.bf16 = d->mfma_bf16;
   if (d->first_hidden) {
     if (!X || !W0s_pack || (d->cfg.S1 && !tanc0R)) {
       stpde_set_error("jet_wgrad: first_hidden needs X/W0s_pack/tanc0R");

@@ -31,6 +31,7 @@ struct WgradArgs {
   int SP, KT, MT, ntiles;
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
+  int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
   stpde_jet_cfg cfg;
 };
 
@@ -55,7 +56,9 @@ __device__ __forceinline__ f32x4 lds_get_R(const float* blk, int lane) {
   return *reinterpret_cast<const f32x4*>(blk + (lane & 15) * TPAD + 4 * (lane >> 4));
 }
 
-template <int S1, int S2, int MODE, int ACT, int KC, bool HASX>
+// BF: one v_mfma_f32_16x16x32_bf16 contracts over the 16 rows of the tile for TWO derivative streams (k-slot e of a
+// lane = stream parity e >> 2, row 4g + (e & 3)), operands rounded to bf16 when they leave LDS / the patch.
+template <int S1, int S2, int MODE, int ACT, int KC, bool HASX, bool BF = false>
 __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   constexpr int S = 1 + S1 + S2, MCW = 2, NW = 8, RS = 8;
   constexpr int NM = KC;                    // m-slots per workgroup; k-slots = NW / NM, each KC ring slots wide
@@ -163,6 +166,19 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       }
   };
 
+  constexpr int SH = (S + 1) / 2, SXH = (SX + 1) / 2;
+  bf16x8 pa8[BF ? SH : 1][MCW];
+  const bf16x4 zero4 = to_bf4(f32x4{0.f, 0.f, 0.f, 0.f});
+  auto pack_p = [&](f32x4 (*pa_)[MCW]) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int sp = 0; sp < SH; ++sp)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi)
+          pa8[sp][mi] = cat8(to_bf4(pa_[2 * sp][mi]), 2 * sp + 1 < S ? to_bf4(pa_[2 * sp + 1][mi]) : zero4);
+    }
+  };
+
   const int stride = a.gx;
   int tile = bx;
   f32x4 pa[S][MCW];
@@ -171,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     produce(tile, 0);
     load_p_raw(tile, raw);
     transpose_p(raw, pa);
+    pack_p(pa);
   }
   __syncthreads();
   int buf = 0;
@@ -187,33 +204,53 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         f32x4 H[S];
 #pragma unroll
         for (int st = 0; st < S; ++st) H[st] = get(&hl[buf][q][st][0]);
+        if constexpr (BF) {
+#pragma unroll
+          for (int sp = 0; sp < SH; ++sp) {
+            const bf16x8 H8 = cat8(to_bf4(H[2 * sp]), 2 * sp + 1 < S ? to_bf4(H[2 * sp + 1]) : zero4);
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma_bf(pa8[sp][mi], H8, acc[mi][ki]);
+          }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int st = 0; st < S; ++st) acc[mi][ki] = mfma4(pa[st][mi][r], H[st][r], acc[mi][ki]);
+        }
       } else if (kq < KT + XT) {
         f32x4 H[SX];
 #pragma unroll
         for (int st = 0; st < SX; ++st) H[st] = get(&hl[buf][q][st][0]);
+        if constexpr (BF) {
+#pragma unroll
+          for (int sp = 0; sp < SXH; ++sp) {
+            const bf16x8 H8 = cat8(to_bf4(H[2 * sp]), 2 * sp + 1 < SX ? to_bf4(H[2 * sp + 1]) : zero4);
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma_bf(pa8[sp][mi], H8, acc[mi][ki]);
+          }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int st = 0; st < SX; ++st) acc[mi][ki] = mfma4(pa[st][mi][r], H[st][r], acc[mi][ki]);
+        }
       }
     }
     if (NBUF == 2) {
       produce(nx, buf ^ 1);
       transpose_p(raw, pa);
+      pack_p(pa);
       __syncthreads();
       buf ^= 1;
     } else {
       __syncthreads();
       produce(nx, 0);
       transpose_p(raw, pa);
+      pack_p(pa);
       __syncthreads();
     }
   }
@@ -249,10 +286,20 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
     gx = (gx + 7) / 8 * 8;
     if (gx < 8) gx = 8;
     a.gx = gx;
-    if (part == 0)
-      STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false>), dim3(gx * a.gy * a.gz), dim3(512), 0, stream, a);
-    else
-      STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true>), dim3(gx * a.gy * a.gz), dim3(512), 0, stream, a);
+    constexpr bool HAS_BF = KC >= 4;          // bf16 variant compiled for the wide layers only (MT >= 8)
+    const dim3 grid(gx * a.gy * a.gz);
+    if (HAS_BF && a.bf16) {
+      if constexpr (HAS_BF) {
+        if (part == 0)
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true>), grid, dim3(512), 0, stream, a);
+        else
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, true>), grid, dim3(512), 0, stream, a);
+      }
+    } else if (part == 0) {
+      STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false>), grid, dim3(512), 0, stream, a);
+    } else {
+      STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true>), grid, dim3(512), 0, stream, a);
+    }
     int rc = stpde_check_launch("k_wgrad_coop");
     if (rc) return rc;
   }

@@ -11,6 +11,7 @@ Everything here is plumbing (buffer allocation, weight packing by index gather, 
 query points runs in the HIP library.  There is no fallback: tensors must be CUDA/HIP float32.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -162,6 +163,18 @@ class ImNetPlan:
         theta = torch.cat([p.detach().reshape(-1).float() for p in params] + [torch.zeros(1, device=dev)])
         return theta[pidx]
 
+    def pack_bf16(self, packs):
+        """bf16 A-operand packs of the hidden-to-hidden weights (config-4 path): block (q, mt) = the fp32 blocks
+        (2q, mt) and (2q+1, mt) lane by lane, rounded to bf16.  Returns {(l, "Wh"|"WhT"): tensor}."""
+        out = {}
+        for l in range(1, 6):
+            kt, mt = self.layers[l]["KT"], self.layers[l]["MT"]
+            for name, (ka, ma) in (("Wh", (kt, mt)), ("WhT", (mt, kt))):
+                if ka % 2 == 0:
+                    w = self.pack_view(packs, l, name).view(ka // 2, 2, ma, 64, 4)
+                    out[(l, name)] = w.permute(0, 2, 3, 1, 4).to(torch.bfloat16).contiguous()
+        return out
+
     def pack_view(self, packs, l, name):
         off, n = self.pack_off[l][name]
         return packs[off:off + n]
@@ -284,9 +297,10 @@ class _Meta:
     pass
 
 
-def _layer_desc(ntiles, lay, cfg, first_hidden):
+def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=False):
     d = LayerDesc()
     d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg = ntiles, lay["KT"], lay["MT"], int(first_hidden), cfg
+    d.mfma_bf16 = int(bf16)
     return d
 
 
@@ -320,11 +334,12 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     for l in range(1, 6):
         lay = plan.layers[l]
         out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
-        d = _layer_desc(nt, lay, cfg, l == 1)
+        w16 = meta.packs16.get((l, "Wh")) if meta.packs16 else None
+        d = _layer_desc(nt, lay, cfg, l == 1, w16 is not None)
         with _timed("layer%d_fwd" % l):
             check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")),
                                         ptr(pv(packs, l, "Ws")), ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(out), ptr(cw), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(out), ptr(cw), ptr(w16), st))
         bufs.append(out)
         prev = out
     with _timed("reduce_fwd"):
@@ -353,7 +368,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
     for l in range(5, 0, -1):
         lay = plan.layers[l]
-        d = _layer_desc(nt, lay, cfg, l == 1)
+        w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
+        d = _layer_desc(nt, lay, cfg, l == 1, w16 is not None)
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
@@ -363,7 +379,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), ptr(w16), st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
@@ -393,6 +409,7 @@ class LigJetFunction(torch.autograd.Function):
     def forward(ctx, meta, latent, pts, act_param, *params):
         # act_param: the learnable swish beta (a tensor input so that autograd routes its gradient) or None
         packs = meta.plan.pack(params)
+        meta.packs16 = meta.plan.pack_bf16(packs) if meta.bf16 else None
         P = pts.shape[0]
         jets = torch.empty(meta.S_out, meta.plan.cout, P, device=pts.device)
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
@@ -458,8 +475,22 @@ def activation_name(module):
 
 DEFAULT_CHUNK = 1 << 16   # query points per launch chunk (bounds the per-chunk backward scratch)
 
+# MFMA operand precision of the hidden-to-hidden GEMMs of the wide layers: "fp32" (exact-fp32 MFMA, the default and
+# the parity path) or "bf16" (BASELINE config 4: bf16 operands, fp32 accumulation, everything else fp32).
+mlp_precision = os.environ.get("STPDE_MLP_PRECISION", "fp32")
 
-def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=None, combo=None):
+
+def set_mlp_precision(precision):
+    """Select "fp32" or "bf16" MFMA operands for subsequent HIP jet calls; returns the previous setting."""
+    global mlp_precision
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("mlp precision must be 'fp32' or 'bf16'")
+    prev, mlp_precision = mlp_precision, precision
+    return prev
+
+
+def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=None, combo=None,
+             precision=None):
     """HIP evaluation of y and its coordinate derivatives.
 
     imnet: implicit_net.ImNet (dim=3); latent_grid [b, n0, n1, n2, c]; query_pts [b, p, 3].
@@ -467,6 +498,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     Stream order: value, d/dq_0, d/dq_1, d/dq_2, then d2/dq_a dq_b per pair.
     combo = {(a, b): alpha}: instead of one stream per pair, ONE combined second-order stream
     sum alpha_ab d2y/dq_a dq_b is carried through the network (S = 5); returned pairs = ["combo"].
+    precision: "fp32" | "bf16" MFMA operands of the wide layers (None = module setting ``mlp_precision``).
     """
     if not (latent_grid.is_cuda and query_pts.is_cuda):
         raise RuntimeError("the HIP jet path needs CUDA/HIP tensors (no CPU fallback)")
@@ -490,6 +522,11 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
         raise ValueError("latent channels != imnet.in_features")
     meta = _Meta()
     meta.plan = plan
+    precision = precision or mlp_precision
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("mlp precision must be 'fp32' or 'bf16'")
+    meta.bf16 = precision == "bf16"
+    meta.packs16 = None
     # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
     # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams
     # go through the network and the reduction supplies the second derivatives from the weight cross terms

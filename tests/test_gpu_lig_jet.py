@@ -227,3 +227,51 @@ def test_edge_cases_empty_single_and_boundary_points(hiplib):
     out = O.lig_pde_step(p32, "softplus", lat, pts, torch.zeros(1, 5, 4), O.rb2_oracle(**kw), backward=False)
     for k, v in out["residues"].items():
         assert (res[k].cpu() - v).abs().max().item() < 1e-4 * max(v.abs().max().item(), 1e-3), k
+
+
+def _bf16_layers(nf):
+    """Layers whose hidden-to-hidden GEMM runs on bf16 MFMA operands (include/stpde_hip.h, stpde_layer_desc.mfma_bf16):
+    those served by the workgroup-cooperative kernels, KT % 4 == 0, KT >= 8, MT % 8 == 0."""
+    widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf]
+    return tuple(l for l in range(1, 5) if (widths[l - 1] // 16) % 4 == 0 and widths[l - 1] // 16 >= 8
+                 and (widths[l] // 16) % 8 == 0)
+
+
+@pytest.mark.parametrize("act", ["softplus", "leakyrelu", "tanh"])
+def test_bf16_mfma_mode_config4(hiplib, act):
+    """BASELINE config 4: bf16 MFMA operands / fp32 accumulation in the wide layers.  Tolerances (explicit, looser
+    than the fp32 path): vs an oracle that rounds the same operands to bf16: 5e-4 (Frobenius); vs exact fp64: 3e-2."""
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(2, 150, 3, generator=g)
+    pairs = ((1, 1), (2, 2))
+    net = _net(act, nf=32).to(dev)
+    assert _bf16_layers(32) == (1, 2)
+    latd = lat.to(dev).requires_grad_(True)
+    jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, pairs, chunk_points=128, precision="bf16")
+    with torch.no_grad():
+        jets32, _ = lig_jet.lig_jets(net, lat.to(dev), pts.to(dev), 0., 1., True, pairs, chunk_points=128)
+    emu = J.lig_jets(_params64(net), act, lat.double(), pts.double(), 0., 1., second=tuple(pp),
+                     bf16_layers=_bf16_layers(32))
+    emu = emu.permute(0, 3, 1, 2).reshape(emu.shape[0], 4, -1)
+    p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
+    lat64 = lat.double().requires_grad_(True)
+    ref = J.lig_jets(p64, act, lat64, pts.double(), 0., 1., second=tuple(pp))
+    ref = ref.permute(0, 3, 1, 2).reshape(ref.shape[0], 4, -1)
+    pl_act = act == "leakyrelu"
+    for s in range(ref.shape[0]):
+        assert _normerr(jets[s], emu[s]) < (5e-3 if pl_act else 5e-4), "stream %d vs bf16-emulating oracle" % s
+        assert _normerr(jets[s], ref[s].detach()) < 3e-2, "stream %d vs exact" % s
+        assert _normerr(jets[s], jets32[s].double().cpu()) > 1e-5, "bf16 mode did not engage (stream %d)" % s
+    cot = torch.randn(jets.shape, generator=g)
+    (jets * cot.to(dev)).sum().backward()
+    (ref * cot.double()).sum().backward()
+    # piecewise-linear activations: operand rounding flips kinks (sigma' jumps), so the early layers' gradients of
+    # this random-cotangent functional move more than for smooth activations
+    gtol = 1e-1 if pl_act else 3e-2
+    assert _normerr(latd.grad, lat64.grad) < gtol
+    for k in range(6):
+        assert _normerr(net.fc[k].weight.grad, p64[k][0].grad) < gtol, "dW%d" % k
+        assert _normerr(net.fc[k].bias.grad, p64[k][1].grad) < gtol, "db%d" % k
