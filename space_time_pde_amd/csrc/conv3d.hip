@@ -45,7 +45,10 @@ __device__ __forceinline__ int tap_neighbour(const stpde_conv3d_desc& d, const V
 }
 
 // VT voxel tiles (16 voxels each) per wave: every weight block that is loaded feeds VT*4 MFMAs per output tile.
-template <int MC, int VT>
+// SPLIT (small volumes = the deep U-Net levels, where a handful of waves would otherwise walk 27 taps x all channel
+// tiles serially): blockIdx.z owns a slice of the taps and adds its partial sums to the zero-filled output with fp32
+// atomics; taps whose 16 neighbours all fall outside the volume are skipped.
+template <int MC, int VT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
   const int lane = threadIdx.x & 63;
   const int tile0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * VT;
@@ -71,7 +74,10 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
     for (int t = 0; t < VT; ++t)
 #pragma unroll
       for (int mi = 0; mi < MC; ++mi) acc[t][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tap = 0; tap < ntap; ++tap) {
+    const int tps = SPLIT ? (ntap + (int)gridDim.z - 1) / (int)gridDim.z : ntap;
+    const int tap_lo = SPLIT ? (int)blockIdx.z * tps : 0;
+    const int tap_hi = tap_lo + tps < ntap ? tap_lo + tps : ntap;
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
       int nb[VT];
       const float* src[VT];
 #pragma unroll
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
         nb[t] = vin[t] ? tap_neighbour(a.d, c[t], tap) : -1;
         src[t] = a.x + (size_t)(nb[t] < 0 ? 0 : nb[t]) * Ci + 4 * g;
       }
+      if (SPLIT && VT == 1 && __ballot(nb[0] >= 0) == 0) continue;   // wave-uniform: nothing to add for this tap
       for (int kt = 0; kt < KT; ++kt) {
         f32x4 B[VT];
 #pragma unroll
@@ -106,16 +113,27 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
         const int mt = mt0 + mi;
         if (mt >= MT) continue;
         f32x4 o = acc[t][mi];
-        if (a.bias) o += ld4(a.bias + 16 * mt + 4 * g);
-        st4(a.y + (size_t)v[t] * Co + 16 * mt + 4 * g, o);
+        float* yp = a.y + (size_t)v[t] * Co + 16 * mt + 4 * g;
+        if (SPLIT) {
+          if (a.bias && blockIdx.z == 0) o += ld4(a.bias + 16 * mt + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(yp + r, o[r]);
+        } else {
+          if (a.bias) o += ld4(a.bias + 16 * mt + 4 * g);
+          st4(yp, o);
+        }
       }
     }
   }
 }
 
-// one wave per (tap, co-tile block, ci-tile block), striding over voxel tiles; dW[tap][co][ci]
-template <int MCW, int KCW>
+// Weight gradient: a wave owns (tap group of TG taps, MCW co-tiles, KCW ci-tiles) and strides over voxel tiles; the
+// ybar fragment of a tile is loaded once and reused for the TG taps (the shifted x fragments mostly hit L1), and the
+// voxel coordinates are decoded once per tile.  The four waves of a block are summed through LDS before ONE set of
+// fp32 atomics per block, so at most gridDim.x atomics hit any dW address.
+template <int MCW, int KCW, int TG>
 __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
+  __shared__ float red[4][256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int kk = lane >> 4, i = lane & 15;
@@ -125,51 +143,60 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
   const int kb = id % nkb;
   id /= nkb;
   const int mb = id % nmb;
-  const int tap = id / nmb;
-  f32x4 acc[MCW][KCW];
+  const int tap0 = (id / nmb) * TG;
+  f32x4 acc[TG][MCW][KCW];
 #pragma unroll
-  for (int mi = 0; mi < MCW; ++mi)
+  for (int tg = 0; tg < TG; ++tg)
 #pragma unroll
-    for (int ki = 0; ki < KCW; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+      for (int ki = 0; ki < KCW; ++ki) acc[tg][mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (a.nvox + 15) / 16;
+#pragma unroll 1
   for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int v = tile * 16 + 4 * s + kk;
       const bool vin = v < a.nvox;
       const Vox c = vox_coords(a.d, vin ? v : 0);
-      const int nb = vin ? tap_neighbour(a.d, c, tap) : -1;
-      float pa[MCW], qb[KCW];
+      float pa[MCW];
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         const int mt = mb * MCW + mi;
         pa[mi] = (vin && mt < MT) ? a.ybar[(size_t)v * Co + 16 * mt + i] : 0.f;
       }
 #pragma unroll
-      for (int ki = 0; ki < KCW; ++ki) {
-        const int kt = kb * KCW + ki;
-        qb[ki] = (nb >= 0 && kt < KT) ? a.x[(size_t)nb * Ci + 16 * kt + i] : 0.f;
+      for (int tg = 0; tg < TG; ++tg) {
+        const int nb = vin ? tap_neighbour(a.d, c, tap0 + tg) : -1;
+        float qb[KCW];
+#pragma unroll
+        for (int ki = 0; ki < KCW; ++ki) {
+          const int kt = kb * KCW + ki;
+          qb[ki] = (nb >= 0 && kt < KT) ? a.x[(size_t)nb * Ci + 16 * kt + i] : 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+          for (int ki = 0; ki < KCW; ++ki) acc[tg][mi][ki] = mfma4(pa[mi], qb[ki], acc[tg][mi][ki]);
       }
-#pragma unroll
-      for (int mi = 0; mi < MCW; ++mi)
-#pragma unroll
-        for (int ki = 0; ki < KCW; ++ki) acc[mi][ki] = mfma4(pa[mi], qb[ki], acc[mi][ki]);
     }
   }
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
-  for (int mi = 0; mi < MCW; ++mi) {
-    const int mt = mb * MCW + mi;
-    if (mt >= MT) continue;
+  for (int tg = 0; tg < TG; ++tg)
 #pragma unroll
-    for (int ki = 0; ki < KCW; ++ki) {
-      const int kt = kb * KCW + ki;
-      if (kt >= KT) continue;
+    for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomicAdd(a.dW + ((size_t)tap * Co + 16 * mt + 4 * g + r) * Ci + 16 * kt + c, acc[mi][ki][r]);
-    }
-  }
+      for (int ki = 0; ki < KCW; ++ki) {
+        __syncthreads();
+        st4(&red[wv][lane * 4], acc[tg][mi][ki]);
+        __syncthreads();
+        const int mt = mb * MCW + mi, kt = kb * KCW + ki;
+        if (mt >= MT || kt >= KT) continue;          // block-uniform
+        // wave w sums and adds register r == w of every lane's fragment
+        const float sum = (red[0][lane * 4 + wv] + red[1][lane * 4 + wv]) + (red[2][lane * 4 + wv] + red[3][lane * 4 + wv]);
+        atomicAdd(a.dW + ((size_t)(tap0 + tg) * Co + 16 * mt + 4 * g + wv) * Ci + 16 * kt + c, sum);
+      }
 }
 
 static int check_conv(const stpde_conv3d_desc* d) {
@@ -202,11 +229,36 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
   a.nvox = d->B * d->T * d->Z * d->X;
   const int ntiles = (a.nvox + 15) / 16;
   const int nchunks = (d->Co / 16 + 3) / 4;
+  const int MT = d->Co / 16;
+  const hipStream_t st = (hipStream_t)stream;
+  // MC = output-channel tiles per pass: never more than the layer has (a clamped tile would redo real MFMA work)
   if (ntiles >= 16384) {   // big volumes: 4 voxel tiles per wave (4x weight reuse), one wave walks all chunks
-    STPDE_LAUNCH((k_conv3d_fwd<4, 4>), dim3((ntiles + 15) / 16, 1), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((ntiles + 15) / 16, 1);
+    if (MT == 1)
+      STPDE_LAUNCH((k_conv3d_fwd<1, 4>), grid, dim3(256), 0, st, a);
+    else if (MT == 2)
+      STPDE_LAUNCH((k_conv3d_fwd<2, 4>), grid, dim3(256), 0, st, a);
+    else
+      STPDE_LAUNCH((k_conv3d_fwd<4, 4>), grid, dim3(256), 0, st, a);
   } else {
-    const int gy = (ntiles + 3) / 4 >= 1024 ? 1 : nchunks;
-    STPDE_LAUNCH((k_conv3d_fwd<4, 1>), dim3((ntiles + 3) / 4, gy), dim3(256), 0, (hipStream_t)stream, a);
+    const int gx = (ntiles + 3) / 4;
+    const int gy = gx >= 1024 ? 1 : nchunks;
+    // 3x3x3 convs of the deep levels: too few (voxel tile, channel chunk) pairs to fill 256 CUs -> split the taps
+    int gz = 1;
+    if (d->ksize == 3 && gx * gy < 256) {
+      gz = (256 + gx * gy - 1) / (gx * gy);
+      if (gz > 27) gz = 27;
+    }
+    if (gz > 1) {
+      (void)hipMemsetAsync(y, 0, (size_t)a.nvox * d->Co * sizeof(float), st);
+      STPDE_LAUNCH((k_conv3d_fwd<4, 1, true>), dim3(gx, gy, gz), dim3(256), 0, st, a);
+    } else if (MT == 1) {
+      STPDE_LAUNCH((k_conv3d_fwd<1, 1>), dim3(gx, gy), dim3(256), 0, st, a);
+    } else if (MT == 2) {
+      STPDE_LAUNCH((k_conv3d_fwd<2, 1>), dim3(gx, gy), dim3(256), 0, st, a);
+    } else {
+      STPDE_LAUNCH((k_conv3d_fwd<4, 1>), dim3(gx, gy), dim3(256), 0, st, a);
+    }
   }
   return stpde_check_launch("k_conv3d_fwd");
 }
@@ -225,14 +277,24 @@ extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, co
   a.ybar = ybar;
   a.dW = dW;
   a.nvox = d->B * d->T * d->Z * d->X;
-  constexpr int MCW = 2, KCW = 2;
-  const int ntap = d->ksize == 3 ? 27 : 1;
-  const int nmb = (d->Co / 16 + MCW - 1) / MCW, nkb = (d->Ci / 16 + KCW - 1) / KCW;
-  const int gy = ntap * nmb * nkb;
   const int ntiles = (a.nvox + 15) / 16;
-  int gx = 2048 / gy;
-  if (gx < 1) gx = 1;
-  if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
-  STPDE_LAUNCH((k_conv3d_wgrad<MCW, KCW>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  const int KT = d->Ci / 16, MT = d->Co / 16;
+  // (tap group, co block, ci block) triples on blockIdx.y; voxel-tile stripes on blockIdx.x: ~2048 blocks in total
+  // (8 waves per SIMD hide the dword-load latency), at most 1024 stripes (= atomic adds any dW element receives)
+  auto stripes = [&](int gy) {
+    int gx = 2048 / gy;
+    if (gx > 1024) gx = 1024;
+    if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+    return gx < 1 ? 1 : gx;
+  };
+  if (d->ksize == 3 && KT == 1 && MT == 1) {
+    STPDE_LAUNCH((k_conv3d_wgrad<1, 1, 9>), dim3(stripes(3), 3), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (d->ksize == 3) {
+    const int gy = 9 * ((MT + 1) / 2) * ((KT + 1) / 2);
+    STPDE_LAUNCH((k_conv3d_wgrad<2, 2, 3>), dim3(stripes(gy), gy), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    const int gy = ((MT + 1) / 2) * ((KT + 1) / 2);
+    STPDE_LAUNCH((k_conv3d_wgrad<2, 2, 1>), dim3(stripes(gy), gy), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return stpde_check_launch("k_conv3d_wgrad");
 }

@@ -1,0 +1,81 @@
+"""Per-layer timing of the UNet3d convolutions (HIP kernels) and of the whole UNet forward / backward.
+
+Usage (GPU box):  python tools/unet_profile.py [T Z X]
+"""
+import collections
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from space_time_pde_amd import _lib, unet3d  # noqa: E402
+
+
+class _Proxy:
+    def __init__(self, real, rec):
+        self._real, self._rec = real, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name not in ("stpde_conv3d_fwd", "stpde_conv3d_wgrad"):
+            return fn
+
+        def wrapped(desc, *args):
+            d = C.cast(desc, C.POINTER(_lib.Conv3dDesc)).contents
+            key = (name[6:], d.B * d.T * d.Z * d.X, d.Ci, d.Co, d.ksize)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(desc, *args)
+            e1.record()
+            self._rec.append((key, e0, e1))
+            return rc
+        return wrapped
+
+
+def main():
+    igres = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 128, 128)
+    dev = torch.device("cuda:0")
+    real = _lib.lib()
+    rec = []
+    proxy = _Proxy(real, rec)
+    _lib.lib = lambda: proxy
+    unet3d._lib.lib = _lib.lib
+    torch.manual_seed(0)
+    net = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256).to(dev).train()
+    x = torch.randn(1, 4, *igres, device=dev)
+    g = torch.randn(1, 32, *igres, device=dev)
+    tf, tb = [], []
+    for it in range(4):
+        if it == 1:
+            rec.clear()
+        for p in net.parameters():
+            p.grad = None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        y = net(x)
+        e[1].record()
+        y.backward(g)
+        e[2].record()
+        torch.cuda.synchronize()
+        if it:
+            tf.append(e[0].elapsed_time(e[1]))
+            tb.append(e[1].elapsed_time(e[2]))
+    print("UNet3d igres=%s: forward %.2f ms, backward %.2f ms (mean of 3)" % (igres, sum(tf) / 3, sum(tb) / 3))
+    agg = collections.OrderedDict()
+    for key, e0, e1 in rec:
+        a = agg.setdefault(key, [0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+    tot = 0.0
+    print("%-14s %9s %4s %4s %2s %6s %9s %9s %8s" % ("kernel", "nvox", "Ci", "Co", "k", "calls", "ms/step", "us/call", "TFLOP/s"))
+    for (kind, nvox, ci, co, k), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        flop = 2.0 * nvox * ci * co * k ** 3
+        print("%-14s %9d %4d %4d %2d %6d %9.3f %9.1f %8.1f" % (kind, nvox, ci, co, k, n // 3, ms / 3, 1e3 * ms / n,
+                                                              flop / (ms / n * 1e-3) / 1e12))
+        tot += ms / 3
+    print("conv kernels total: %.2f ms/step (event-bracketed, includes launch gaps)" % tot)
+
+
+if __name__ == "__main__":
+    main()
