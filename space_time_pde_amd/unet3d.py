@@ -65,26 +65,36 @@ def _desc(x, ci, co, k):
 
 
 class _Conv3dHip(torch.autograd.Function):
-    """y = conv3d(x, weight, bias), stride 1, padding (k-1)/2, on channels-last x [B,T,Z,X,Ci]."""
+    """y = conv3d(x, weight, bias), stride 1, padding (k-1)/2, on channels-last x [B,T,Z,X,Ci].
+
+    packs = (forward A-operand pack, input-gradient pack) prepared by the caller (UNet3d packs all of its convolutions
+    with one gather per step), or None: packed here."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, packs=None):
         L = _lib.lib()
         co, ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
-        fidx, bidx, cip, cop = _pack_indices(co, ci, k, x.device)
+        cip, cop = (ci + 15) // 16 * 16, (co + 15) // 16 * 16
         if cop != co:
             raise NotImplementedError("HIP conv3d needs out_channels to be a multiple of 16 (got %d)" % co)
-        wflat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
+        ctx.dwbuf = None
+        if packs is None:
+            fidx, bidx, _, _ = _pack_indices(co, ci, k, x.device)
+            wflat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
+            fpack, bpack = wflat[fidx], None
+        else:
+            fpack, bpack, ctx.dwbuf = packs
+            wflat = bidx = None
         xin = x.detach()
         if cip != ci:
             xin = F.pad(xin, (0, cip - ci))
         xin = xin.contiguous()
         y = torch.empty(x.shape[:-1] + (co,), device=x.device, dtype=torch.float32)
         d = _desc(xin, cip, co, k)
-        _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(xin), _lib.ptr(wflat[fidx]),
+        _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(xin), _lib.ptr(fpack),
                                       _lib.ptr(bias.detach().contiguous()) if bias is not None else None,
                                       _lib.ptr(y), _lib.stream_ptr()))
-        ctx.save_for_backward(xin, wflat)
+        ctx.save_for_backward(xin, wflat if bpack is None else bpack)
         ctx.meta = (co, ci, k, cip, bidx, bias is not None)
         return y
 
@@ -92,31 +102,34 @@ class _Conv3dHip(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         L = _lib.lib()
-        xin, wflat = ctx.saved_tensors
+        xin, wsaved = ctx.saved_tensors
         co, ci, k, cip, bidx, has_bias = ctx.meta
         gy = gy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dxp = torch.empty(xin.shape, device=gy.device, dtype=torch.float32)
             d = _desc(gy, co, cip, k)
-            _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(gy), _lib.ptr(wflat[bidx]), None, _lib.ptr(dxp),
+            bpack = wsaved if bidx is None else wsaved[bidx]
+            _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(gy), _lib.ptr(bpack), None, _lib.ptr(dxp),
                                           _lib.stream_ptr()))
             dx = dxp[..., :ci] if cip != ci else dxp
         if ctx.needs_input_grad[1]:
             ntap = k ** 3
-            dwt = torch.zeros(ntap, co, cip, device=gy.device, dtype=torch.float32)
+            dwt, ctx.dwbuf = ctx.dwbuf, None     # zero-filled slice of the per-step buffer (used once), else a fresh one
+            if dwt is None:
+                dwt = torch.zeros(ntap, co, cip, device=gy.device, dtype=torch.float32)
             d = _desc(xin, cip, co, k)
             _lib.check(L.stpde_conv3d_wgrad(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt), _lib.stream_ptr()))
             dw = dwt[:, :, :ci].permute(1, 2, 0).reshape(co, ci, k, k, k)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.reshape(-1, co).sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def _conv_cl(x, conv):
     """Apply an nn.Conv3d (1x1x1 or 3x3x3/pad 1, stride 1) to a channels-last tensor [B,T,Z,X,C]."""
     if x.is_cuda:
-        return _Conv3dHip.apply(x, conv.weight, conv.bias)
+        return _Conv3dHip.apply(x, conv.weight, conv.bias, getattr(conv, "_stpde_packs", None))
     y = F.conv3d(x.permute(0, 4, 1, 2, 3), conv.weight, conv.bias, padding=conv.padding)
     return y.permute(0, 2, 3, 4, 1).contiguous()
 
@@ -124,7 +137,8 @@ def _conv_cl(x, conv):
 def _bn_cl(x, bn):
     """nn.BatchNorm3d semantics (batch statistics in training, running-stat update) on channels-last data."""
     shp = x.shape
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None \
+            and not getattr(bn, "_stpde_counted", False):
         bn.num_batches_tracked.add_(1)
     y = F.batch_norm(x.reshape(-1, shp[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
                      bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
@@ -262,8 +276,61 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
         self.down_pools = nn.ModuleList(down_pools)
         self.up_interps = nn.ModuleList(up_interps)
 
+    def _prepare_step(self, device):
+        """CUDA path: pack the weights of ALL convolutions with one concatenation + one index gather (instead of two
+        small kernels per convolution per pass) and bump all BatchNorm step counters with one foreach op."""
+        convs = [m for m in self.modules() if isinstance(m, nn.Conv3d)]
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or plan[0] != str(device):
+            total = sum(c.weight.numel() for c in convs)
+            chunks, spans, off, pos = [], [], 0, 0
+            for c in convs:
+                co, ci, k = c.weight.shape[0], c.weight.shape[1], c.weight.shape[2]
+                fidx, bidx, _, _ = _pack_indices(co, ci, k, device)
+                n = c.weight.numel()
+                for idx in (fidx, bidx):
+                    chunks.append(torch.where(idx == n, torch.full_like(idx, total), idx + off))
+                spans.append((pos, pos + fidx.numel(), pos + fidx.numel() + bidx.numel()))
+                pos += fidx.numel() + bidx.numel()
+                off += n
+            plan = (str(device), torch.cat(chunks), spans)
+            self._pack_plan = plan
+        theta = torch.cat([c.weight.detach().reshape(-1) for c in convs] + [torch.zeros(1, device=device)])
+        packs = theta[plan[1]]
+        # one zero-filled buffer for all weight gradients of this step (the kernels accumulate with atomics)
+        need_dw = torch.is_grad_enabled() and any(c.weight.requires_grad for c in convs)
+        sizes = [c.weight.shape[2] ** 3 * c.weight.shape[0] * ((c.weight.shape[1] + 15) // 16 * 16) for c in convs]
+        dwall = torch.zeros(sum(sizes), device=device) if need_dw else None
+        o = 0
+        for c, (a, b, e), n in zip(convs, plan[2], sizes):
+            co, ci, k = c.weight.shape[0], c.weight.shape[1], c.weight.shape[2]
+            dw = dwall[o:o + n].view(k ** 3, co, (ci + 15) // 16 * 16) if need_dw else None
+            c._stpde_packs = (packs[a:b], packs[b:e], dw)
+            o += n
+        bns = []
+        if self.training:
+            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm3d) and m.track_running_stats
+                   and m.num_batches_tracked is not None]
+            if bns:
+                torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+                for m in bns:
+                    m._stpde_counted = True
+        return convs, bns
+
     def forward(self, x):
         """x [batch, in_features, *igres] -> [batch, out_features, *ogres] (channels-last strides; reference :208-240)."""
+        if not x.is_cuda:
+            return self._forward_impl(x)
+        convs, bns = self._prepare_step(x.device)
+        try:
+            return self._forward_impl(x)
+        finally:
+            for c in convs:
+                c._stpde_packs = None
+            for m in bns:
+                m._stpde_counted = False
+
+    def _forward_impl(self, x):
         h = self.conv_in.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous())
         skips = [h]
         for mod, kernel in zip(self.down_modules, self._pool_kernels):
