@@ -134,6 +134,20 @@ def _conv_cl(x, conv):
     return y.permute(0, 2, 3, 4, 1).contiguous()
 
 
+class _ContiguousGrad(torch.autograd.Function):
+    """Identity whose backward hands a contiguous gradient upstream: a strided grad (e.g. a loss taken on the
+    [B,C,T,Z,X] view in NCHW order) would otherwise send torch's batch-norm backward down its generic, 100x slower
+    reduction kernel instead of the channels-last one."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 def _bn_cl(x, bn):
     """nn.BatchNorm3d semantics (batch statistics in training, running-stat update) on channels-last data."""
     shp = x.shape
@@ -185,7 +199,10 @@ class ResBlock3D(nn.Module):
         return F.relu(h) if self.final_relu else h
 
     def forward(self, x):  # [B, C, T, Z, X] -> [B, C', T, Z, X] (channels-last view)
-        return self.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous()).permute(0, 4, 1, 2, 3)
+        h = self.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous())
+        if h.is_cuda and h.requires_grad:
+            h = _ContiguousGrad.apply(h)
+        return h.permute(0, 4, 1, 2, 3)
 
 
 class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
@@ -346,4 +363,6 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
             for mod, factors in zip(self.exp_modules, self._exp_factors):
                 h = _upsample_cl(mod.forward_cl(h), factors)
         h = self.conv_out.forward_cl(h)
+        if h.is_cuda and h.requires_grad:
+            h = _ContiguousGrad.apply(h)
         return h.permute(0, 4, 1, 2, 3)

@@ -44,7 +44,7 @@ def main():
     torch.manual_seed(0)
     net = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256).to(dev).train()
     x = torch.randn(1, 4, *igres, device=dev)
-    g = torch.randn(1, 32, *igres, device=dev)
+    g = torch.randn(1, *igres, 32, device=dev).permute(0, 4, 1, 2, 3)   # channels-last, as the LIG backward delivers it
     tf, tb = [], []
     for it in range(4):
         if it == 1:
