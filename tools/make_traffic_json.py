@@ -19,16 +19,16 @@ def parse(path):
 
 
 def bench_name(sym):
-    m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)>", sym)
-    if m:
+    m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?>", sym)
+    if m and m.group(8) in (None, "false"):
         pro, epi = int(m.group(4)), int(m.group(5))
         if pro == 2 and epi == 0:
             return "layer1_fwd"
         if epi == 2:
             return "layer1_dgrad"
         return "layer2_fwd" if epi == 0 else "layer2_dgrad"
-    m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+)>", sym)
-    if m and int(m.group(3)) == 1 and m.group(6) == "false":
+    m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+?)(?:,(\w+))?>", sym)
+    if m and int(m.group(3)) == 1 and m.group(6) == "false" and m.group(7) in (None, "false"):
         return "layer1_wgrad"
     return None
 
