@@ -205,6 +205,39 @@ def main():
     dt = tt.item()
     assert lig.stats["hip_jet_calls"] >= args.steps, "HIP jet path was not taken"
 
+    # SURVEY 8(d) side figures (outside the timed region, rank 0 of a single-GPU run only): value-only inference rate,
+    # the step without the UNet, and the gather stage against its algorithmic 1036 B / point
+    side = None
+    if rank == 0 and world == 1:
+        import torch.nn.functional as F
+        with torch.no_grad():
+            latent = unet(crop).permute(0, 2, 3, 4, 1)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        with torch.no_grad():
+            lig.query_local_implicit_grid(net, latent, pts, 0., 1.)
+            ev[0].record()
+            for _ in range(3):
+                lig.query_local_implicit_grid(net, latent, pts, 0., 1.)
+            ev[1].record()
+
+        def lig_only_step():
+            for p in params:
+                p.grad = None
+            lat = latent.detach().requires_grad_(True)
+            layer.update_forward_method(lambda q: lig.query_local_implicit_grid(net, lat, q, 0., 1.))
+            pred, res = layer(pts, return_residue=True)
+            st = torch.stack(list(res.values()), 0)
+            (ALPHA_REG * F.l1_loss(pred, tgt) + ALPHA_PDE * st.abs().mean()).backward()
+
+        lig_only_step()
+        ev[2].record()
+        for _ in range(2):
+            lig_only_step()
+        ev[3].record()
+        torch.cuda.synchronize()
+        side = dict(inference_value_only_points_per_s=round(3 * args.points / (ev[0].elapsed_time(ev[1]) * 1e-3)),
+                    lig_only_step_points_per_s=round(2 * args.points / (ev[2].elapsed_time(ev[3]) * 1e-3)))
+
     if rank == 0:
         smooth = args.act not in ("relu", "leakyrelu")
         # piecewise-linear activations have identically zero second-order MLP jets
@@ -241,6 +274,14 @@ def main():
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
                                                 / PEAK_F32_TFLOPS, 4),
                         kernels={k: round(v["total_ms"] / args.steps, 2) for k, v in sorted(kern.items())})
+        if "gather" in kern:   # the gather stage in isolation is HBM-bound: algorithmic 1036 B per point
+            g_ms = kern["gather"]["avg_ms"]
+            roofline["gather_stage"] = dict(bound="hbm", achieved=round(1036.0 * min(args.chunk, n_local) / (g_ms * 1e-3) / 1e9, 1),
+                                            peak=8000.0, unit="GB/s", avg_launch_ms=round(g_ms, 3),
+                                            note="algorithmic 12 B coords + 8 x 32 x 4 B corner latents per point; the kernel "
+                                                 "also writes the 3 KiB/point fragment images of the MLP input")
+        if side:
+            roofline["side_figures"] = side
         bf16 = args.mlp_precision == "bf16"
         if bf16:
             # bf16 operands make the layer kernels HBM-bound on the fp32 stash: price them against HBM instead
