@@ -188,6 +188,24 @@ typedef struct {
 } stpde_adam_desc;
 int stpde_clip_adam(const stpde_adam_desc* d, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     void* stream);
+/* The same update for ALL parameter tensors in one launch (the reference's optimizer walks ~300 tensors).  Both
+ * tables live in device memory and are built by the caller: one stpde_adam_tensor per parameter (16-byte aligned
+ * pointers; step_size / bias2_sqrt per tensor, d->step_size / d->bias2_sqrt / d->n are ignored) and one
+ * stpde_adam_chunk per block of work: elements [offset, offset + chunk_elems) of tensor `tensor`, offset % 4 == 0. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long n;
+  float step_size, bias2_sqrt;
+} stpde_adam_tensor;
+typedef struct {
+  int tensor, pad;
+  long offset;
+} stpde_adam_chunk;
+int stpde_clip_adam_multi(const stpde_adam_desc* d, const stpde_adam_tensor* tensors_dev,
+                          const stpde_adam_chunk* chunks_dev, int nchunks, int chunk_elems, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "stpde_conv3d_fwd": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),
     "stpde_conv3d_wgrad": ([C.POINTER(Conv3dDesc)] + [_VP] * 4, C.c_int),
     "stpde_clip_adam": ([C.POINTER(AdamDesc)] + [_VP] * 5, C.c_int),
+    "stpde_clip_adam_multi": ([C.POINTER(AdamDesc), _VP, _VP, C.c_int, C.c_int, _VP], C.c_int),
 }
 
 

@@ -49,6 +49,54 @@ __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
   }
 }
 
+// Multi-tensor variant: ONE launch updates every parameter tensor of the model.  Block b works on chunk b of the
+// chunk table (tensor index, element offset); the tensor table holds the four pointers, the length and the
+// bias-correction factors (tensors may have different step counts).
+__global__ __launch_bounds__(256) void k_clip_adam_multi(stpde_adam_desc d, const stpde_adam_tensor* tensors,
+                                                         const stpde_adam_chunk* chunks, int chunk_elems) {
+  const stpde_adam_chunk c = chunks[blockIdx.x];
+  const stpde_adam_tensor t = tensors[c.tensor];
+  d.step_size = t.step_size;
+  d.bias2_sqrt = t.bias2_sqrt;
+  const long lo = c.offset;
+  const long hi = lo + chunk_elems < t.n ? lo + chunk_elems : t.n;
+  const long n4 = (hi - lo) / 4;           // offsets are multiples of 4 and the pointers 16-byte aligned
+  for (long i = threadIdx.x; i < n4; i += 256) {
+    const long e = lo + 4 * i;
+    f32x4 p = ld4(t.p + e), g = ld4(t.g + e), m = ld4(t.m + e), v = ld4(t.v + e);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pp = p[r], mm = m[r], vv = v[r];
+      adam_elem(d, pp, g[r], mm, vv);
+      p[r] = pp;
+      m[r] = mm;
+      v[r] = vv;
+    }
+    st4(t.p + e, p);
+    st4(t.m + e, m);
+    st4(t.v + e, v);
+  }
+  const long e = lo + 4 * n4 + threadIdx.x;
+  if (e < hi) {
+    float pp = t.p[e], mm = t.m[e], vv = t.v[e];
+    adam_elem(d, pp, t.g[e], mm, vv);
+    t.p[e] = pp;
+    t.m[e] = mm;
+    t.v[e] = vv;
+  }
+}
+
+extern "C" int stpde_clip_adam_multi(const stpde_adam_desc* d, const stpde_adam_tensor* tensors_dev,
+                                     const stpde_adam_chunk* chunks_dev, int nchunks, int chunk_elems, void* stream) {
+  if (!d || !tensors_dev || !chunks_dev || nchunks <= 0 || chunk_elems <= 0 || (chunk_elems & 3)) {
+    stpde_set_error("clip_adam_multi: bad argument (chunk_elems must be a positive multiple of 4)");
+    return STPDE_E_BADARG;
+  }
+  STPDE_LAUNCH(k_clip_adam_multi, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, *d, tensors_dev,
+               chunks_dev, chunk_elems);
+  return stpde_check_launch("k_clip_adam_multi");
+}
+
 extern "C" int stpde_clip_adam(const stpde_adam_desc* d, float* param, const float* grad, float* exp_avg,
                                float* exp_avg_sq, void* stream) {
   if (!d || d->n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !(d->bias2_sqrt > 0.f)) {

@@ -1,16 +1,22 @@
 """Fused gradient-value clipping + Adam.
 
-``FusedClipAdam`` is a ``torch.optim.Optimizer`` whose ``step()`` does, per parameter tensor, in ONE HIP kernel
-(``stpde_clip_adam``) what the reference does with ``clip_grad_value_`` followed by ``optim.Adam.step``
+``FusedClipAdam`` is a ``torch.optim.Optimizer`` whose ``step()`` does, for ALL parameter tensors of a group in ONE HIP
+kernel launch (``stpde_clip_adam_multi``; ``stpde_clip_adam`` is the single-tensor entry point), what the reference does with ``clip_grad_value_`` followed by ``optim.Adam.step``
 (experiments/rb2d/train.py:79-83): same state names (``step``, ``exp_avg``, ``exp_avg_sq``), so
 ``state_dict()`` / ``load_state_dict()`` interoperate with ``torch.optim.Adam`` checkpoints written by the reference.
 """
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
+
+_CHUNK = 1 << 16     # elements per block of the multi-tensor kernel
+_TENSOR_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("step_size", "<f4"),
+                      ("bias2_sqrt", "<f4")])      # = stpde_adam_tensor
+_CHUNK_DT = np.dtype([("tensor", "<i4"), ("pad", "<i4"), ("offset", "<i8")])   # = stpde_adam_chunk
 
 
 class FusedClipAdam(torch.optim.Optimizer):
@@ -25,9 +31,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = None
+        L = _lib.lib()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            rows, chunks, keep = [], [], []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -40,15 +47,27 @@ class FusedClipAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 t = float(st["step"])
-                d = _lib.AdamDesc()
-                d.n = p.numel()
-                d.clip, d.beta1, d.beta2, d.eps = float(group["clip_grad"] or 0.0), b1, b2, group["eps"]
-                d.weight_decay = group["weight_decay"]
-                d.step_size = group["lr"] / (1.0 - b1 ** t)
-                d.bias2_sqrt = math.sqrt(1.0 - b2 ** t)
-                if L is None:
-                    L = _lib.lib()
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _lib.check(L.stpde_clip_adam(C.byref(d), _lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]),
-                                             _lib.ptr(st["exp_avg_sq"]), _lib.stream_ptr()))
+                keep.append(g)
+                ptrs = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+                if any(q & 15 for q in ptrs):
+                    raise RuntimeError("FusedClipAdam needs 16-byte aligned tensors")
+                n = p.numel()
+                for off in range(0, n, _CHUNK):
+                    chunks.append((len(rows), 0, off))
+                rows.append(ptrs + (n, group["lr"] / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)))
+            if not rows:
+                continue
+            dev = group["params"][0].device
+            # ONE launch for the whole group: tensor table + chunk table (a few KB) are uploaded per step
+            tab = torch.from_numpy(np.array(rows, dtype=_TENSOR_DT).view(np.uint8)).to(dev)
+            chk = torch.from_numpy(np.array(chunks, dtype=_CHUNK_DT).view(np.uint8)).to(dev)
+            d = _lib.AdamDesc()
+            d.n = 0
+            d.clip, d.beta1, d.beta2, d.eps = float(group["clip_grad"] or 0.0), b1, b2, group["eps"]
+            d.weight_decay, d.step_size, d.bias2_sqrt = group["weight_decay"], 0.0, 1.0
+            _lib.check(L.stpde_clip_adam_multi(C.byref(d), _lib.ptr(tab), _lib.ptr(chk), len(chunks), _CHUNK,
+                                               _lib.stream_ptr()))
+            tab.record_stream(torch.cuda.current_stream())
+            chk.record_stream(torch.cuda.current_stream())
         return loss
