@@ -271,6 +271,144 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Narrow layers (MT <= 4 output tiles, KT = 2 / 4 / 8 hidden k-tiles: fc3..fc5 of the reference IM-NET): per-wave
+// variant.  The cooperative kernel above keeps one 8-wave workgroup per CU (its ring takes most of the LDS) and pays
+// one barrier + one exposed HBM latency per row tile, which is all there is when a tile carries only a few hundred
+// MFMAs; here every wave owns whole row tiles (MCW output tiles x all KT + XT k-tiles), transposes its operands through
+// a private 2.5 KB patch with wave-local barriers only, and 3-4 waves per SIMD overlap each other's latencies.  The
+// four waves of a block are summed through LDS before the atomics.
+// ------------------------------------------------------------------------------------------------------------
+template <int S1, int S2, int ACT, int MCW, int KTT>
+__global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
+  constexpr int S = 1 + S1 + S2, NK = KTT + XT;
+  __shared__ __attribute__((aligned(16))) float pp[4][2][TBLK];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int lo = lane * 4;
+  const int MT = a.MT;
+  const int mt0 = blockIdx.y * MCW;
+  const int g = lane >> 4, c = lane & 15;
+
+  f32x4 acc[MCW][NK];
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+    for (int ki = 0; ki < NK; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int flip = 0;
+  auto transpose = [&](f32x4 v) -> f32x4 {   // column-major image -> row-major image (alternating patches)
+    float* patch = pp[wv][flip];
+    flip ^= 1;
+    lds_put_T(patch, lane, v);
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 r = lds_get_R(patch, lane);
+    __builtin_amdgcn_wave_barrier();
+    return r;
+  };
+
+#pragma unroll 1
+  for (int tile = blockIdx.x * 4 + wv; tile < a.ntiles; tile += gridDim.x * 4) {
+    float cq[6];
+    load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
+    f32x4 pa[S][MCW];
+    {
+      const float* pbase = a.P + (size_t)tile * S * MT * 256 + lo;
+      f32x4 raw[S][MCW];
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) {
+          const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
+          raw[st][mi] = ld4(pbase + ((size_t)st * MT + mt) * 256);
+        }
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(raw[st][mi]);
+    }
+    const float* qbase = a.Q + (size_t)tile * S * KTT * 256 + lo;
+#pragma unroll
+    for (int ki = 0; ki < KTT; ++ki) {
+      f32x4 pre[S], H[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) pre[st] = ld4(qbase + ((size_t)st * KTT + ki) * 256);
+      act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        const f32x4 hr = transpose(H[st]);
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ki] = mfma4(pa[st][mi][r], hr[r], acc[mi][ki]);
+      }
+    }
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+      const f32x4 xr = ld4(a.XR + ((size_t)tile * XT + xt) * 256 + lo);   // already the row-major image
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][KTT + xt] = mfma4(pa[0][mi][r], xr[r], acc[mi][KTT + xt]);
+      if (S1 == 3 && xt == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float u = c == d ? 1.f : 0.f;     // tangent stream d sees the unit vector e_d
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][KTT] = mfma4(pa[1 + d][mi][r], u, acc[mi][KTT]);
+        }
+      }
+    }
+  }
+
+  // block reduction (4 waves) through the patches, then one set of atomics per block
+  float* red = &pp[0][0][0];        // 4 x 256 floats needed, 8 x 320 available
+  const int ldw = 16 * (KTT + XT);
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+    for (int ki = 0; ki < NK; ++ki) {
+      __syncthreads();
+      st4(red + wv * 256 + lo, acc[mi][ki]);
+      __syncthreads();
+      const int mt = mt0 + mi;
+      if (mt >= MT) continue;      // block-uniform
+      const float sum = (red[lo + wv] + red[256 + lo + wv]) + (red[512 + lo + wv] + red[768 + lo + wv]);
+      atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + wv) * ldw + 16 * ki + c, sum);
+    }
+}
+
+template <int S1, int S2, int ACT, int MCW, int KTT>
+static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
+  const int gy = (a.MT + MCW - 1) / MCW;
+  int gx = 768 / gy;                       // ~3 waves per SIMD over the chip
+  if (gx > (a.ntiles + 3) / 4) gx = (a.ntiles + 3) / 4;
+  if (gx < 1) gx = 1;
+  STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT>), dim3(gx, gy), dim3(256), 0, stream, a);
+  return stpde_check_launch("k_wgrad_wave");
+}
+
+// returns -1 when the shape is not served by the per-wave kernel
+template <int S1, int S2, int ACT>
+static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
+  if (a.MT > 4 || a.SP != 1 + S1 + S2 || a.bf16) return -1;
+  if constexpr (S1 + S2 > 5) {
+    return -1;                             // S = 10: the accumulators + operands would not fit the register file
+  } else {
+    if (a.MT == 1) {
+      if (a.KT == 2) return launch_wgrad_wave<S1, S2, ACT, 1, 2>(a, stream);
+      if (a.KT == 4) return launch_wgrad_wave<S1, S2, ACT, 1, 4>(a, stream);
+    } else {
+      if (a.KT == 2) return launch_wgrad_wave<S1, S2, ACT, 2, 2>(a, stream);
+      if (a.KT == 4) return launch_wgrad_wave<S1, S2, ACT, 2, 4>(a, stream);
+      if (a.KT == 8) return launch_wgrad_wave<S1, S2, ACT, 2, 8>(a, stream);
+    }
+    return -1;
+  }
+}
+
 template <int S1, int S2, int MODE, int ACT, int KC>
 static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   WgradArgs a = a0;
@@ -308,6 +446,10 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
 
 template <int S1, int S2, int MODE, int ACT>
 static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
+  if constexpr (MODE == 0) {
+    const int rc = try_wgrad_wave<S1, S2, ACT>(a, stream);
+    if (rc >= 0) return rc;
+  }
   if (a.MT >= 16) return launch_wgrad_kc<S1, S2, MODE, ACT, 8>(a, stream);
   if constexpr (MODE == 1) {
     return launch_wgrad_kc<S1, S2, MODE, ACT, 4>(a, stream);   // the first hidden layer is never narrower than 8 tiles
