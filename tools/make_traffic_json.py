@@ -19,6 +19,8 @@ def parse(path):
 
 
 def bench_name(sym):
+    if re.match(r"k_\w+<0,0,", sym):      # value-only kernels of bench.py's inference side figure, not the training step
+        return None
     m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?>", sym)
     if m and m.group(8) in (None, "false"):
         pro, epi = int(m.group(4)), int(m.group(5))
@@ -27,6 +29,9 @@ def bench_name(sym):
         if epi == 2:
             return "layer1_dgrad"
         return "layer2_fwd" if epi == 0 else "layer2_dgrad"
+    m = re.match(r"k_layer_coop2<(\d+),(\d+),(\d+),(\d+),(-?\d+)>", sym)
+    if m:
+        return {2: "layer1_dgrad", 1: "layer2_dgrad"}.get(int(m.group(4)))
     m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+?)(?:,(\w+))?>", sym)
     if m and int(m.group(3)) == 1 and m.group(6) == "false" and m.group(7) in (None, "false"):
         return "layer1_wgrad"
