@@ -178,6 +178,33 @@ int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_
 /* dW[tap][Co][Ci] += sum_voxels ybar[v][co] * x[v + offset(tap)][ci]  (fp32 atomics; caller zero-fills dW). */
 int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, void* stream);
 
+/* ---- a7/a8/a9: PDE residuals from the jet streams ---------------------------------------------------
+ * Replaces the elementwise algebra that src/pde.py:115-143 evaluates through the lambdified equation strings once the
+ * derivatives are known (e.g. the four Rayleigh-Benard residuals of experiments/rb2d/physics.py:26-57), and its
+ * autograd backward.  The host compiles every equation into ONE straight-line program in SSA form: instruction i
+ * produces value i from earlier values a, b (indices < i):
+ *   JET   value = jets[a * ld_stream + b * ld_channel + p]   (a = stream, b = output channel)
+ *   X     value = x[p][a]            CONST value = c
+ *   ADD SUB MUL DIV (a, b)   NEG (a)   POWI value = v[a]^b (integer b)   SIN COS EXP LOG SQRT TANH ABS (a)
+ *   OUT   residual b of the point = v[a]
+ * res [n_eq][P]; the adjoint adds d loss / d jets into jets_bar (same layout as jets, zero-filled by the caller).
+ * The coordinates x are not differentiated here (the jets already are the coordinate derivatives). */
+#define STPDE_RES_MAX_INS 192
+enum {
+  STPDE_RES_JET = 0, STPDE_RES_X, STPDE_RES_CONST, STPDE_RES_ADD, STPDE_RES_SUB, STPDE_RES_MUL, STPDE_RES_DIV,
+  STPDE_RES_NEG, STPDE_RES_POWI, STPDE_RES_SIN, STPDE_RES_COS, STPDE_RES_EXP, STPDE_RES_LOG, STPDE_RES_SQRT,
+  STPDE_RES_TANH, STPDE_RES_ABS, STPDE_RES_OUT
+};
+typedef struct {
+  int op, a, b;
+  float c;
+} stpde_res_ins;
+int stpde_residual_fwd(const stpde_res_ins* prog_dev, int nins, int n_eq, int n_out, int P, const float* jets,
+                       long ld_stream, long ld_channel, const float* x /* [P][3] or NULL */, float* res, void* stream);
+int stpde_residual_bwd(const stpde_res_ins* prog_dev, int nins, int n_eq, int n_out, int P, const float* jets,
+                       long ld_stream, long ld_channel, const float* x, const float* res_bar, float* jets_bar,
+                       void* stream);
+
 /* ---- N1: train-step tail -- gradient value clipping + Adam in one pass ---------------------------------
  * Replaces torch.nn.utils.clip_grad_value_ + optim.Adam.step of experiments/rb2d/train.py:79-83 for one
  * parameter tensor (fp32, 16-byte aligned).  g = clamp(grad, +-clip) (clip <= 0: off); m, v, p are updated in

@@ -16,12 +16,16 @@ Two evaluation strategies:
   elementwise algebra on them.  If the forward method is anything else (or post-processes the query result) the
   generic strategy is used, exactly like the reference.
 """
+import ctypes as C
+
+import numpy as np
 import sympy
 import torch
 from sympy.core.function import AppliedUndef
 from sympy.parsing.sympy_parser import parse_expr
 from torch.autograd import grad
 
+from . import _lib
 from . import local_implicit_grid as _lig
 
 
@@ -44,6 +48,131 @@ class _JetProgram:
         self.syms = syms      # {atom key: sympy Dummy}
 
 
+# ---- residual programs for the HIP evaluator (stpde_residual_fwd / _bwd) ---------------------------------------
+_RES_OPS = {"JET": 0, "X": 1, "CONST": 2, "ADD": 3, "SUB": 4, "MUL": 5, "DIV": 6, "NEG": 7, "POWI": 8, "SIN": 9, "COS": 10,
+            "EXP": 11, "LOG": 12, "SQRT": 13, "TANH": 14, "ABS": 15, "OUT": 16}
+_RES_UNARY = {sympy.sin: "SIN", sympy.cos: "COS", sympy.exp: "EXP", sympy.log: "LOG", sympy.tanh: "TANH",
+              sympy.Abs: "ABS"}
+_RES_MAX_INS = 192      # STPDE_RES_MAX_INS
+_RES_DT = np.dtype([("op", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<f4")])   # = stpde_res_ins
+
+
+class _Unsupported(Exception):
+    pass
+
+
+def _compile_residual_program(exprs, in_vars, sym_to_slot):
+    """Straight-line SSA program (common sub-expressions shared) for a list of sympy expressions.
+
+    sym_to_slot: {sympy symbol: (stream, channel)} for the jet atoms.  Returns (numpy program, uses_x) or None when
+    an expression contains something the device evaluator does not implement."""
+    ins, memo, uses_x = [], {}, [False]
+
+    def emit(op, a=0, b=0, c=0.0):
+        ins.append((_RES_OPS[op], int(a), int(b), float(c)))
+        return len(ins) - 1
+
+    def rec(e):
+        if e in memo:
+            return memo[e]
+        if e.is_Symbol:
+            if e in sym_to_slot:
+                idx = emit("JET", *sym_to_slot[e])
+            elif e in in_vars:
+                uses_x[0] = True
+                idx = emit("X", in_vars.index(e))
+            else:
+                raise _Unsupported(e)
+        elif e.is_Number:
+            if not e.is_real or not e.is_finite:
+                raise _Unsupported(e)
+            idx = emit("CONST", c=float(e))
+        elif e.is_Add:
+            terms = list(e.args)
+            pos = [t for t in terms if not t.could_extract_minus_sign()] or [terms[0]]
+            first = pos[0]
+            idx = rec(first)
+            for t in terms:
+                if t is first:
+                    continue
+                if t.could_extract_minus_sign():
+                    idx = emit("SUB", idx, rec(-t))
+                else:
+                    idx = emit("ADD", idx, rec(t))
+        elif e.is_Mul:
+            c, rest = e.as_coeff_Mul()
+            if c == -1:
+                idx = emit("NEG", rec(rest))
+            else:
+                num, den = [], []
+                for f in e.args:
+                    if f.is_Pow and f.args[1].is_Integer and f.args[1] < 0:
+                        den.append(sympy.Pow(f.args[0], -f.args[1]))
+                    else:
+                        num.append(f)
+                idx = rec(num[0]) if num else emit("CONST", c=1.0)
+                for f in num[1:]:
+                    idx = emit("MUL", idx, rec(f))
+                for f in den:
+                    idx = emit("DIV", idx, rec(f))
+        elif e.is_Pow:
+            base, ex = e.args
+            if ex.is_Integer:
+                idx = emit("POWI", rec(base), int(ex))
+            elif ex == sympy.Rational(1, 2):
+                idx = emit("SQRT", rec(base))
+            elif ex == -sympy.Rational(1, 2):
+                idx = emit("DIV", emit("CONST", c=1.0), emit("SQRT", rec(base)))
+            else:
+                raise _Unsupported(e)
+        elif e.func in _RES_UNARY and len(e.args) == 1:
+            idx = emit(_RES_UNARY[e.func], rec(e.args[0]))
+        else:
+            raise _Unsupported(e)
+        memo[e] = idx
+        return idx
+
+    try:
+        for k, e in enumerate(exprs):
+            emit("OUT", rec(sympy.sympify(e)), k)
+    except _Unsupported:
+        return None
+    if len(ins) > _RES_MAX_INS:
+        return None
+    return np.array(ins, dtype=_RES_DT), uses_x[0]
+
+
+class _ResidualHip(torch.autograd.Function):
+    """res[n_eq, P] = program(jets[S, n_out, P], x[P, 3]); backward returns d loss / d jets."""
+
+    @staticmethod
+    def forward(ctx, jets, x2d, prog_t, nins, n_eq):
+        L = _lib.lib()
+        jets = jets if jets.stride(2) == 1 and jets.stride(1) >= jets.shape[2] else jets.contiguous()
+        P, n_out = jets.shape[2], jets.shape[1]
+        res = torch.empty(n_eq, P, device=jets.device, dtype=torch.float32)
+        _lib.check(L.stpde_residual_fwd(_lib.ptr(prog_t), nins, n_eq, n_out, P, _lib.ptr(jets), jets.stride(0),
+                                        jets.stride(1), _lib.ptr(x2d), _lib.ptr(res), _lib.stream_ptr()))
+        ctx.save_for_backward(jets, x2d, prog_t)
+        ctx.meta = (nins, n_eq)
+        return res
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gres):
+        L = _lib.lib()
+        jets, x2d, prog_t = ctx.saved_tensors
+        nins, n_eq = ctx.meta
+        P, n_out = jets.shape[2], jets.shape[1]
+        jbar = torch.zeros_like(jets)      # preserves the strides of jets (dense or sliced-contiguous)
+        if jbar.stride() != jets.stride():
+            raise RuntimeError("residual backward: unexpected jets layout")
+        _lib.check(L.stpde_residual_bwd(_lib.ptr(prog_t), nins, n_eq, n_out, P, _lib.ptr(jets), jets.stride(0),
+                                        jets.stride(1), _lib.ptr(x2d), _lib.ptr(gres.contiguous()), _lib.ptr(jbar),
+                                        _lib.stream_ptr()))
+        return jbar, None, None, None, None
+
+
 class PDELayer(object):
     """PDE Layer for querying values and computing PDE residues."""
 
@@ -62,6 +191,7 @@ class PDELayer(object):
         self.eqns_fn = {}    # lambda functions (generic autograd strategy)
         self.eqns_jet = {}   # _JetProgram or None per equation
         self._combo = False  # lazily built combined-second-order plan (False = not built yet)
+        self._res_progs = {}  # {(stream layout key): compiled device residual program or None}
         self.forward_method = None
 
     # ------------------------------------------------------------------------------------------------
@@ -88,6 +218,7 @@ class PDELayer(object):
         self.eqns_fn.update({eqn_name: fn})
         self.eqns_jet.update({eqn_name: self._compile_jet(expr)})
         self._combo = False   # combined-second-order plan is rebuilt lazily
+        self._res_progs = {}
 
     def _combo_plan(self):
         """If every equation is LINEAR in the second derivatives and uses them only through one common combination
@@ -144,7 +275,7 @@ class PDELayer(object):
                         [((c, ("L",)), v) for c, v in lam.items()]
                 atoms.sort(key=lambda a: (a[0][0], len(a[0][1]), str(a[0][1])))
                 fn = sympy.lambdify(list(self.in_vars) + [a[1] for a in atoms], e, [_TORCH_FUNCS])
-                new[name] = _JetProgram(fn, [a[0] for a in atoms])
+                new[name] = _JetProgram(fn, [a[0] for a in atoms], e, {a[0]: a[1] for a in atoms})
             self._combo = dict(alpha=alpha, progs=new)
         except Exception:   # any sympy corner case -> one stream per pair (never wrong, only slower)
             self._combo = None
@@ -239,6 +370,9 @@ class PDELayer(object):
         else:
             for k, p in enumerate(pairs):
                 stream_of.setdefault(tuple(p), 4 + k)
+        hip = self._residues_hip(x, jets, progs, stream_of, shape)
+        if hip is not None:
+            return hip
         cols = [x[..., i:i + 1] for i in range(self.n_in)]
         cache = {}
 
@@ -248,6 +382,31 @@ class PDELayer(object):
             return cache[key]
 
         return {name: prog.fn(*(cols + [atom(k) for k in prog.atoms])) for name, prog in progs.items()}
+
+    def _residues_hip(self, x, jets, progs, stream_of, shape):
+        """All residuals of all equations in ONE HIP kernel (and one for the backward) instead of ~100 elementwise
+        torch kernels; None when an equation uses something the device evaluator does not implement."""
+        if not (jets.is_cuda and jets.dtype == torch.float32 and all(p.expr is not None for p in progs.values())):
+            return None
+        key = (tuple(sorted((str(k), v) for k, v in stream_of.items())), str(jets.device))
+        ent = self._res_progs.get(key, False)
+        if ent is False:
+            slots = {}
+            for prog in progs.values():
+                for akey, sym in prog.syms.items():
+                    slots[sym] = (stream_of[akey[1]], akey[0])
+            comp = _compile_residual_program([p.expr for p in progs.values()], list(self.in_vars), slots)
+            ent = None
+            if comp is not None:
+                arr, uses_x = comp
+                ent = (torch.from_numpy(arr.view(np.uint8).copy()).to(jets.device), len(arr), uses_x)
+            self._res_progs[key] = ent
+        if ent is None:
+            return None
+        prog_t, nins, uses_x = ent
+        x2d = x.detach().reshape(-1, self.n_in).contiguous().float() if uses_x else None
+        res = _ResidualHip.apply(jets, x2d, prog_t, nins, len(progs))
+        return {name: res[k].reshape(shape) for k, name in enumerate(progs)}
 
     def __call__(self, x, return_residue=True):
         """y = forward(x) and, optionally, the residue of every equation (reference :115-143)."""
