@@ -205,6 +205,17 @@ int stpde_residual_bwd(const stpde_res_ins* prog_dev, int nins, int n_eq, int n_
                        long ld_stream, long ld_channel, const float* x, const float* res_bar, float* jets_bar,
                        void* stream);
 
+/* ---- a11: loss reductions of the train step (experiments/rb2d/train.py:69-76) -------------------------------
+ * out_sum += sum_i f(a[i] - b[i]) with f = |d| (L1), d^2 (L2) or smooth-l1 with beta 1 (b == NULL: against 0);
+ * a SUM, not a mean: the caller divides by the GLOBAL element count (point-sharded multi-GPU step).  The caller
+ * zero-fills out_sum.  stpde_loss_grad writes grad_a[i] = *grad_sum_dev * f'(a[i] - b[i]) (sign(0) = 0 like torch). */
+#define STPDE_LOSS_L1 0
+#define STPDE_LOSS_L2 1
+#define STPDE_LOSS_HUBER 2
+int stpde_loss_sum(int kind, long n, const float* a, const float* b, float* out_sum, void* stream);
+int stpde_loss_grad(int kind, long n, const float* a, const float* b, const float* grad_sum_dev, float* grad_a,
+                    void* stream);
+
 /* ---- N1: train-step tail -- gradient value clipping + Adam in one pass ---------------------------------
  * Replaces torch.nn.utils.clip_grad_value_ + optim.Adam.step of experiments/rb2d/train.py:79-83 for one
  * parameter tensor (fp32, 16-byte aligned).  g = clamp(grad, +-clip) (clip <= 0: off); m, v, p are updated in

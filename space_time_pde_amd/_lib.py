@@ -115,6 +115,8 @@ _SIGNATURES = {
     "stpde_residual_fwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_residual_bwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP],
                            C.c_int),
+    "stpde_loss_sum": ([C.c_int, C.c_long, _VP, _VP, _VP, _VP], C.c_int),
+    "stpde_loss_grad": ([C.c_int, C.c_long, _VP, _VP, _VP, _VP, _VP], C.c_int),
     "stpde_clip_adam": ([C.POINTER(AdamDesc)] + [_VP] * 5, C.c_int),
     "stpde_clip_adam_multi": ([C.POINTER(AdamDesc), _VP, _VP, C.c_int, C.c_int, _VP], C.c_int),
 }

@@ -138,3 +138,70 @@ extern "C" int stpde_residual_bwd(const stpde_res_ins* prog_dev, int nins, int n
   STPDE_LAUNCH(k_residual_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_residual_bwd");
 }
+
+// ---- loss reductions of the train step (experiments/rb2d/train.py:69-76: l1 / mse / smooth_l1 of prediction vs target
+// and of the stacked residuals vs 0), as SUMS (the caller divides by the global element count, so that the same code
+// serves the point-sharded multi-GPU step).  One pass, block reduction, one atomic per block.
+struct LossArgs {
+  int kind;
+  long n;
+  const float* a;
+  const float* b;      // null: compare against 0
+  float* out;          // forward: scalar accumulator (zero-filled by the caller)
+  const float* gscale; // backward: device scalar = d loss / d sum
+  float* ga;           // backward: d loss / d a
+};
+
+__device__ __forceinline__ float loss_elem(int kind, float d) {
+  const float ad = fabsf(d);
+  if (kind == STPDE_LOSS_L1) return ad;
+  if (kind == STPDE_LOSS_L2) return d * d;
+  return ad < 1.f ? 0.5f * d * d : ad - 0.5f;          // smooth_l1, beta = 1 (torch default)
+}
+__device__ __forceinline__ float loss_grad(int kind, float d) {
+  if (kind == STPDE_LOSS_L1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  if (kind == STPDE_LOSS_L2) return 2.f * d;
+  return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+}
+
+__global__ __launch_bounds__(256) void k_loss_sum(LossArgs a) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256)
+    s += loss_elem(a.kind, a.a[i] - (a.b ? a.b[i] : 0.f));
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(a.out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(256) void k_loss_grad(LossArgs a) {
+  const float g = *a.gscale;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256)
+    a.ga[i] = g * loss_grad(a.kind, a.a[i] - (a.b ? a.b[i] : 0.f));
+}
+
+extern "C" int stpde_loss_sum(int kind, long n, const float* a, const float* b, float* out_sum, void* stream) {
+  if (kind < 0 || kind > 2 || n <= 0 || !a || !out_sum) {
+    stpde_set_error("loss_sum: bad argument");
+    return STPDE_E_BADARG;
+  }
+  LossArgs args{kind, n, a, b, out_sum, nullptr, nullptr};
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  STPDE_LAUNCH(k_loss_sum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, args);
+  return stpde_check_launch("k_loss_sum");
+}
+
+extern "C" int stpde_loss_grad(int kind, long n, const float* a, const float* b, const float* grad_sum_dev,
+                               float* grad_a, void* stream) {
+  if (kind < 0 || kind > 2 || n <= 0 || !a || !grad_sum_dev || !grad_a) {
+    stpde_set_error("loss_grad: bad argument");
+    return STPDE_E_BADARG;
+  }
+  LossArgs args{kind, n, a, b, nullptr, grad_sum_dev, grad_a};
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  STPDE_LAUNCH(k_loss_grad, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, args);
+  return stpde_check_launch("k_loss_grad");
+}

@@ -36,6 +36,43 @@ _LOSS_SUMS = {
     "l2": lambda a, b: ((a - b) ** 2).sum(),
     "huber": lambda a, b: F.smooth_l1_loss(a, b, reduction="sum"),
 }
+_LOSS_KIND = {"l1": 0, "l2": 1, "huber": 2}
+
+
+class _LossSumHip(torch.autograd.Function):
+    """sum_i f(a_i - b_i) (b None: against zero) in one HIP pass; backward = one elementwise pass (stpde_loss_sum /
+    stpde_loss_grad).  Replaces sub + abs + sum (+ zeros_like, stack) and their backward kernels of train.py:69-76."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind):
+        from . import _lib
+        L = _lib.lib()
+        a = a.contiguous()
+        b = b.contiguous() if b is not None else None
+        out = torch.zeros((), device=a.device, dtype=torch.float32)
+        _lib.check(L.stpde_loss_sum(kind, a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(a, b)
+        ctx.kind = kind
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib
+        L = _lib.lib()
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        _lib.check(L.stpde_loss_grad(ctx.kind, a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(g.contiguous().float()),
+                                     _lib.ptr(ga), _lib.stream_ptr()))
+        return ga, None, None
+
+
+def loss_sum(a, b, loss_type):
+    """Sum-reduced loss of a against b (None = zero): HIP kernels on CUDA fp32 tensors, torch ops otherwise."""
+    if a.is_cuda and a.dtype == torch.float32 and (b is None or (b.dtype == torch.float32 and b.shape == a.shape)) \
+            and not (b is not None and b.requires_grad):
+        return _LossSumHip.apply(a, b, _LOSS_KIND[loss_type])
+    return _LOSS_SUMS[loss_type](a, torch.zeros_like(a) if b is None else b)
 
 
 def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n_points_global, alpha_reg=1.0,
@@ -48,16 +85,20 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
     """
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    lsum = _LOSS_SUMS[loss_type]
+    if loss_type not in _LOSS_SUMS:
+        raise KeyError(loss_type)
     latent_grid = unet(input_grid).permute(0, 2, 3, 4, 1)            # train.py:58-60
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)
     pde_layer.update_forward_method(lambda pts: query_local_implicit_grid(imnet, latent_grid, pts, xmin, xmax))
     pred, residues = pde_layer(point_coord, return_residue=True)    # train.py:66-67
     b = point_coord.shape[0]
-    reg = lsum(pred, point_value) / (b * n_points_global * pred.shape[-1])
-    stack = torch.stack(list(residues.values()), dim=0)
-    pde = lsum(stack, torch.zeros_like(stack)) / (stack.shape[0] * b * n_points_global)
+    reg = loss_sum(pred, point_value, loss_type) / (b * n_points_global * pred.shape[-1])
+    res = list(residues.values())
+    # the residuals of the HIP evaluator are rows of ONE [n_eq, P] tensor: reduce it in place of a stacked copy
+    base = res[0]._base if all(r._base is not None and r._base is res[0]._base for r in res) else None
+    stack = base if (base is not None and base.numel() == sum(r.numel() for r in res)) else torch.stack(res, dim=0)
+    pde = loss_sum(stack, None, loss_type) / (len(res) * b * n_points_global)
     loss = alpha_reg * reg + alpha_pde * pde
     loss.backward()
     if distributed:

@@ -116,3 +116,23 @@ def test_residual_kernels_match_torch_path(hiplib, which):
     for k in res:
         assert torch.allclose(res[k], ref[k], rtol=2e-5, atol=2e-5), k
     assert torch.allclose(got_bar, jets.grad, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["l1", "l2", "huber"])
+@pytest.mark.parametrize("with_target", [True, False])
+def test_loss_sum_kernels_match_torch(hiplib, kind, with_target):
+    from space_time_pde_amd import train_step as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    a = (2.0 * torch.randn(3, 777, 4, generator=g)).to(dev).requires_grad_(True)
+    b = torch.randn(3, 777, 4, generator=g).to(dev) if with_target else None
+    w = torch.tensor(0.37, device=dev)
+    got = T.loss_sum(a, b, kind)
+    (w * got).backward()
+    ga = a.grad.clone()
+    a.grad = None
+    want = T._LOSS_SUMS[kind](a, b if with_target else torch.zeros_like(a))
+    (w * want).backward()
+    assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item())
+    assert torch.allclose(ga, a.grad, rtol=1e-6, atol=1e-7)
