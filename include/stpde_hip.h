@@ -178,6 +178,24 @@ int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_
 /* dW[tap][Co][Ci] += sum_voxels ybar[v][co] * x[v + offset(tap)][ci]  (fp32 atomics; caller zero-fills dW). */
 int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, void* stream);
 
+/* ---- a10: BatchNorm3d (+ residual add) (+ ReLU) of the ResBlock3D chain (src/unet3d.py:39-56) -------------
+ * Channels-last x [N][C], N = B*T*Z*X, C a power of two in [16, 512].
+ * forward:  y = act(bn(x) [+ residual]);  training != 0: batch statistics (biased variance for the normalisation,
+ *           running_mean / running_var updated in place with torch's momentum rule and the unbiased variance);
+ *           training == 0: running statistics.  sums: [3][C] scratch (training), stat: [2][C] receives mean, rstd.
+ * backward: dz = dy * [y > 0] (relu) ; dresidual = dz ; dx, dgamma, dbeta as torch's batch_norm backward
+ *           (training: with the batch-statistics terms, evaluation: without).  bsum: [2][C] scratch.
+ * Any of residual, gamma, beta, dx, dresidual, dgamma, dbeta may be NULL. */
+typedef struct {
+  long N;
+  int C, training, relu;
+  float eps, momentum;
+} stpde_bn_desc;
+int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float* residual, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float* sums, float* stat, float* y, void* stream);
+int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float* y, const float* dy, const float* gamma,
+                 const float* stat, float* bsum, float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream);
+
 /* ---- a7/a8/a9: PDE residuals from the jet streams ---------------------------------------------------
  * Replaces the elementwise algebra that src/pde.py:115-143 evaluates through the lambdified equation strings once the
  * derivatives are known (e.g. the four Rayleigh-Benard residuals of experiments/rb2d/physics.py:26-57), and its

@@ -5,9 +5,9 @@ On CUDA tensors every convolution (1x1x1 and 3x3x3) runs in the HIP implicit-GEM
 (``stpde_conv3d_fwd`` for forward and input-gradient, ``stpde_conv3d_wgrad`` for the weight gradient) on
 channels-last activations [B, T, Z, X, C]; the network output is returned as a channels-last *view* of logical
 shape [B, C, T, Z, X], so the ``latent_grid.permute(0, 2, 3, 4, 1)`` of experiments/rb2d/train.py:60 is a free
-contiguous view that feeds the local-implicit-grid kernels directly.  BatchNorm / ReLU / pooling / nearest
-upsampling / concatenation are elementwise-or-copy plumbing done with torch ops on the same layout (they are
-<1% of the step; fusing them into the conv epilogues is listed as next work in DESIGN.md).
+contiguous view that feeds the local-implicit-grid kernels directly.  BatchNorm (+ residual add) (+ ReLU) run in the
+fused HIP kernels ``stpde_bn_fwd`` / ``stpde_bn_bwd``; pooling / nearest upsampling / concatenation are copy
+plumbing done with torch ops on the same layout.
 ``Encoder3d`` of the reference (src/unet3d.py:243-344) is dead code there and is not provided.
 """
 import ctypes as C
@@ -159,6 +159,75 @@ def _bn_cl(x, bn):
     return y.reshape(shp)
 
 
+class _BnActHip(torch.autograd.Function):
+    """y = act(batch_norm(x) [+ residual]) on channels-last x, one HIP pass for the statistics and one for the
+    normalisation (stpde_bn_fwd); backward = one reduction + one elementwise pass (stpde_bn_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        L = _lib.lib()
+        x = x.contiguous()
+        residual = residual.contiguous() if residual is not None else None
+        c = x.shape[-1]
+        d = _lib.BnDesc()
+        d.N, d.C, d.training, d.relu, d.eps, d.momentum = x.numel() // c, c, int(training), int(relu), eps, momentum
+        sums = torch.empty(3 * c, device=x.device) if training else None
+        stat = torch.empty(2 * c, device=x.device)
+        y = torch.empty_like(x)
+        _lib.check(L.stpde_bn_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(residual),
+                                  _lib.ptr(weight.detach() if weight is not None else None),
+                                  _lib.ptr(bias.detach() if bias is not None else None),
+                                  _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(sums), _lib.ptr(stat),
+                                  _lib.ptr(y), _lib.stream_ptr()))
+        ctx.save_for_backward(x, y if relu else None, weight, stat)
+        ctx.desc = (d.N, c, int(training), int(relu), eps, momentum)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x, y, weight, stat = ctx.saved_tensors
+        d = _lib.BnDesc()
+        d.N, d.C, d.training, d.relu, d.eps, d.momentum = ctx.desc
+        c = d.C
+        gy = gy.contiguous()
+        need_x, need_r, need_w, need_b = ctx.needs_input_grad[:4]
+        dx = torch.empty_like(x) if need_x else None
+        dr = torch.empty_like(x) if (ctx.has_res and need_r) else None
+        dw = torch.empty(c, device=x.device) if (weight is not None and need_w) else None
+        db = torch.empty(c, device=x.device) if need_b else None
+        bsum = torch.empty(2 * c, device=x.device)
+        _lib.check(L.stpde_bn_bwd(C.byref(d), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gy),
+                                  _lib.ptr(weight.detach() if weight is not None else None), _lib.ptr(stat),
+                                  _lib.ptr(bsum), _lib.ptr(dx), _lib.ptr(dr), _lib.ptr(dw), _lib.ptr(db),
+                                  _lib.stream_ptr()))
+        return dx, dr, dw, db, None, None, None, None, None, None
+
+
+def _bn_act(x, bn, relu, residual=None):
+    """act(bn(x) [+ residual]) with nn.BatchNorm3d semantics on channels-last data: the HIP kernels on CUDA tensors,
+    torch ops otherwise (CPU, exotic BatchNorm configurations)."""
+    c = x.shape[-1]
+    training = bn.training or not bn.track_running_stats
+    hip = (x.is_cuda and x.dtype == torch.float32 and 16 <= c <= 512 and (c & (c - 1)) == 0
+           and bn.momentum is not None and (training or bn.running_mean is not None)
+           and (bn.weight is None) == (bn.bias is None))
+    if not hip:
+        h = _bn_cl(x, bn)
+        if residual is not None:
+            h = h + residual
+        return F.relu(h) if relu else h
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None \
+            and not getattr(bn, "_stpde_counted", False):
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BnActHip.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps),
+                           bool(relu))
+
+
 def _pool_cl(x, kernel):
     if all(int(k) == 1 for k in kernel):
         return x
@@ -192,11 +261,10 @@ class ResBlock3D(nn.Module):
 
     def forward_cl(self, x):
         """Channels-last in, channels-last out: conv1-bn1-relu-conv2-bn2-relu-conv3-bn3 + shortcut (+relu)."""
-        h = F.relu(_bn_cl(_conv_cl(x, self.conv1), self.bn1))
-        h = F.relu(_bn_cl(_conv_cl(h, self.conv2), self.bn2))
-        h = _bn_cl(_conv_cl(h, self.conv3), self.bn3)
-        h = h + _conv_cl(x, self.shortcut)
-        return F.relu(h) if self.final_relu else h
+        h = _bn_act(_conv_cl(x, self.conv1), self.bn1, True)
+        h = _bn_act(_conv_cl(h, self.conv2), self.bn2, True)
+        # bn3 + shortcut + final ReLU in one pass
+        return _bn_act(_conv_cl(h, self.conv3), self.bn3, self.final_relu, residual=_conv_cl(x, self.shortcut))
 
     def forward(self, x):  # [B, C, T, Z, X] -> [B, C', T, Z, X] (channels-last view)
         h = self.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous())
