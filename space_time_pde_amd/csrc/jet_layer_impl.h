@@ -516,6 +516,9 @@ static int launch_fwd_act_mc(const LayerArgs& a, hipStream_t stream) {
 
 template <int S1, int S2, int PRO, int EPI>
 static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
+  // the two narrowest layers (fc4: 2 output tiles, fc5: 1): exact tile count and compile-time activation
+  if (a.MT == 2 && S1 + S2 <= 5) return launch_fwd_act_mc<S1, S2, PRO, EPI, 2>(a, stream);
+  if (a.MT == 1 && S1 + S2 <= 5) return launch_fwd_act_mc<S1, S2, PRO, EPI, 1>(a, stream);
   if (a.MT % 4 != 0) return launch_layer<S1, S2, 4, PRO, EPI, -1, true>(a, stream);
   // workgroup-cooperative variant: B operand produced once per 4 waves (S = 10 would not fit two workgroups of LDS)
   if (a.KT % 4 == 0 && a.KT >= 8 && S1 + S2 <= 5) {
