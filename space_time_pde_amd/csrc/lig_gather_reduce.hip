@@ -374,7 +374,25 @@ __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
     const int MT = a.d.MT[l], SP = a.d.SP[l];
     const float* ab = a.abar[l] + (size_t)tile * SP * MT * 256 + lo;  // stream 0
     const float* w = a.wst[l] + lo;
-    for (int mt = 0; mt < MT; ++mt) {
+    // two output tiles per iteration (MT is even for every hidden layer): their loads are issued together
+    for (int mt = 0; mt + 1 < MT; mt += 2) {
+      f32x4 B0 = ld4(ab + (size_t)mt * 256), B1 = ld4(ab + (size_t)(mt + 1) * 256);
+      f32x4 w0[XT], w1[XT];
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+        w0[xt] = ld4(w + ((size_t)mt * XT + xt) * 256);
+        w1[xt] = ld4(w + ((size_t)(mt + 1) * XT + xt) * 256);
+      }
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[xt] = mfma4(w0[xt][r], B0[r], acc[xt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[xt] = mfma4(w1[xt][r], B1[r], acc[xt]);
+      }
+    }
+    if (MT & 1) {
+      const int mt = MT - 1;
       f32x4 B = ld4(ab + (size_t)mt * 256);
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) {
