@@ -211,10 +211,12 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // BF: the hidden-to-hidden GEMM runs on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 in the produce stage /
 // the bf16 weight pack, fp32 accumulation); the ring then holds 8-byte bf16 fragments and one MFMA contracts over TWO
 // k-tiles.  Layer-0 regeneration, skip GEMM, activation jets and epilogues stay fp32.
-template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false>
+// PK (bf16 variant only): k-tiles produced per wave and group -- the bf16 MFMAs of a k-tile take 1/16 of the fp32
+// time, so twice the k-tiles per barrier halve the number of exposed load -> activation -> LDS -> barrier chains.
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1>
 __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
-  constexpr int S = 1 + S1 + S2;
-  __shared__ __attribute__((aligned(16))) float hb[2][NW][S][BF ? 128 : 256];
+  constexpr int S = 1 + S1 + S2, GK = NW * PK;
+  __shared__ __attribute__((aligned(16))) float hb[2][GK][S][BF ? 128 : 256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int KT = a.KT, MT = a.MT;
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   }
   const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
 
-  // produce the B block of k-tile kt (this wave's turn) into ring slot (buf, wv)
-  auto produce = [&](int kt, int buf) {
+  // produce the B block of k-tile kt (this wave's turn) into ring slot (buf, slot)
+  auto produce = [&](int kt, int buf, int slot) {
     f32x4 raw[S], B[S];
     if (PRO == PRO_L0) {
       raw[0] = layer0_block(a.W0s, KT, kt, lo, xb);
@@ -265,13 +267,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
     for (int st = 0; st < S; ++st) {
       if constexpr (BF)
-        *reinterpret_cast<bf16x4*>(&hb[buf][wv][st][lane * 2]) = to_bf4(B[st]);
+        *reinterpret_cast<bf16x4*>(&hb[buf][slot][st][lane * 2]) = to_bf4(B[st]);
       else
-        st4(&hb[buf][wv][st][lo], B[st]);
+        st4(&hb[buf][slot][st][lo], B[st]);
     }
   };
+  auto produce_group = [&](int g, int buf) {      // this wave's PK k-tiles of group g
+#pragma unroll
+    for (int k = 0; k < PK; ++k) produce(GK * g + NW * k + wv, buf, NW * k + wv);
+  };
 
-  const int ngroups = KT / NW;
+  const int ngroups = KT / GK;
   for (int mt0 = (pass0 * NW + wv) * MCg; mt0 < MT; mt0 += pstep * NW * MCg) {
     f32x4 acc[MCg][S];
 #pragma unroll
@@ -280,15 +286,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
     __syncthreads();              // ring free (previous pass fully consumed)
-    produce(wv, 0);
+    produce_group(0, 0);
     __syncthreads();
     for (int gi = 0; gi < ngroups; ++gi) {
       const int buf = gi & 1;
       if constexpr (BF) {
         const bf16x8* wp16 = reinterpret_cast<const bf16x8*>(a.Wp16) + (size_t)mt0 * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < NW / 2; ++q) {
-          const int kp = NW / 2 * gi + q;       // pair of k-tiles (2 kp, 2 kp + 1)
+        for (int q = 0; q < GK / 2; ++q) {
+          const int kp = GK / 2 * gi + q;       // pair of k-tiles (2 kp, 2 kp + 1)
           bf16x8 B8[S], w8[MCg];
 #pragma unroll
           for (int st = 0; st < S; ++st)
@@ -303,8 +309,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
         }
       } else {
 #pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const int kt = NW * gi + q;
+      for (int q = 0; q < GK; ++q) {
+        const int kt = GK * gi + q;
         f32x4 B[S], w[MCg];
 #pragma unroll
         for (int st = 0; st < S; ++st) B[st] = ld4(&hb[buf][q][st][lo]);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
-      produce(gi + 1 < ngroups ? NW * (gi + 1) + wv : NW * gi + wv, buf ^ 1);
+      produce_group(gi + 1 < ngroups ? gi + 1 : gi, buf ^ 1);
       __syncthreads();
     }
 #pragma unroll
@@ -476,7 +482,9 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
   a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
   const int nblocks = a.split ? (a.ntiles + 7) / 8 * 8 * a.split : a.ntiles;
-  if (a.Wp16)
+  if (a.Wp16 && a.KT % (2 * NW) == 0)
+    STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 2>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+  else if (a.Wp16)
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   else
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
