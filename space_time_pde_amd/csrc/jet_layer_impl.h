@@ -1,13 +1,14 @@
-// One IM-NET layer on all derivative streams, forward and input-gradient (dgrad), as a per-wave MFMA GEMM.
-//
-// Each wave owns one tile of 16 corner rows (2 query points x 8 corners) and MC output feature tiles, for all
-// S streams:   out^T[16*MC x 16] (per stream) = W[16*MC x K] * in^T[K x 16]
-// A operand = packed weights (one float4 per lane per (k-tile, m-tile) block = the 4 k-steps of the block),
-// B operand = the fragment block of the previous layer (C/D image == B image, so nothing is re-laid out),
-// accumulators = MC*S float4 per lane.  No LDS, no barriers: waves are independent and the weights stream
-// from L2 (every wave reads the same blocks).  The k-loop is software pipelined: the loads and the activation
-// jet of block kt+1 are issued while the MFMAs of block kt run.
-//
+// One IM-NET layer on all derivative streams, forward and input-gradient (dgrad), as MFMA GEMMs
+//   out^T[16*MT x 16 rows] (per stream) = W[16*MT x K] * in^T[K x 16 rows]
+// over row tiles of 16 corner rows (2 query points x 8 corners).  A operand = packed weights (one float4 per lane per
+// (k-tile, m-tile) block = the 4 k-steps of the block, streamed from L2), B operand = the fragment block of the
+// previous layer (C/D image == B image, so nothing is re-laid out), accumulators = float4 per (output tile, stream).
+// Kernel variants (dispatch at the bottom of this file):
+//   k_layer        per wave, no LDS / barriers: narrow layers (fewer than 8 output tiles) -- HBM-bound on the stash
+//   k_layer_coop   4 / 8 waves share ONE row tile and split its output tiles; the B operand of every k-tile (stash load
+//                  + activation jet, or layer-0 regeneration) is produced once per workgroup into a double-buffered
+//                  LDS ring; bf16-operand variant for BASELINE configs[3]
+//   k_layer_coop2  8 waves share TWO row tiles (dgrad of the widest layer)
 // Replaces (reference): src/implicit_net.py:48-54 on the rows of src/local_implicit_grid.py:53, and the reverse
 // sweeps of src/pde.py:8-9 (streams carry d/dr and d2/dr2 forward instead).
 #pragma once

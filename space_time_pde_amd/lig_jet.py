@@ -473,7 +473,7 @@ def activation_name(module):
     return None
 
 
-DEFAULT_CHUNK = 1 << 16   # query points per launch chunk (bounds the per-chunk backward scratch)
+DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
 
 # MFMA operand precision of the hidden-to-hidden GEMMs of the wide layers: "fp32" (exact-fp32 MFMA, the default and
 # the parity path) or "bf16" (BASELINE config 4: bf16 operands, fp32 accumulation, everything else fp32).
