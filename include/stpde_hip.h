@@ -196,6 +196,18 @@ int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float* residual, 
 int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float* y, const float* dy, const float* gamma,
                  const float* stat, float* bsum, float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream);
 
+/* ---- a10: max pooling / nearest up-sampling between the U-Net levels (src/unet3d.py:163-176, 216-238) ----------
+ * Channels-last [B][T][Z][X][C], C % 4 == 0.  The descriptor holds the dimensions of the SMALL tensor (pooled output /
+ * up-sampling input) and the integer factors (1..4) per dimension; the big tensor is [B][T*ft][Z*fz][X*fx][C].
+ * mode 0: max-pool forward (in = big, out = small)       mode 1: max-pool backward (in = d small, aux = forward
+ * input, out = d big; ties go to the first maximum of the window like torch)
+ * mode 2: nearest up-sampling forward (in = small, out = big)   mode 3: its backward (in = d big, out = d small). */
+typedef struct {
+  int B, T, Z, X, C, ft, fz, fx;
+} stpde_resample_desc;
+int stpde_resample3d(const stpde_resample_desc* d, int mode, const float* in, const float* aux, float* out,
+                     void* stream);
+
 /* ---- a7/a8/a9: PDE residuals from the jet streams ---------------------------------------------------
  * Replaces the elementwise algebra that src/pde.py:115-143 evaluates through the lambdified equation strings once the
  * derivatives are known (e.g. the four Rayleigh-Benard residuals of experiments/rb2d/physics.py:26-57), and its

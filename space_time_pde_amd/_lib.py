@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
@@ -44,6 +44,11 @@ class XbarDesc(C.Structure):
 class Conv3dDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("Z", C.c_int), ("X", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("ksize", C.c_int)]
+
+
+class ResampleDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Z", C.c_int), ("X", C.c_int), ("C", C.c_int), ("ft", C.c_int),
+                ("fz", C.c_int), ("fx", C.c_int)]
 
 
 class BnDesc(C.Structure):
@@ -120,6 +125,7 @@ _SIGNATURES = {
     "stpde_residual_fwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_residual_bwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP],
                            C.c_int),
+    "stpde_resample3d": ([C.POINTER(ResampleDesc), C.c_int, _VP, _VP, _VP, _VP], C.c_int),
     "stpde_bn_fwd": ([C.POINTER(BnDesc)] + [_VP] * 10, C.c_int),
     "stpde_bn_bwd": ([C.POINTER(BnDesc)] + [_VP] * 11, C.c_int),
     "stpde_loss_sum": ([C.c_int, C.c_long, _VP, _VP, _VP, _VP], C.c_int),

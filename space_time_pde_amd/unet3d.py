@@ -6,8 +6,8 @@ On CUDA tensors every convolution (1x1x1 and 3x3x3) runs in the HIP implicit-GEM
 channels-last activations [B, T, Z, X, C]; the network output is returned as a channels-last *view* of logical
 shape [B, C, T, Z, X], so the ``latent_grid.permute(0, 2, 3, 4, 1)`` of experiments/rb2d/train.py:60 is a free
 contiguous view that feeds the local-implicit-grid kernels directly.  BatchNorm (+ residual add) (+ ReLU) run in the
-fused HIP kernels ``stpde_bn_fwd`` / ``stpde_bn_bwd``; pooling / nearest upsampling / concatenation are copy
-plumbing done with torch ops on the same layout.
+fused HIP kernels ``stpde_bn_fwd`` / ``stpde_bn_bwd``, max pooling and nearest up-sampling in ``stpde_resample3d``;
+only the channel concatenation of the skip connections is a torch copy.
 ``Encoder3d`` of the reference (src/unet3d.py:243-344) is dead code there and is not provided.
 """
 import ctypes as C
@@ -228,14 +228,60 @@ def _bn_act(x, bn, relu, residual=None):
                            bool(relu))
 
 
+class _ResampleHip(torch.autograd.Function):
+    """Max pooling (pool=True) or nearest up-sampling by integer factors on channels-last data (stpde_resample3d)."""
+
+    @staticmethod
+    def forward(ctx, x, factors, pool):
+        L = _lib.lib()
+        x = x.contiguous()
+        ft, fz, fx = (int(f) for f in factors)
+        b, t, z, xx, c = x.shape
+        d = _lib.ResampleDesc()
+        if pool:
+            d.B, d.T, d.Z, d.X = b, t // ft, z // fz, xx // fx
+        else:
+            d.B, d.T, d.Z, d.X = b, t, z, xx
+        d.C, d.ft, d.fz, d.fx = c, ft, fz, fx
+        shape = (b, d.T, d.Z, d.X, c) if pool else (b, t * ft, z * fz, xx * fx, c)
+        y = torch.empty(shape, device=x.device, dtype=torch.float32)
+        _lib.check(L.stpde_resample3d(C.byref(d), 0 if pool else 2, _lib.ptr(x), None, _lib.ptr(y), _lib.stream_ptr()))
+        ctx.desc, ctx.pool, ctx.in_shape = (d.B, d.T, d.Z, d.X, c, ft, fz, fx), pool, x.shape
+        ctx.save_for_backward(x if pool else None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (x,) = ctx.saved_tensors
+        d = _lib.ResampleDesc()
+        d.B, d.T, d.Z, d.X, d.C, d.ft, d.fz, d.fx = ctx.desc
+        gy = gy.contiguous()
+        gx = torch.empty(ctx.in_shape, device=gy.device, dtype=torch.float32)
+        _lib.check(L.stpde_resample3d(C.byref(d), 1 if ctx.pool else 3, _lib.ptr(gy), _lib.ptr(x), _lib.ptr(gx),
+                                      _lib.stream_ptr()))
+        return gx, None, None
+
+
+def _hip_resample_ok(x, factors):
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and all(1 <= int(f) <= 4 for f in factors))
+
+
 def _pool_cl(x, kernel):
     if all(int(k) == 1 for k in kernel):
         return x
+    if _hip_resample_ok(x, kernel) and all(x.shape[1 + i] % int(k) == 0 for i, k in enumerate(kernel)):
+        return _ResampleHip.apply(x, tuple(kernel), True)
     y = F.max_pool3d(x.permute(0, 4, 1, 2, 3), tuple(int(k) for k in kernel))
     return y.permute(0, 2, 3, 4, 1).contiguous()
 
 
 def _upsample_cl(x, factors):
+    if all(int(f) == 1 for f in factors):
+        return x
+    if _hip_resample_ok(x, factors):
+        return _ResampleHip.apply(x, tuple(factors), False)
     for dim, f in zip((1, 2, 3), factors):
         if int(f) != 1:
             x = x.repeat_interleave(int(f), dim=dim)

@@ -110,3 +110,37 @@ def test_conv3d_hip_vs_torch_fp64(hiplib):
         assert rel(xd.grad, x64.grad) < 1e-5
         assert rel(cd.weight.grad, c64.weight.grad) < 1e-4
         assert rel(cd.bias.grad, c64.bias.grad) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factors", [(2, 2, 2), (1, 2, 2), (2, 1, 1)])
+def test_pool_and_upsample_hip_vs_torch(hiplib, factors):
+    """stpde_resample3d against F.max_pool3d / repeat_interleave, values and gradients, including exact ties."""
+    import torch.nn.functional as F
+    from space_time_pde_amd import unet3d
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 6, 8, 16, generator=g)
+    x = torch.relu(x)                                   # many exact ties (zeros), as after a ResBlock
+    x[0, :2, :2, :2, :] = 1.5                           # and a window of equal positive values
+    xa = x.to(dev).requires_grad_(True)
+    xb = x.to(dev).requires_grad_(True)
+    y = unet3d._pool_cl(xa, factors)
+    yr = F.max_pool3d(xb.permute(0, 4, 1, 2, 3), factors).permute(0, 2, 3, 4, 1)
+    assert torch.equal(y, yr.contiguous())
+    cot = torch.randn(y.shape, generator=g).to(dev)
+    (y * cot).sum().backward()
+    (yr * cot).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    ua = x.to(dev).requires_grad_(True)
+    ub = x.to(dev).requires_grad_(True)
+    u = unet3d._upsample_cl(ua, factors)
+    ur = ub
+    for dim, f in zip((1, 2, 3), factors):
+        if f != 1:
+            ur = ur.repeat_interleave(f, dim=dim)
+    assert torch.equal(u, ur)
+    cot = torch.randn(u.shape, generator=g).to(dev)
+    (u * cot).sum().backward()
+    (ur * cot).sum().backward()
+    assert torch.allclose(ua.grad, ub.grad, rtol=1e-6, atol=1e-6)
