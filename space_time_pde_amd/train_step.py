@@ -76,12 +76,15 @@ def loss_sum(a, b, loss_type):
 
 
 def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n_points_global, alpha_reg=1.0,
-                 alpha_pde=1.0, loss_type="l1", xmin=0.0, xmax=1.0, distributed=None):
+                 alpha_pde=1.0, loss_type="l1", xmin=0.0, xmax=1.0, distributed=None, sync_unet_grads=False):
     """Forward + backward of one step on this rank's slice of the query points.
 
     input_grid [b, c, T, Z, X] (identical on every rank); point_coord / point_value [b, n_local, 3|o] (this rank's
     slice); n_points_global = total points per batch element over all ranks.  Gradients are left in ``.grad`` of
     the UNet / IM-NET parameters, already summed over ranks.  Returns (loss, reg_loss, pde_loss) global values.
+    sync_unet_grads: the replicated UNet backward uses fp32 atomics, so its gradients agree across ranks only to
+    rounding (~1e-7 relative); True averages them with one more all-reduce so that long runs keep the replicas
+    bit-identical (the reference's DDP all-reduces every gradient, train_ddp.py:401-406).
     """
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -109,6 +112,15 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
         for g in grads:
             g.copy_(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
+        if sync_unet_grads:
+            ug = [p.grad for p in unet.parameters() if p.grad is not None]
+            uflat = torch.cat([g.reshape(-1) for g in ug])
+            dist.all_reduce(uflat)
+            uflat /= dist.get_world_size()
+            o = 0
+            for g in ug:
+                g.copy_(uflat[o:o + g.numel()].view_as(g))
+                o += g.numel()
         stats = torch.stack([loss.detach(), reg.detach(), pde.detach()])
         dist.all_reduce(stats)
         return stats[0], stats[1], stats[2]
