@@ -36,7 +36,8 @@ def _worker(rank, world, port, out):
     unet, imnet, layer, crop, pts, tgt = _build()
     n = pts.shape[1] // world
     sl = slice(rank * n, (rank + 1) * n)
-    loss, reg, pde = sharded_step(unet, imnet, layer, crop, pts[:, sl], tgt[:, sl], pts.shape[1], 1.0, 0.0125)
+    loss, reg, pde = sharded_step(unet, imnet, layer, crop, pts[:, sl], tgt[:, sl], pts.shape[1], 1.0, 0.0125,
+                                  sync_unet_grads=True)
     if rank == 0:
         torch.save(dict(loss=loss, reg=reg, pde=pde, g_im=[p.grad for p in imnet.parameters()],
                         g_un=[p.grad for p in unet.parameters()]), out)
