@@ -125,3 +125,27 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
         dist.all_reduce(stats)
         return stats[0], stats[1], stats[2]
     return loss.detach(), reg.detach(), pde.detach()
+
+
+def data_parallel_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, alpha_reg=1.0, alpha_pde=1.0,
+                       loss_type="l1", xmin=0.0, xmax=1.0):
+    """The reference's own split (experiments/rb2d/train_ddp.py:361-368, 401-406): every rank holds DIFFERENT crops
+    (and their query points), runs the whole step locally, and all parameter gradients are averaged over ranks with
+    one flat all-reduce.  BatchNorm statistics stay per rank, as under the reference's DistributedDataParallel."""
+    loss, reg, pde = sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, point_coord.shape[1],
+                                  alpha_reg, alpha_pde, loss_type, xmin, xmax, distributed=False)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        grads = [p.grad for m in (unet, imnet) for p in m.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)
+        flat /= world
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        stats = torch.stack([loss, reg, pde])
+        dist.all_reduce(stats)
+        stats /= world
+        return stats[0], stats[1], stats[2]
+    return loss, reg, pde

@@ -66,3 +66,48 @@ def test_two_rank_step_equals_single_process(tmp_path):
         assert (a - p.grad).abs().max() <= 2e-5 * p.grad.abs().max() + 1e-9
     for a, p in zip(got["g_un"], unet.parameters()):
         assert (a - p.grad).abs().max() <= 1e-4 * p.grad.abs().max() + 1e-8
+
+
+def _worker_dp(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from space_time_pde_amd.train_step import data_parallel_step
+    unet, imnet, layer, crop, pts, tgt = _build()
+    g = torch.Generator().manual_seed(100 + rank)
+    crop = crop + 0.1 * torch.randn(crop.shape, generator=g)          # a different crop per rank
+    loss, reg, pde = data_parallel_step(unet, imnet, layer, crop, pts, tgt, 1.0, 0.0125)
+    if rank == 0:
+        torch.save(dict(loss=loss, g_im=[p.grad for p in imnet.parameters()], g_un=[p.grad for p in unet.parameters()]), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_averages_gradients(tmp_path):
+    """The reference's batch-of-crops split (train_ddp.py:401-406): gradients = mean over ranks of the local ones."""
+    sys.path.insert(0, ROOT)
+    from space_time_pde_amd.train_step import data_parallel_step
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "rank0_dp.pt")
+    mp.spawn(_worker_dp, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.set_num_threads(1)
+    acc_im, acc_un, losses = None, None, []
+    for rank in range(2):
+        unet, imnet, layer, crop, pts, tgt = _build()
+        g = torch.Generator().manual_seed(100 + rank)
+        crop = crop + 0.1 * torch.randn(crop.shape, generator=g)
+        loss, _, _ = data_parallel_step(unet, imnet, layer, crop, pts, tgt, 1.0, 0.0125)
+        losses.append(loss.item())
+        gi, gu = [p.grad.clone() for p in imnet.parameters()], [p.grad.clone() for p in unet.parameters()]
+        acc_im = gi if acc_im is None else [a + b for a, b in zip(acc_im, gi)]
+        acc_un = gu if acc_un is None else [a + b for a, b in zip(acc_un, gu)]
+    assert abs(got["loss"].item() - sum(losses) / 2) < 1e-6 * abs(sum(losses) / 2)
+    for a, b in zip(got["g_im"], acc_im):
+        assert (a - b / 2).abs().max() <= 2e-5 * (b / 2).abs().max() + 1e-9
+    for a, b in zip(got["g_un"], acc_un):
+        assert (a - b / 2).abs().max() <= 1e-4 * (b / 2).abs().max() + 1e-8
