@@ -90,7 +90,20 @@ __global__ __launch_bounds__(256) void k_residual_bwd(ResArgs a) {
       case STPDE_RES_MUL: g[in.a] += gi * v[in.b]; g[in.b] += gi * v[in.a]; break;
       case STPDE_RES_DIV: g[in.a] += gi / v[in.b]; g[in.b] -= gi * v[i] / v[in.b]; break;
       case STPDE_RES_NEG: g[in.a] -= gi; break;
-      case STPDE_RES_POWI: g[in.a] += gi * (float)in.b * v[i] / v[in.a]; break;   // d(x^n) = n x^n / x (x != 0)
+      case STPDE_RES_POWI: {   // d(x^n)/dx = n x^(n-1), evaluated without dividing by x (x = 0 is a regular point for n >= 1)
+        if (in.b != 0) {
+          const int m = in.b - 1;
+          float base = v[in.a], r = 1.f;
+          int e = m < 0 ? -m : m;
+          while (e) {
+            if (e & 1) r *= base;
+            base *= base;
+            e >>= 1;
+          }
+          g[in.a] += gi * (float)in.b * (m < 0 ? 1.f / r : r);
+        }
+        break;
+      }
       case STPDE_RES_SIN: g[in.a] += gi * cosf(v[in.a]); break;
       case STPDE_RES_COS: g[in.a] -= gi * sinf(v[in.a]); break;
       case STPDE_RES_EXP: g[in.a] += gi * v[i]; break;
