@@ -219,6 +219,8 @@ def _bn_act(x, bn, relu, residual=None):
         if residual is not None:
             h = h + residual
         return F.relu(h) if relu else h
+    if training and x.numel() // c == 1:   # same refusal as torch.nn.functional.batch_norm
+        raise ValueError("Expected more than 1 value per channel when training, got input size {}".format(tuple(x.shape)))
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None \
             and not getattr(bn, "_stpde_counted", False):
         bn.num_batches_tracked.add_(1)
