@@ -302,3 +302,29 @@ def test_other_network_widths(hiplib, nf, cout):
     for k in range(6):
         assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
         assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
+
+
+@pytest.mark.parametrize("nf", [16, 32])
+def test_value_only_query_backward(hiplib, nf):
+    """Plain query (no PDE layer, e.g. a regression-only loss): the S = 1 kernels, forward and backward."""
+    from space_time_pde_amd import local_implicit_grid as lig
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(2, 333, 3, generator=g)
+    net = _net("softplus", nf=nf).to(dev)
+    latd = lat.to(dev).requires_grad_(True)
+    n0 = lig.stats["hip_value_calls"]
+    y = lig.query_local_implicit_grid(net, latd, pts.to(dev), 0., 1.)
+    assert lig.stats["hip_value_calls"] == n0 + 1
+    cot = torch.randn(y.shape, generator=g)
+    (y * cot.to(dev)).sum().backward()
+    p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
+    lat64 = lat.double().requires_grad_(True)
+    ref = O.query_lig(lambda f: O.imnet_forward(p64, f, O.activation_fn("softplus")), lat64, pts.double(), 0., 1.)
+    (ref * cot.double()).sum().backward()
+    assert _relerr(y, ref.detach()) < 2e-5
+    assert _relerr(latd.grad, lat64.grad) < 2e-4
+    for k in range(6):
+        assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
+        assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
