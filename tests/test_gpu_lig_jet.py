@@ -328,3 +328,31 @@ def test_value_only_query_backward(hiplib, nf):
     for k in range(6):
         assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
         assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
+
+
+@pytest.mark.parametrize("nf", [16, 32])
+def test_backward_all_six_second_order_streams(hiplib, nf):
+    """S = 10 (value, gradient, full Hessian): the widest stream set, forward and backward."""
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(13)
+    lat = 0.5 * torch.randn(1, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(1, 150, 3, generator=g)
+    pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+    net = _net("tanh", nf=nf).to(dev)
+    latd = lat.to(dev).requires_grad_(True)
+    jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, pairs)
+    assert jets.shape[0] == 10
+    cot = torch.randn(jets.shape, generator=g)
+    (jets * cot.to(dev)).sum().backward()
+    p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
+    lat64 = lat.double().requires_grad_(True)
+    ref = J.lig_jets(p64, "tanh", lat64, pts.double(), 0., 1., second=tuple(pp))
+    ref = ref.permute(0, 3, 1, 2).reshape(ref.shape[0], 4, -1)
+    (ref * cot.double()).sum().backward()
+    for s in range(10):
+        assert _relerr(jets[s], ref[s].detach()) < 2e-5, "stream %d" % s
+    assert _relerr(latd.grad, lat64.grad) < 2e-4
+    for k in range(6):
+        assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
+        assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
