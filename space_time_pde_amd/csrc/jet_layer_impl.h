@@ -214,9 +214,10 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // k-tiles.  Layer-0 regeneration, skip GEMM, activation jets and epilogues stay fp32.
 // PK (bf16 variant only): k-tiles produced per wave and group -- the bf16 MFMAs of a k-tile take 1/16 of the fp32
 // time, so twice the k-tiles per barrier halve the number of exposed load -> activation -> LDS -> barrier chains.
-template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1>
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1, bool WRING = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, GK = NW * PK;
+  static_assert(!WRING || (!BF && GK == 4), "the weight ring is written for 4 k-tiles per group, fp32");
   __shared__ __attribute__((aligned(16))) float hb[2][GK][S][BF ? 128 : 256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -286,6 +287,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
       for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
+    f32x4 wr[WRING ? 4 : 1][MCg];
+    if constexpr (WRING) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi) wr[q][mi] = ld4(wp + ((size_t)q * MT + mi) * 256);
+    }
     __syncthreads();              // ring free (previous pass fully consumed)
     produce_group(0, 0);
     __syncthreads();
@@ -307,6 +315,26 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
           for (int mi = 0; mi < MCg; ++mi)
 #pragma unroll
             for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(w8[mi], B8[st], acc[mi][st]);
+        }
+      } else if constexpr (WRING) {
+        // weight fragments through a register ring three k-tiles deep that runs straight across the group barriers
+        // (GK == 4 == ring length, so the slot of k-tile kt is the compile-time q): an L2 round trip then has
+        // ~3 x (MCg * S * 4) MFMAs of cover instead of the one k-tile the scheduler arranges on its own
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kt = 4 * gi + q;
+          const int ktn = kt + 3 < KT ? kt + 3 : KT - 1;
+          f32x4 B[S];
+#pragma unroll
+          for (int st = 0; st < S; ++st) B[st] = ld4(&hb[buf][q][st][lo]);
+#pragma unroll
+          for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int st = 0; st < S; ++st) acc[mi][st] = mfma4(wr[q][mi][r], B[st][r], acc[mi][st]);
+#pragma unroll
+          for (int mi = 0; mi < MCg; ++mi) wr[(q + 3) & 3][mi] = ld4(wp + ((size_t)ktn * MT + mi) * 256);
         }
       } else {
 #pragma unroll
@@ -487,8 +515,18 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 2>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   else if (a.Wp16)
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
-  else
+  else {
+    // forward of the widest layer (4 output tiles per wave): weight fragments through the 3-deep register ring
+    // (-2.5 % on that kernel; no gain for the 2-tile-per-wave shapes).  STPDE_WRING=0 switches it off.
+    static const int wring_env = getenv("STPDE_WRING") ? atoi(getenv("STPDE_WRING")) : 1;
+    if constexpr (NW == 4 && MCg == 4 && EPI == EPI_FWD) {
+      if (wring_env && a.KT >= 8) {
+        STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false, 1, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+        return stpde_check_launch("k_layer_coop");
+      }
+    }
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+  }
   return stpde_check_launch("k_layer_coop");
 }
 
