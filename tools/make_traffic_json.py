@@ -21,7 +21,7 @@ def parse(path):
 def bench_name(sym):
     if re.match(r"k_\w+<0,0,", sym):      # value-only kernels of bench.py's inference side figure, not the training step
         return None
-    m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?>", sym)
+    m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?(?:,[\w,]+)?>", sym)
     if m and m.group(8) in (None, "false"):
         pro, epi = int(m.group(4)), int(m.group(5))
         if pro == 2 and epi == 0:
