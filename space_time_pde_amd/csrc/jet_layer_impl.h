@@ -8,7 +8,6 @@
 //   k_layer_coop   4 / 8 waves share ONE row tile and split its output tiles; the B operand of every k-tile (stash load
 //                  + activation jet, or layer-0 regeneration) is produced once per workgroup into a double-buffered
 //                  LDS ring; bf16-operand variant for BASELINE configs[3]
-//   k_layer_coop2  8 waves share TWO row tiles (dgrad of the widest layer)
 // Replaces (reference): src/implicit_net.py:48-54 on the rows of src/local_implicit_grid.py:53, and the reverse
 // sweeps of src/pde.py:8-9 (streams carry d/dr and d2/dr2 forward instead).
 #pragma once
@@ -365,145 +364,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   flush_pbar<EPI, ACT>(a, pacc, lane);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Two-row-tile form of the cooperative kernel for the widest layers (MT % 16 == 0): an 8-wave workgroup owns TWO row
-// tiles (32 corner rows) and 16 output tiles per pass (2 per wave), so every weight fragment fetched from L2 feeds
-// 2 x S x 4 MFMAs instead of S x 4 and every barrier covers twice the matrix work.  tools/micro/mfma_loop.hip shows
-// why: with the B operand in LDS the loop runs at 98 % of the MFMA peak, streaming the A fragments from L2 costs
-// ~10 % at 2-3 workgroups per CU whatever the prefetch scheme, and the load -> VALU -> LDS produce stage another
-// ~8 %; doubling the MFMAs per fragment / per produced block recovers part of both.  Ring: 2 buffers x 4 k-tiles x
-// 2 tiles x S blocks (80 KB for S = 5) -> one workgroup (2 waves per SIMD) per CU; wave w produces k-tile w % 4 of
-// tile w / 4.
-// ------------------------------------------------------------------------------------------------------------
-template <int S1, int S2, int PRO, int EPI, int ACT>
-__global__ __launch_bounds__(512, 2) void k_layer_coop2(LayerArgs a) {
-  constexpr int S = 1 + S1 + S2, MCg = 2, NW = 8, GK = 4;
-  constexpr bool NEEDX = PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0;
-  __shared__ __attribute__((aligned(16))) float hb[2][GK][2][S][256];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int KT = a.KT, MT = a.MT;
-  const int lo = lane * 4;
-  const int npairs = (a.ntiles + 1) / 2;
-  int pair = blockIdx.x, pass0 = 0, pstep = 1;
-  if (a.split > 0) {     // output passes of one tile pair on consecutive slots of the same XCD (shared L2)
-    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-    pass0 = slot % a.split;
-    pstep = a.split;
-    pair = (slot / a.split) * 8 + xcd;
-  }
-  if (pair >= npairs) return;
-  const int t0 = 2 * pair;
-  const bool valid1 = t0 + 1 < a.ntiles;
-  const int pq = wv & 3, pt = wv >> 2;                 // produce role
-  const int ptile = (pt == 1 && valid1) ? t0 + 1 : t0;
-  float pacc = 0.f;
-  float cqp[6];
-  load_cq<S2>(a.cw, ptile * 2 + ((lane & 15) >> 3), cqp);
-  f32x4 xbp[XT];
-  if (PRO == PRO_L0) {
-#pragma unroll
-    for (int xt = 0; xt < XT; ++xt) xbp[xt] = ld4(a.X + ((size_t)ptile * XT + xt) * 256 + lo);
-  }
-  const float* bin = a.Bin + (size_t)ptile * S * KT * 256 + lo;
-
-  auto produce = [&](int kt, int buf) {
-    f32x4 raw[S], B[S];
-    if (PRO == PRO_L0) {
-      raw[0] = layer0_block(a.W0s, KT, kt, lo, xbp);
-      if (S1 == 3) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
-#pragma unroll
-        for (int p = 0; p < S2; ++p) raw[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    } else {
-#pragma unroll
-      for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT + kt) * 256);
-    }
-    if (PRO == PRO_NONE) {
-#pragma unroll
-      for (int st = 0; st < S; ++st) B[st] = raw[st];
-    } else {
-      act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cqp);
-    }
-#pragma unroll
-    for (int st = 0; st < S; ++st) st4(&hb[buf][pq][pt][st][lo], B[st]);
-  };
-
-  const int ngroups = KT / GK;
-  for (int mt0 = (pass0 * NW + wv) * MCg; mt0 < MT; mt0 += pstep * NW * MCg) {
-    f32x4 acc[MCg][2 * S];
-#pragma unroll
-    for (int mi = 0; mi < MCg; ++mi)
-#pragma unroll
-      for (int j = 0; j < 2 * S; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
-    __syncthreads();              // ring free (previous pass fully consumed)
-    produce(pq, 0);
-    __syncthreads();
-    for (int gi = 0; gi < ngroups; ++gi) {
-      const int buf = gi & 1;
-#pragma unroll
-      for (int q = 0; q < GK; ++q) {
-        const int kt = GK * gi + q;
-        f32x4 B[2 * S], w[MCg];
-#pragma unroll
-        for (int j = 0; j < 2 * S; ++j) B[j] = ld4(&hb[buf][q][0][0][lo] + j * 256);
-#pragma unroll
-        for (int mi = 0; mi < MCg; ++mi) w[mi] = ld4(wp + ((size_t)kt * MT + mi) * 256);
-#pragma unroll
-        for (int mi = 0; mi < MCg; ++mi)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < 2 * S; ++j) acc[mi][j] = mfma4(w[mi][r], B[j][r], acc[mi][j]);
-      }
-      produce(gi + 1 < ngroups ? GK * (gi + 1) + pq : GK * gi + pq, buf ^ 1);   // branch-free tail
-      __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (t == 1 && !valid1) break;
-      const int tile = t0 + t;
-      float cqe[6];
-      load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cqe);
-      f32x4 xbe[XT];
-      if (NEEDX) {
-#pragma unroll
-        for (int xt = 0; xt < XT; ++xt) xbe[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
-      }
-#pragma unroll
-      for (int mi = 0; mi < MCg; ++mi)
-        layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, &acc[mi][t * S], xbe, cqe, pacc);
-    }
-  }
-  flush_pbar<EPI, ACT>(a, pacc, lane);
-}
-
-template <int S1, int S2, int PRO, int EPI, int ACT>
-static int launch_layer_coop2(const LayerArgs& a0, hipStream_t stream) {
-  LayerArgs a = a0;
-  const int npass = a.MT / 16;
-  const int npairs = (a.ntiles + 1) / 2;
-  a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
-  const int nblocks = a.split ? (npairs + 7) / 8 * 8 * a.split : npairs;
-  STPDE_LAUNCH((k_layer_coop2<S1, S2, PRO, EPI, ACT>), dim3(nblocks), dim3(512), 0, stream, a);
-  return stpde_check_launch("k_layer_coop2");
-}
-
-template <int S1, int S2, int PRO, int EPI>
-static int launch_coop2_act(const LayerArgs& a, hipStream_t stream) {
-  switch (a.cfg.act) {
-    case STPDE_ACT_TANH: return launch_layer_coop2<S1, S2, PRO, EPI, STPDE_ACT_TANH>(a, stream);
-    case STPDE_ACT_RELU: return launch_layer_coop2<S1, S2, PRO, EPI, STPDE_ACT_RELU>(a, stream);
-    case STPDE_ACT_SOFTPLUS: return launch_layer_coop2<S1, S2, PRO, EPI, STPDE_ACT_SOFTPLUS>(a, stream);
-    case STPDE_ACT_ELU: return launch_layer_coop2<S1, S2, PRO, EPI, STPDE_ACT_ELU>(a, stream);
-    case STPDE_ACT_LEAKYRELU: return launch_layer_coop2<S1, S2, PRO, EPI, STPDE_ACT_LEAKYRELU>(a, stream);
-    default: return launch_layer_coop2<S1, S2, PRO, EPI, STPDE_ACT_SWISH>(a, stream);
-  }
-}
-
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
 static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   LayerArgs a = a0;
@@ -516,10 +376,10 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   else if (a.Wp16)
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   else {
-    // forward of the widest layer (4 output tiles per wave): weight fragments through the 3-deep register ring
-    // (-2.5 % on that kernel; no gain for the 2-tile-per-wave shapes).  STPDE_WRING=0 switches it off.
+    // 4 output tiles per wave: weight fragments through the 3-deep register ring (-2.5 % on the forward of the widest
+    // layer; no gain for the 2-tile-per-wave shapes).  STPDE_WRING=0 switches it off.
     static const int wring_env = getenv("STPDE_WRING") ? atoi(getenv("STPDE_WRING")) : 1;
-    if constexpr (NW == 4 && MCg == 4 && EPI == EPI_FWD) {
+    if constexpr (NW == 4 && MCg == 4) {
       if (wring_env && a.KT >= 8) {
         STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false, 1, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
         return stpde_check_launch("k_layer_coop");
@@ -569,12 +429,6 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
   if (a.MT % 4 != 0) return launch_layer<S1, S2, 4, PRO, EPI, -1, true>(a, stream);
   // workgroup-cooperative variant: B operand produced once per 4 waves (S = 10 would not fit two workgroups of LDS)
   if (a.KT % 4 == 0 && a.KT >= 8 && S1 + S2 <= 5) {
-    // dgrad of the widest layer: two row tiles per 8-wave workgroup (measured -3 % on MI355X; the forward kernel
-    // gains nothing from it and keeps the one-tile form).  STPDE_COOP2=0 switches it off.
-    static const int coop2_env = getenv("STPDE_COOP2") ? atoi(getenv("STPDE_COOP2")) : 1;
-    if constexpr (S1 + S2 <= 4 && EPI != EPI_FWD) {   // two tiles x S streams of accumulators, 80 KB ring: S <= 5
-      if (coop2_env && a.MT % 16 == 0 && !a.Wp16) return launch_coop2_act<S1, S2, PRO, EPI>(a, stream);
-    }
     if (EPI == EPI_FWD) {
       if (a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4, 4>(a, stream);
       if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
@@ -582,6 +436,8 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
       // dgrad epilogues are VALU heavy: 2 output tiles per wave keeps two waves per SIMD.  Measured on MI355X: the
       // 8-wave workgroup (one pass over 16 output tiles) wins when it makes the kernel single-pass (MT == 16);
       // for MT == 32 four passes of the 4-wave workgroup are faster than two passes of the 8-wave one.
+      // and 4 output tiles per wave with the weight ring beat both for MT % 16 == 0 (layers 1 and 2 of the reference net)
+      if (a.MT % 16 == 0 && S1 + S2 <= 4) return launch_coop_act<S1, S2, PRO, EPI, 4, 4>(a, stream);
       if (a.KT % 8 == 0 && a.MT == 16) return launch_coop_act<S1, S2, PRO, EPI, 2, 8>(a, stream);
       if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
     }
