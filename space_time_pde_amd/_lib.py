@@ -70,37 +70,59 @@ def _sources():
     return [os.path.join(_CSRC, s) for s in _SOURCES if os.path.exists(os.path.join(_CSRC, s))]
 
 
+def _source_hash(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(_HIPFLAGS).encode())
+    return h.hexdigest()
+
+
 def build_library(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into libstpde_hip.so (cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 into libstpde_hip.so (cross-compiles without a GPU).
+
+    Staleness is decided by a content hash of all sources / headers / flags stored next to the library (not by file
+    times, which a copy of the tree to another machine may not preserve)."""
     srcs = _sources()
-    deps = srcs + [os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "jet_layer_impl.h"), os.path.join(_CSRC, "jet_wgrad_impl.h"), os.path.join(_HERE, "..", "include", "stpde_hip.h")]
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in deps if os.path.exists(p))
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+    hdrs = [os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "jet_layer_impl.h"),
+            os.path.join(_CSRC, "jet_wgrad_impl.h"), os.path.join(_HERE, "..", "include", "stpde_hip.h")]
+    deps = srcs + hdrs
+    stamp = LIB_PATH + ".srchash"
+    want = _source_hash([p for p in deps if os.path.exists(p)])
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return LIB_PATH
     objdir = os.path.join(_CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    hdr_hash = _source_hash([p for p in hdrs if os.path.exists(p)])
     procs = []
     objs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        if (not force and os.path.exists(o)
-                and os.path.getmtime(o) >= max(os.path.getmtime(p) for p in [s] + deps[len(srcs):])):
+        ostamp = o + ".srchash"
+        owant = _source_hash([s]) + hdr_hash
+        if not force and os.path.exists(o) and os.path.exists(ostamp) and open(ostamp).read().strip() == owant:
             continue
         flags = _HIPFLAGS if s.endswith(".hip") else ["-O3", "-std=c++17", "-fPIC"]
         cmd = ["hipcc"] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, p in procs:
+        procs.append((cmd, ostamp, owant, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, ostamp, owant, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+        with open(ostamp, "w") as f:
+            f.write(owant)
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
+    with open(stamp, "w") as f:
+        f.write(want)
     return LIB_PATH
 
 
