@@ -62,6 +62,12 @@ typedef struct {
 
 int stpde_version(void);
 int stpde_last_error(char* buf, unsigned long n);
+/* Dispatch trace (test / debugging facility; nothing in the reference corresponds to it): while enabled, every kernel
+ * launch records which template instantiation it dispatched ("<kernel expression> @ <launcher with template
+ * arguments>", unique entries).  stpde_trace_enable clears the set; stpde_trace_read copies the newline-separated
+ * entries (truncated to n - 1 bytes) and returns the number of bytes needed for all of them. */
+int stpde_trace_enable(int on);
+long stpde_trace_read(char* buf, unsigned long n);
 
 /* ---- a1/a2: clip, cell index, corner gather, weights, relative coords ------------------------------
  * Replaces regular_nd_grid_interpolation_coefficients (src/regular_nd_grid_interpolation.py:14-78) +

@@ -133,6 +133,8 @@ _VP = C.c_void_p
 _SIGNATURES = {
     "stpde_version": ([], C.c_int),
     "stpde_last_error": ([C.c_char_p, C.c_ulong], C.c_int),
+    "stpde_trace_enable": ([C.c_int], C.c_int),
+    "stpde_trace_read": ([C.c_char_p, C.c_ulong], C.c_long),
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
     "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
     "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
@@ -198,11 +200,80 @@ def check(rc):
         raise _EXC.get(rc, RuntimeError)("libstpde_hip: " + buf.value.decode())
 
 
+class dispatch_trace:
+    """``with dispatch_trace() as tr: ...; tr.kernels`` = the kernel template instantiations launched inside
+    (tests use it to assert that a parity case really exercised the kernels the benchmark times)."""
+
+    def __enter__(self):
+        lib().stpde_trace_enable(1)
+        self.kernels = []
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        n = L.stpde_trace_read(None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        L.stpde_trace_read(buf, n + 1)
+        L.stpde_trace_enable(0)
+        self.kernels = [k for k in buf.value.decode().split("\n") if k]
+        return False
+
+    def has(self, *needles):
+        """True if one traced entry contains every needle."""
+        return any(all(n in k for n in needles) for k in self.kernels)
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
 def stream_ptr():
+    """torch's current stream of the CURRENT device.  Launch sites run under ``device_of(tensor)`` (see ``guarded``), so
+    the current device is the one the tensors live on."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class device_of:
+    """``with device_of(t):`` makes t's device the current HIP device for the launches inside (and restores the
+    previous one); a no-op when it already is.  Without it a model on ``cuda:1`` driven from a process whose current
+    device is 0 -- e.g. the replicas of the reference's multi-device nn.DataParallel (experiments/rb2d/train.py:352-355)
+    -- would be launched on device 0's stream."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index if (t is not None and t.is_cuda) else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None:
+            import torch
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            import torch
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def guarded(fn):
+    """Decorator for the static forward / backward of an autograd Function (or any function whose arguments include the
+    tensors it launches on): runs it under ``device_of`` the first CUDA tensor argument."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(*args, **kw):
+        t = None
+        for a in args:
+            if hasattr(a, "is_cuda") and a.is_cuda:
+                t = a
+                break
+        with device_of(t):
+            return fn(*args, **kw)
+    return wrap

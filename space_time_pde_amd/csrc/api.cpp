@@ -4,6 +4,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
 
 #include "../../include/stpde_hip.h"
 
@@ -32,4 +35,32 @@ extern "C" int stpde_last_error(char* buf, unsigned long n) {
   strncpy(buf, g_err, n - 1);
   buf[n - 1] = 0;
   return STPDE_OK;
+}
+
+// ---- dispatch trace (tests assert which template instantiations a call reached) -------------------------------
+int stpde_trace_on = 0;
+static std::mutex g_trace_mu;
+static std::set<std::string> g_trace;
+
+void stpde_trace_note(const char* launcher, const char* kernel) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace.insert(std::string(kernel) + " @ " + launcher);
+}
+
+extern "C" int stpde_trace_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace.clear();
+  stpde_trace_on = on ? 1 : 0;
+  return STPDE_OK;
+}
+
+extern "C" long stpde_trace_read(char* buf, unsigned long n) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  std::string all;
+  for (const auto& s : g_trace) all += s + "\n";
+  if (buf && n > 0) {
+    strncpy(buf, all.c_str(), n - 1);
+    buf[n - 1] = 0;
+  }
+  return (long)all.size() + 1;   // bytes needed
 }

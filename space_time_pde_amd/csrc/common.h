@@ -248,12 +248,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 
+extern int stpde_trace_on;
+void stpde_trace_note(const char* launcher, const char* kernel);
+
 // Launch with a clean error slot: hipGetLastError() is sticky per thread, a stale error from an unrelated earlier
 // runtime call must not be attributed to this launch.
-#define STPDE_LAUNCH(...)      \
-  do {                         \
-    (void)hipGetLastError();   \
-    hipLaunchKernelGGL(__VA_ARGS__); \
+// With tracing enabled (stpde_trace_enable, a test / debugging facility) every launch also notes WHICH template
+// instantiation was dispatched: the enclosing launcher's __PRETTY_FUNCTION__ (carries the template argument values)
+// plus the kernel expression as written (carries the literal flags).
+#define STPDE_LAUNCH(kern, ...)                                              \
+  do {                                                                       \
+    (void)hipGetLastError();                                                 \
+    if (stpde_trace_on) stpde_trace_note(__PRETTY_FUNCTION__, #kern);        \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);                                   \
   } while (0)
 
 // per-row weights of the combined second-order stream: cw[P][8], point of row j of a tile = 2*tile + (j >> 3)

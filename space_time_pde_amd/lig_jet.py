@@ -406,6 +406,7 @@ class LigJetFunction(torch.autograd.Function):
     """jets[S, n_out, P] of the LIG+IM-NET composite; differentiable w.r.t. latent grid and IM-NET parameters."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, meta, latent, pts, act_param, *params):
         # act_param: the learnable swish beta (a tensor input so that autograd routes its gradient) or None
         packs = meta.plan.pack(params)
@@ -428,6 +429,7 @@ class LigJetFunction(torch.autograd.Function):
         return jets
 
     @staticmethod
+    @_lib.guarded
     def backward(ctx, jets_bar):
         if ctx.used:
             raise RuntimeError("LigJetFunction.backward ran twice: the activation stash is consumed in place "

@@ -53,11 +53,20 @@ def _fast_eligible(model, latent_grid, query_pts):
             and lig_jet.activation_name(model.activ) is not None)
 
 
-def _xmin_is_zero(xmin):
+def _xmin_is_zero(xmin, xmax=None, shape3=None):
+    """The HIP kernels reproduce the reference's cell index, which ignores xmin (quirk a-Q1), for xmin == 0 only; any
+    other lower bound takes the generic formulation, which behaves like the reference on every device.  Tensor bounds
+    are decided through the (cached, sync-free after the first call) box-constant evaluation."""
     if isinstance(xmin, (int, float)):
         return xmin == 0
     if torch.is_tensor(xmin):
-        return None  # decided (and cached) inside lig_jet.box_constants
+        if torch.is_tensor(xmax) and shape3 is not None:
+            try:
+                lig_jet.cached_box_constants(shape3, xmin, xmax)
+                return True
+            except ValueError:
+                return False
+        return bool((xmin.detach() == 0).all())
     return all(float(v) == 0 for v in xmin)
 
 
@@ -72,7 +81,7 @@ def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
     # wrapper is the identity, so the HIP path reads the wrapped module's parameters directly
     if isinstance(model, torch.nn.DataParallel) and len(model.device_ids or []) <= 1:
         model = model.module
-    if _fast_eligible(model, latent_grid, query_pts) and _xmin_is_zero(xmin) is not False:
+    if _fast_eligible(model, latent_grid, query_pts) and _xmin_is_zero(xmin, xmax, tuple(latent_grid.shape[1:4])):
         wants_point_grad = query_pts.requires_grad and torch.is_grad_enabled()
         if req is not None and req.x is query_pts:
             jets, pairs = lig_jet.lig_jets(model, latent_grid, query_pts, xmin, xmax, req.first, req.pairs,

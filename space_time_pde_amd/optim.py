@@ -25,6 +25,17 @@ class FusedClipAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_grad=clip_grad))
 
+    def __setstate__(self, state):
+        # Optimizer.load_state_dict replaces param_groups with the SAVED groups: a checkpoint written by the
+        # reference's torch.optim.Adam (train.py:390-397) has no ``clip_grad`` entry, and carries Adam options
+        # (amsgrad, maximize, foreach, ...) this optimizer does not implement -- keep this instance's clip value and
+        # refuse the options that would change the update rule.
+        super().__setstate__(state)
+        for group in self.param_groups:
+            group.setdefault("clip_grad", self.defaults["clip_grad"])
+            if group.get("amsgrad") or group.get("maximize"):
+                raise ValueError("FusedClipAdam does not implement amsgrad / maximize")
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -58,7 +69,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                 rows.append(ptrs + (n, group["lr"] / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)))
             if not rows:
                 continue
-            dev = group["params"][0].device
+            dev = keep[0].device
             # ONE launch for the whole group: tensor table + chunk table (a few KB) are uploaded per step
             tab = torch.from_numpy(np.array(rows, dtype=_TENSOR_DT).view(np.uint8)).to(dev)
             chk = torch.from_numpy(np.array(chunks, dtype=_CHUNK_DT).view(np.uint8)).to(dev)
@@ -66,8 +77,9 @@ class FusedClipAdam(torch.optim.Optimizer):
             d.n = 0
             d.clip, d.beta1, d.beta2, d.eps = float(group["clip_grad"] or 0.0), b1, b2, group["eps"]
             d.weight_decay, d.step_size, d.bias2_sqrt = group["weight_decay"], 0.0, 1.0
-            _lib.check(L.stpde_clip_adam_multi(C.byref(d), _lib.ptr(tab), _lib.ptr(chk), len(chunks), _CHUNK,
-                                               _lib.stream_ptr()))
-            tab.record_stream(torch.cuda.current_stream())
-            chk.record_stream(torch.cuda.current_stream())
+            with _lib.device_of(tab):
+                _lib.check(L.stpde_clip_adam_multi(C.byref(d), _lib.ptr(tab), _lib.ptr(chk), len(chunks), _CHUNK,
+                                                   _lib.stream_ptr()))
+                tab.record_stream(torch.cuda.current_stream())
+                chk.record_stream(torch.cuda.current_stream())
         return loss

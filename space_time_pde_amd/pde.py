@@ -146,6 +146,7 @@ class _ResidualHip(torch.autograd.Function):
     """res[n_eq, P] = program(jets[S, n_out, P], x[P, 3]); backward returns d loss / d jets."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, jets, x2d, prog_t, nins, n_eq):
         L = _lib.lib()
         jets = jets if jets.stride(2) == 1 and jets.stride(1) >= jets.shape[2] else jets.contiguous()
@@ -159,6 +160,7 @@ class _ResidualHip(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_lib.guarded
     def backward(ctx, gres):
         L = _lib.lib()
         jets, x2d, prog_t = ctx.saved_tensors

@@ -68,8 +68,13 @@ def _hip_eligible(grid, query_pts):
 
 
 def _desc(grid, query_pts, xmin, xmax):
+    """Kernel descriptor, or None when the bounds are outside the HIP envelope (xmin != 0: the reference's cell index
+    ignores xmin, quirk a-Q1; the composed formulation below reproduces whatever the reference does there)."""
     dim = grid.dim() - 2
-    lo_c, hi_c, cube = cached_box_constants(tuple(grid.shape[1:-1]), xmin, xmax)
+    try:
+        lo_c, hi_c, cube = cached_box_constants(tuple(grid.shape[1:-1]), xmin, xmax)
+    except ValueError:
+        return None
     d = _lib.InterpDesc()
     d.B, d.N = query_pts.shape[0], query_pts.shape[1]
     d.P, d.dim, d.C = d.B * d.N, dim, grid.shape[-1]
@@ -80,6 +85,7 @@ def _desc(grid, query_pts, xmin, xmax):
 
 class _InterpHip(torch.autograd.Function):
     @staticmethod
+    @_lib.guarded
     def forward(ctx, grid, pts, desc, want_coeffs):
         L = _lib.lib()
         g = grid.contiguous()
@@ -104,6 +110,7 @@ class _InterpHip(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_lib.guarded
     def backward(ctx, *gouts):
         if not ctx.needs_input_grad[0]:
             return None, None, None, None
@@ -126,14 +133,16 @@ def regular_nd_grid_interpolation_coefficients(grid, query_pts, xmin=0., xmax=1.
     (batch, num_points, 2**dim, in_features), weights (batch, num_points, 2**dim), x_relative
     (batch, num_points, 2**dim, dim) in [-1, 1].
     """
-    if _hip_eligible(grid, query_pts):
-        return _InterpHip.apply(grid, query_pts, _desc(grid, query_pts, xmin, xmax), True)
+    desc = _desc(grid, query_pts, xmin, xmax) if _hip_eligible(grid, query_pts) else None
+    if desc is not None:
+        return _InterpHip.apply(grid, query_pts, desc, True)
     return _coefficients_autograd(grid, query_pts, xmin, xmax)
 
 
 def regular_nd_grid_interpolation(grid, query_pts, xmin=0., xmax=1.):
     """Batched multilinear interpolation of grid values at query points (reference :81-104)."""
-    if _hip_eligible(grid, query_pts):
-        return _InterpHip.apply(grid, query_pts, _desc(grid, query_pts, xmin, xmax), False)[0]
+    desc = _desc(grid, query_pts, xmin, xmax) if _hip_eligible(grid, query_pts) else None
+    if desc is not None:
+        return _InterpHip.apply(grid, query_pts, desc, False)[0]
     corner_values, weights, _ = _coefficients_autograd(grid, query_pts, xmin, xmax)
     return torch.sum(corner_values * weights.unsqueeze(-1), dim=-2)

@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _lib
 from .local_implicit_grid import query_local_implicit_grid
 
 
@@ -44,8 +45,8 @@ class _LossSumHip(torch.autograd.Function):
     stpde_loss_grad).  Replaces sub + abs + sum (+ zeros_like, stack) and their backward kernels of train.py:69-76."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, a, b, kind):
-        from . import _lib
         L = _lib.lib()
         a = a.contiguous()
         b = b.contiguous() if b is not None else None
@@ -57,8 +58,8 @@ class _LossSumHip(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_lib.guarded
     def backward(ctx, g):
-        from . import _lib
         L = _lib.lib()
         a, b = ctx.saved_tensors
         ga = torch.empty_like(a)

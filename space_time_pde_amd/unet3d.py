@@ -71,6 +71,7 @@ class _Conv3dHip(torch.autograd.Function):
     with one gather per step), or None: packed here."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, x, weight, bias, packs=None):
         L = _lib.lib()
         co, ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -100,6 +101,7 @@ class _Conv3dHip(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_lib.guarded
     def backward(ctx, gy):
         L = _lib.lib()
         xin, wsaved = ctx.saved_tensors
@@ -126,11 +128,24 @@ class _Conv3dHip(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _hip_conv_ok(x, conv):
+    """Envelope of the HIP implicit-GEMM convolution: fp32 CUDA data, out_channels a multiple of 16, cubic 1x1x1 or
+    3x3x3 kernel, stride 1, 'same' zero padding, no dilation / groups.  Anything else (e.g. unet_nf = 8, half / double
+    models) takes torch's convolution on the permuted tensor -- API compatibility, never the benchmarked path."""
+    w = conv.weight
+    k = w.shape[2]
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_cuda
+            and w.shape[0] % 16 == 0 and k in (1, 3) and tuple(w.shape[2:]) == (k, k, k)
+            and tuple(conv.stride) == (1, 1, 1) and tuple(conv.padding) == ((k - 1) // 2,) * 3
+            and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and (conv.bias is None or conv.bias.dtype == torch.float32))
+
+
 def _conv_cl(x, conv):
     """Apply an nn.Conv3d (1x1x1 or 3x3x3/pad 1, stride 1) to a channels-last tensor [B,T,Z,X,C]."""
-    if x.is_cuda:
+    if _hip_conv_ok(x, conv):
         return _Conv3dHip.apply(x, conv.weight, conv.bias, getattr(conv, "_stpde_packs", None))
-    y = F.conv3d(x.permute(0, 4, 1, 2, 3), conv.weight, conv.bias, padding=conv.padding)
+    y = conv(x.permute(0, 4, 1, 2, 3))
     return y.permute(0, 2, 3, 4, 1).contiguous()
 
 
@@ -140,10 +155,12 @@ class _ContiguousGrad(torch.autograd.Function):
     reduction kernel instead of the channels-last one."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, x):
         return x.view_as(x)
 
     @staticmethod
+    @_lib.guarded
     def backward(ctx, g):
         return g.contiguous()
 
@@ -164,6 +181,7 @@ class _BnActHip(torch.autograd.Function):
     normalisation (stpde_bn_fwd); backward = one reduction + one elementwise pass (stpde_bn_bwd)."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
         L = _lib.lib()
         x = x.contiguous()
@@ -186,6 +204,7 @@ class _BnActHip(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_lib.guarded
     def backward(ctx, gy):
         L = _lib.lib()
         x, y, weight, stat = ctx.saved_tensors
@@ -234,6 +253,7 @@ class _ResampleHip(torch.autograd.Function):
     """Max pooling (pool=True) or nearest up-sampling by integer factors on channels-last data (stpde_resample3d)."""
 
     @staticmethod
+    @_lib.guarded
     def forward(ctx, x, factors, pool):
         L = _lib.lib()
         x = x.contiguous()
@@ -254,6 +274,7 @@ class _ResampleHip(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @_lib.guarded
     def backward(ctx, gy):
         L = _lib.lib()
         (x,) = ctx.saved_tensors
@@ -412,7 +433,8 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
     def _prepare_step(self, device):
         """CUDA path: pack the weights of ALL convolutions with one concatenation + one index gather (instead of two
         small kernels per convolution per pass) and bump all BatchNorm step counters with one foreach op."""
-        convs = [m for m in self.modules() if isinstance(m, nn.Conv3d)]
+        convs = [m for m in self.modules() if isinstance(m, nn.Conv3d) and m.weight.shape[0] % 16 == 0
+                 and m.weight.dtype == torch.float32 and m.weight.shape[2] in (1, 3)]
         plan = getattr(self, "_pack_plan", None)
         if plan is None or plan[0] != str(device):
             total = sum(c.weight.numel() for c in convs)

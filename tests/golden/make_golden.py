@@ -25,6 +25,8 @@ import physics  # noqa: E402
 import regular_nd_grid_interpolation as rgi  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, OUT)
+import det_init  # noqa: E402  (numpy-seeded parameter / input generation shared with the tests)
 ACTS = ["softplus", "leakyrelu", "tanh", "relu", "elu", "swish"]
 MEAN = (0.01, 0.0, 0.02, -0.01)
 STD = (0.05, 0.3, 0.15, 0.12)
@@ -229,7 +231,188 @@ def g7_unet():
     np.savez_compressed(os.path.join(OUT, "g7_unet.npz"), **d)
 
 
+def _rb2_step(unet, net, crop, pts, tgt, alpha_pde=0.0125, latent=None):
+    """experiments/rb2d/train.py:58-77 around the imported reference modules (tensor bounds as train.py:48-49)."""
+    xmin, xmax = torch.zeros(3, dtype=pts.dtype), torch.ones(3, dtype=pts.dtype)
+    lat = unet(crop).permute(0, 2, 3, 4, 1) if latent is None else latent
+    layer = physics.get_rb2_pde_layer(mean=MEAN, std=STD, t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
+    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, lat, p, xmin, xmax))
+    pred, res = layer(pts.clone(), return_residue=True)
+    reg = torch.nn.functional.l1_loss(pred, tgt)
+    st = torch.stack(list(res.values()), 0)
+    pl = torch.nn.functional.l1_loss(st, torch.zeros_like(st))
+    loss = 1.0 * reg + alpha_pde * pl
+    loss.backward()
+    return lat, pred, res, reg, pl, loss
+
+
+def g5b_nf32():
+    """G5 at the BENCHMARKED network width (nf = 32; softplus -> combined stream S = (3,1), leaky-relu -> S = (3,0)):
+    inputs and weights come from det_init (regenerated by the test), only the reference's outputs are stored."""
+    lat0 = 0.5 * det_init.normal(521, 1, 4, 8, 8, 32)
+    pts = det_init.uniform(522, 1, 256, 3, lo=0.02, hi=0.98)
+    tgt = det_init.normal(523, 1, 256, 4)
+    d = {}
+    for act in ("softplus", "leakyrelu"):
+        net = det_init.fill_module_(make_net(act, nf=32, seed=0), 524)
+        lat = lat0.clone().requires_grad_(True)
+        _, pred, res, reg, pl, _ = _rb2_step(None, net, None, pts, tgt, latent=lat)
+        d[f"{act}_pred"] = t2n(pred)
+        for k, v in res.items():
+            d[f"{act}_res_{k}"] = t2n(v)
+        d[f"{act}_reg_loss"], d[f"{act}_pde_loss"] = t2n(reg), t2n(pl)
+        d[f"{act}_dlatent"] = t2n(lat.grad)
+        for k in range(6):
+            gw, gb = net.fc[k].weight.grad, net.fc[k].bias.grad
+            d[f"{act}_db{k}"] = t2n(gb)
+            d[f"{act}_dw{k}_norm"] = t2n(gw.norm())
+            d[f"{act}_dw{k}"] = t2n(gw[::3] if k < 2 else gw)      # fc0 / fc1: every third output row (fixture size)
+    np.savez_compressed(os.path.join(OUT, "g5b_nf32.npz"), **d)
+
+
+def g8_c1_step():
+    """BASELINE configs[0] end to end: the reference's UNet3d(igres=(16,32,32), nf=16, mf=256) in
+    training mode -> latent grid -> LIG + ImNet(nf=32) + RB2 residuals on 4096 points -> L1 losses -> backward to every
+    UNet and ImNet parameter.  Weights / inputs from det_init; stored: losses, a slice of predictions / residuals / the
+    latent grid, the gradient norm of EVERY parameter and a few small gradients in full.
+    The same step is also run with the reference cast to float64 (``*_f64`` keys): BatchNorm over the 8 voxels of the
+    deepest level amplifies fp32 rounding (the reference's fp32 latent grid differs from its own fp64 one by ~9e-4 of
+    the maximum), so parity tolerances for this config are stated relative to the reference's own fp32-vs-fp64
+    distance."""
+    import unet3d
+    crop = det_init.normal(800, 1, 4, 16, 32, 32)
+    pts = det_init.uniform(801, 1, 4096, 3)
+    tgt = det_init.normal(802, 1, 4096, 4)
+    d = {}
+    full = ("conv_in.conv2.weight", "conv_in.bn1.weight", "conv_in.shortcut.bias", "conv_out.conv3.weight",
+            "conv_out.bn3.bias", "down_modules.0.conv2.weight", "up_modules.3.conv1.bias")
+    for act in ("softplus", "leakyrelu"):
+        for dt, sfx in ((torch.float32, ""), (torch.float64, "_f64")):
+            unet = det_init.fill_module_(unet3d.UNet3d(in_features=4, out_features=32, igres=(16, 32, 32), nf=16, mf=256), 810)
+            net = det_init.fill_module_(make_net(act, nf=32, seed=0), 820)
+            unet.to(dt).train()
+            net.to(dt).train()
+            lat, pred, res, reg, pl, loss = _rb2_step(unet, net, crop.to(dt), pts.to(dt), tgt.to(dt))
+            d[f"{act}_reg_loss{sfx}"], d[f"{act}_pde_loss{sfx}"], d[f"{act}_loss{sfx}"] = t2n(reg), t2n(pl), t2n(loss)
+            d[f"{act}_pred{sfx}"] = t2n(pred[:, :512])
+            for k, v in res.items():
+                d[f"{act}_res_{k}{sfx}"] = t2n(v[:, :512])
+            if act == "softplus":
+                d["latent_slice" + sfx] = t2n(lat[0, ::4, ::8, ::8, :])
+            names, norms = [], []
+            for prefix, mod in (("unet.", unet), ("imnet.", net)):
+                seen = set()
+                for name, p in mod.named_parameters():
+                    if id(p) in seen:
+                        continue
+                    seen.add(id(p))
+                    names.append(prefix + name)
+                    norms.append(float(p.grad.norm()))
+            d[f"{act}_grad_names"], d[f"{act}_grad_norms{sfx}"] = np.array(names), np.array(norms)
+            if act == "softplus":
+                up = dict(unet.named_parameters())
+                for name in full:
+                    d["grad%s/unet.%s" % (sfx, name)] = t2n(up[name].grad)
+                d["grad%s/imnet.fc5.weight" % sfx] = t2n(net.fc5.weight.grad)
+                d["grad%s/imnet.fc4.bias" % sfx] = t2n(net.fc4.bias.grad)
+                d["grad%s/imnet.fc2.bias" % sfx] = t2n(net.fc2.bias.grad)
+                sd = unet.state_dict()
+                for name in ("conv_in.bn1.running_mean", "conv_in.bn1.running_var", "conv_mid.bn2.running_var",
+                             "conv_out.bn3.running_mean"):
+                    d["after%s/%s" % (sfx, name)] = t2n(sd[name])
+    np.savez_compressed(os.path.join(OUT, "g8_c1_step.npz"), **d)
+
+
+def n3_dataloader():
+    """N3: the reference's RB2DataLoader.__getitem__ (dataloader_spacetime.py:118-171) on a small synthetic .npz --
+    low-res crop, sampled points and interpolated targets for every lres_filter / lres_interp / normalisation setting.
+    The synthetic dataset itself is regenerated by the test from the stored seed."""
+    import tempfile
+    import dataloader_spacetime as dl
+    T, X, Z = 12, 40, 24
+    rng = np.random.default_rng(900)
+    arrs = {k: rng.standard_normal((T, X, Z)).astype(np.float32) for k in ("p", "b", "u", "w")}   # stored [t, x, z]
+    d = dict(T=T, X=X, Z=Z, data_seed=900, idx=np.array([0, 37, 1000]))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "synth.npz"), **arrs)
+        cfgs = [("none", "linear", False), ("none", "linear", True), ("gaussian", "linear", False),
+                ("uniform", "linear", True), ("maximum", "linear", False), ("median", "linear", False),
+                ("none", "nearest", False)]
+        for filt, interp, norm in cfgs:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ds = dl.RB2DataLoader(data_dir=tmp, data_filename="synth.npz", nx=16, nz=16, nt=8,
+                                      n_samp_pts_per_crop=64, downsamp_xz=4, downsamp_t=2, normalize_output=norm,
+                                      lres_filter=filt, lres_interp=interp)
+            tag = f"{filt}_{interp}_{int(norm)}"
+            d["len"] = len(ds)
+            d["mean"], d["std"] = ds.channel_mean, ds.channel_std
+            for idx in (0, 37, 1000):
+                np.random.seed(7 + idx)
+                lres, pc, pv = ds[idx]
+                d[f"{tag}/{idx}/lres"], d[f"{tag}/{idx}/pc"], d[f"{tag}/{idx}/pv"] = lres, pc, pv
+    np.savez_compressed(os.path.join(OUT, "n3_dataloader.npz"), **d)
+
+
+def n4_checkpoint():
+    """N4: a checkpoint WRITTEN BY THE REFERENCE (src/train_utils.py:13-30 with the dict of train.py:390-397) after one
+    Adam step, plus what the reference computes when it resumes from it (train.py:339-350) and takes a second step:
+    forward output, losses and a few updated parameters.  The .pth.tar file is data (a pickled dict of tensors)."""
+    import logging
+    import unet3d
+    import train_utils
+    crop = det_init.normal(950, 1, 4, 4, 8, 8)
+    pts = det_init.uniform(951, 1, 128, 3, lo=0.02, hi=0.98)
+    tgt = det_init.normal(952, 1, 128, 4)
+    lr, clip = 1e-2, 0.1
+
+    def build():
+        unet = det_init.fill_module_(unet3d.UNet3d(in_features=4, out_features=32, igres=(4, 8, 8), nf=16, mf=16), 960)
+        net = det_init.fill_module_(make_net("softplus", nf=16, seed=0), 970)
+        opt = torch.optim.Adam(list(unet.parameters()) + list(net.parameters()), lr=lr)
+        return unet, net, opt
+
+    def step(unet, net, opt):
+        unet.train()
+        opt.zero_grad()
+        lat, pred, res, reg, pl, loss = _rb2_step(unet, net, crop, pts, tgt)
+        torch.nn.utils.clip_grad_value_(unet.parameters(), clip)
+        torch.nn.utils.clip_grad_value_(net.parameters(), clip)
+        opt.step()
+        return pred, reg, pl
+
+    unet, net, opt = build()
+    step(unet, net, opt)
+    state = {"epoch": 1, "unet_state_dict": unet.state_dict(), "imnet_state_dict": net.state_dict(),
+             "optim_state_dict": opt.state_dict(), "tracked_stats": 0.25, "global_step": np.ones(1, dtype=np.uint32)}
+    train_utils.save_checkpoint(state, False, 1, os.path.join(OUT, "n4_ckpt"), "_pdenet", logging.getLogger("golden"))
+    # resume exactly as train.py:339-350 does, then one more step
+    unet2, net2, opt2 = build()
+    ck = torch.load(os.path.join(OUT, "n4_ckpt_pdenet_001.pth.tar"), weights_only=False)
+    unet2.load_state_dict(ck["unet_state_dict"])
+    net2.load_state_dict(ck["imnet_state_dict"])
+    opt2.load_state_dict(ck["optim_state_dict"])
+    pred, reg, pl = step(unet2, net2, opt2)
+    d = dict(lr=lr, clip=clip, pred=t2n(pred), reg_loss=t2n(reg), pde_loss=t2n(pl))
+    for name in ("conv_in.conv1.weight", "conv_in.bn1.weight", "conv_out.conv3.weight", "conv_mid.conv2.bias"):
+        d["after/unet." + name] = t2n(dict(unet2.named_parameters())[name])
+    for name in ("fc0.bias", "fc3.weight", "fc5.weight"):
+        d["after/imnet." + name] = t2n(dict(net2.named_parameters())[name])
+    d["after/unet.conv_in.bn1.running_mean"] = t2n(unet2.state_dict()["conv_in.bn1.running_mean"])
+    np.savez_compressed(os.path.join(OUT, "n4_resume.npz"), **d)
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
+    g5b_nf32()
+    g8_c1_step()
+    n3_dataloader()
+    n4_checkpoint()
     g1_interp()
     g3_corners()
     g4_imnet()
