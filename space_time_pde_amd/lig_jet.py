@@ -256,28 +256,37 @@ def box_constants(shape3, xmin, xmax):
 
 
 _box_cache = {}
-_box_tensor_cache = None   # WeakKeyDictionary: tensor object -> (version, {shape: constants})
+_box_tensor_cache = {}     # id(xmin) -> (weakref(xmin), weakref(xmax), key, constants)
 _box_lock = threading.Lock()
 
 
 def cached_box_constants(shape3, xmin, xmax):
     """box_constants with a cache, so that device-tensor bounds (train.py:48-49 passes CUDA tensors) do not cost a
-    device sync per call.  Tensor entries are keyed on the tensor OBJECTS through weak references plus their version
-    counters (an id()/data_ptr key could alias a freed tensor); python scalars / sequences are keyed by value."""
-    global _box_tensor_cache
+    device sync per call.  Tensor entries are keyed on id(xmin) and validated through weak references to BOTH tensor
+    objects plus their version counters (an id alone could alias a freed tensor; a WeakKeyDictionary cannot be used
+    because its lookups compare keys with ``==``, which is elementwise for tensors); python scalars / sequences are
+    keyed by value."""
     shape3 = tuple(shape3)
     if torch.is_tensor(xmin) and torch.is_tensor(xmax):
         import weakref
+        key = (shape3, xmin._version, xmax._version)
         with _box_lock:
-            if _box_tensor_cache is None:
-                _box_tensor_cache = weakref.WeakKeyDictionary()
-            ent = _box_tensor_cache.get(xmin)
-            key = (shape3, id(xmax), xmin._version, xmax._version)
-            if ent is not None and ent[0] == key and ent[1]() is xmax:
-                return ent[2]
+            ent = _box_tensor_cache.get(id(xmin))
+            if ent is not None and ent[0]() is xmin and ent[1]() is xmax and ent[2] == key:
+                return ent[3]
         val = box_constants(shape3, xmin, xmax)
+        ident = id(xmin)
+
+        def _drop(_ref, ident=ident):
+            with _box_lock:
+                cur = _box_tensor_cache.get(ident)
+                if cur is not None and cur[0] is _ref:
+                    del _box_tensor_cache[ident]
+
         with _box_lock:
-            _box_tensor_cache[xmin] = (key, weakref.ref(xmax), val)
+            if len(_box_tensor_cache) > 256:
+                _box_tensor_cache.clear()
+            _box_tensor_cache[ident] = (weakref.ref(xmin, _drop), weakref.ref(xmax), key, val)
         return val
     if torch.is_tensor(xmin) or torch.is_tensor(xmax):
         return box_constants(shape3, xmin, xmax)

@@ -162,3 +162,17 @@ def test_hot_path_never_falls_back_on_cuda_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libstpde_hip.so")
     with pytest.raises(RuntimeError, match="not built"):
         _lib.lib()
+
+
+def test_tensor_bounds_cache_survives_repeated_lookups():
+    """train.py:48-49 hands the SAME xmin / xmax tensors to every step: repeated lookups must hit the cache (r1 bug: a
+    WeakKeyDictionary compared the tensor keys elementwise and raised on the second call)."""
+    from space_time_pde_amd import lig_jet
+    a, b = torch.zeros(3), torch.ones(3)
+    first = lig_jet.cached_box_constants((4, 8, 8), a, b)
+    for _ in range(3):
+        assert lig_jet.cached_box_constants((4, 8, 8), a, b) is first
+    b.mul_(2.0)                                   # in-place change of the bounds: version counter invalidates the entry
+    assert lig_jet.cached_box_constants((4, 8, 8), a, b)[2][0] == pytest.approx(2.0 / 3.0)
+    with pytest.raises(ValueError):
+        lig_jet.cached_box_constants((4, 8, 8), torch.full((3,), 0.5), b)

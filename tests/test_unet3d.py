@@ -144,3 +144,168 @@ def test_pool_and_upsample_hip_vs_torch(hiplib, factors):
     (u * cot).sum().backward()
     (ur * cot).sum().backward()
     assert torch.allclose(ua.grad, ub.grad, rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The U-Net kernels AT BENCHMARK SIZE: the full-resolution levels of BASELINE configs[1]
+# (32 x 128 x 128 = 524,288 voxels -> the 4-voxel-tiles-per-wave conv variants, ntiles >= 16384) and configs[3].
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci,co,k", [(4, 16, 1), (16, 16, 3), (16, 32, 1), (32, 32, 3), (32, 64, 1)])
+def test_conv3d_at_bench_volume_vs_torch_fp64(hiplib, ci, co, k):
+    """Channel shapes of the full-resolution C2 / C4 levels on the C2 volume: forward, input gradient, weight and bias
+    gradient vs torch fp64 on the host; the dispatch trace asserts the big-volume kernel variants ran."""
+    from space_time_pde_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + ci + co + k)
+    shape = (1, 32, 128, 128)
+    conv = torch.nn.Conv3d(ci, co, k, padding=(k - 1) // 2)
+    x = torch.randn(*shape, ci, generator=g)
+    cot = torch.randn(*shape, co, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    cd = conv.to(dev)
+    with _lib.dispatch_trace() as tr:
+        y = unet3d._conv_cl(xd, cd)
+        (y * cot.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+    mt = co // 16
+    assert tr.has("k_conv3d_fwd<%d, 4>" % min(mt, 4)), "\n".join(tr.kernels)     # forward: 4 voxel tiles per wave
+    assert tr.has("k_conv3d_wgrad"), "\n".join(tr.kernels)
+    c64 = torch.nn.Conv3d(ci, co, k, padding=(k - 1) // 2).double()
+    c64.load_state_dict({kk: v.double().cpu() for kk, v in cd.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    y64 = c64(x64.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+    (y64 * cot.double()).sum().backward()
+
+    def rel(a, b):
+        return (a.double().cpu() - b).abs().max().item() / b.abs().max().item()
+
+    assert rel(y.detach(), y64.detach()) < 1e-5
+    assert rel(xd.grad, x64.grad) < 1e-5
+    # 524,288-term fp32 sums (block partial sums + atomics): error grows with sqrt(n) relative to the terms' size
+    assert rel(cd.weight.grad, c64.weight.grad) < 2e-4
+    assert rel(cd.bias.grad, c64.bias.grad) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,relu,res", [(16, True, False), (32, True, True), (32, False, True)])
+def test_batchnorm_at_bench_volume_vs_torch_fp64(hiplib, c, relu, res):
+    """Fused BatchNorm(+add)(+ReLU) over 524,288 voxels (training statistics, running-stat update, backward)."""
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 + c)
+    n = 32 * 128 * 128
+    x = torch.randn(1, 32, 128, 128, c, generator=g) * 1.7 + 0.3
+    r = torch.randn(1, 32, 128, 128, c, generator=g) if res else None
+    cot = torch.randn(1, 32, 128, 128, c, generator=g)
+    bn = torch.nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * torch.randn(c, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(c, generator=g))
+    bnd = torch.nn.BatchNorm3d(c).to(dev)
+    bnd.load_state_dict(bn.state_dict())
+    bnd.train()
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True) if res else None
+    y = unet3d._bn_act(xd, bnd, relu, residual=rd)
+    (y * cot.to(dev)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if res else None
+    w64, b64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    h = F.batch_norm(x64.reshape(n, c), rm, rv, w64, b64, True, 0.1, bn.eps).reshape(x.shape)
+    if res:
+        h = h + r64
+    y64 = F.relu(h) if relu else h
+    (y64 * cot.double()).sum().backward()
+
+    def rel(a, b):
+        return (a.double().cpu() - b).abs().max().item() / b.abs().max().item()
+
+    # elements whose pre-ReLU value is within fp32 rounding of the kink may legitimately take the other branch
+    # (~1 of 16.7 M): they are excluded from the gradient comparison
+    safe = (h.detach().abs() > 1e-5) if relu else torch.ones_like(h, dtype=torch.bool)
+
+    def relm(a, b):
+        return ((a.double().cpu() - b) * safe).abs().max().item() / b.abs().max().item()
+
+    assert rel(y.detach(), y64.detach()) < 1e-5
+    assert rel(bnd.running_mean, rm) < 5e-5 and rel(bnd.running_var, rv) < 5e-5   # fp32 mean of 524,288 values
+    assert relm(xd.grad, x64.grad) < 2e-5
+    if res:
+        assert relm(rd.grad, r64.grad) < 1e-6
+    assert rel(bnd.weight.grad, w64.grad) < 2e-4 and rel(bnd.bias.grad, b64.grad) < 2e-4
+
+
+@pytest.mark.gpu
+def test_resample_at_bench_volume(hiplib):
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    x = torch.relu(torch.randn(1, 32, 128, 128, 32, generator=g)).to(dev)
+    for factors in ((1, 2, 2), (2, 2, 2)):
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        y = unet3d._pool_cl(xa, factors)
+        yr = F.max_pool3d(xb.permute(0, 4, 1, 2, 3), factors).permute(0, 2, 3, 4, 1).contiguous()
+        assert torch.equal(y, yr)
+        cot = torch.randn(y.shape, generator=g).to(dev)
+        (y * cot).sum().backward()
+        (yr * cot).sum().backward()
+        assert torch.equal(xa.grad, xb.grad)
+    small = x[:, :16, :64, :64].contiguous()
+    u = unet3d._upsample_cl(small, (2, 2, 2))
+    assert torch.equal(u, small.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("igres", [(32, 128, 128), (64, 256, 256)])
+def test_unet_at_config_size_hip_vs_torch_cpu(hiplib, igres):
+    """The whole encoder at BASELINE configs[1] / configs[3] size, HIP vs the same module on the host (torch ops).
+
+    In TRAINING mode this network is numerically chaotic in fp32 at these sizes -- on the host, the same fp32 module run
+    with 8 threads and with 1 thread differs by 54 % of the output maximum, fp32 vs fp64 by 28 % (7-8 pooling levels, the
+    deepest BatchNorms see 8 voxels; C1 with 5 levels: 1e-3) -- so no implementation can be pinned on its training-mode
+    output there.  Training-mode parity at size is therefore asserted per kernel (the three tests above: conv, fused
+    BatchNorm, resample on the 524,288-voxel level) and end to end on C1 (G7 / G8); here the whole network runs in
+    EVALUATION mode (running statistics, perturbed so that they are not the identity): every convolution variant, pooling,
+    up-sampling, concatenation and BatchNorm-apply at full size, forward and (C2) input gradient."""
+    import copy
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    net = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.6 + 0.2 * torch.rand(m.num_features, generator=g))
+    x = torch.randn(1, 4, *igres, generator=g)
+    nd = copy.deepcopy(net).to(dev).eval()
+    net.eval()
+    small = igres[0] == 32
+    xd = x.to(dev).requires_grad_(small)
+    xc = x.clone().requires_grad_(small)
+    if small:
+        y, yc = nd(xd), net(xc)
+    else:
+        with torch.no_grad():
+            y, yc = nd(xd), net(xc)
+    assert y.shape == (1, 32) + tuple(igres) and torch.isfinite(y).all()
+
+    def rel(a, b):
+        return (a.double().cpu() - b.double()).abs().max().item() / b.double().abs().max().item()
+
+    assert rel(y.detach(), yc.detach()) < 1e-4
+    if small:
+        cot = torch.randn(y.shape, generator=g)
+        (y * cot.to(dev)).sum().backward()
+        (yc * cot).sum().backward()
+        # a handful of the ~10^8 ReLU inputs sit within rounding of the kink and take the other branch on one side:
+        # isolated gradient outliers, judged in the Frobenius norm with a loose bound on the maximum
+        def nrm(a, b):
+            return (a.double().cpu() - b.double()).norm().item() / b.double().norm().item()
+
+        assert nrm(xd.grad, xc.grad) < 2e-4 and rel(xd.grad, xc.grad) < 5e-2
+        for name in ("conv_in.conv2.weight", "down_modules.0.conv2.weight", "conv_out.conv3.weight", "conv_mid.conv2.weight"):
+            a, b = dict(nd.named_parameters())[name].grad, dict(net.named_parameters())[name].grad
+            assert nrm(a, b) < 5e-4, name
