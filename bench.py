@@ -74,11 +74,13 @@ def make_inputs(n_pts, dev, seed=0, igres=(32, 128, 128)):
     return crop, pts, tgt
 
 
-def cpu_baseline(act, chunk=4096, nchunks=2):
-    """Time the CPU oracle (restatement of the reference's 25-reverse-sweep path) on a bounded sample.
+def cpu_baseline(act, chunk=4096, nchunks=3):
+    """Time the CPU oracle (restatement of the reference's 25-reverse-sweep path) on a bounded sample (~30 s).
 
     The host may have far more cores than the op-level parallelism of this graph can use (128 threads ran 7x slower
-    than 16 on the GPU box), so the thread count is calibrated on a small chunk first and reported as ``cores``.
+    than 16 on the GPU box), so the thread count is calibrated on a small chunk first and reported as ``cores``; one
+    more chunk is timed with 8 threads for comparability with the build-container figures (BASELINE.md section 2, and
+    profiles/r2_cpu_ref_vs_port.json: the restatement takes the same time as the imported reference there).
     """
     from oracle import cpu_ref
     g = torch.Generator().manual_seed(0)
@@ -104,11 +106,16 @@ def cpu_baseline(act, chunk=4096, nchunks=2):
     torch.set_num_threads(best)
     times = sorted(run(chunk) for _ in range(nchunks))
     med = times[len(times) // 2]
-    return dict(value=chunk / med, unit="query-points/s", cores=best, kind="port",
+    t8 = med
+    if best != 8:
+        torch.set_num_threads(min(8, ncpu))
+        t8 = run(chunk)
+    return dict(value=chunk / med, unit="query-points/s", cores=best, kind="port", value_8_threads=chunk / t8,
                 sample="%d chunks of %d points over the same [1,32,128,128,32] latent grid (UNet excluded: <1%% of the "
-                       "work), %s, %d threads (best of 8/16/32 on this host, %d logical CPUs), median chunk %.2f s; the "
-                       "reference path cannot hold 2^20 points at once and pseudo-batches (evaluation.py:54-60)"
-                       % (nchunks, chunk, act, best, ncpu, med))
+                       "work), %s, %d threads (best of 8/16/32 on this host, %d logical CPUs), median chunk %.2f s "
+                       "(+1 chunk at 8 threads: %.2f s); the reference path cannot hold 2^20 points at once and "
+                       "pseudo-batches (evaluation.py:54-60)"
+                       % (nchunks, chunk, act, best, ncpu, med, t8))
 
 
 def main():
@@ -166,14 +173,11 @@ def main():
     from space_time_pde_amd.train_step import sharded_step
     uev = []
     pending = []
-    unet.register_forward_pre_hook(lambda m, i: pending.append(torch.cuda.Event(enable_timing=True)) or pending[-1].record())
 
     def _post(m, i, o):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         uev.append((pending.pop(), e1))
-
-    unet.register_forward_hook(_post)
 
     def step():
         for p in params + uparams:
@@ -191,19 +195,34 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    lig_jet.profile = {}
+    # timed region: exactly `steps` steps between two barrier + synchronize brackets; nothing but one pair of HIP events
+    # per step (on torch's current stream = the stream every kernel of the step is launched on) is recorded inside it
+    sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        sev[k][0].record()
         loss = step()
+        sev[k][1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(a.elapsed_time(b) for a, b in sev)
+    step_ms_median = step_ms[len(step_ms) // 2]
+    # per-kernel HIP-event timings: a SECOND pass outside the timed region (the event pairs around ~70 launches per
+    # step would otherwise sit inside it)
+    lig_jet.profile = {}
+    nprof = 2
+    unet.register_forward_pre_hook(lambda m, i: pending.append(torch.cuda.Event(enable_timing=True)) or pending[-1].record())
+    unet.register_forward_hook(_post)
+    for _ in range(nprof):
+        step()
+    sync()
     prof = lig_jet.profile
     lig_jet.profile = None
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
-    assert lig.stats["hip_jet_calls"] >= args.steps, "HIP jet path was not taken"
+    assert lig.stats["hip_jet_calls"] >= args.steps + args.warmup, "HIP jet path was not taken"
 
     # SURVEY 8(d) side figures (outside the timed region, rank 0 of a single-GPU run only): value-only inference rate,
     # the step without the UNet, and the gather stage against its algorithmic 1036 B / point
@@ -245,7 +264,7 @@ def main():
         fwd_flop_pt = 2 * 8 * (M + (5 if smooth else 3) * T)
         step_flop_pt = 3 * fwd_flop_pt
         kern = {}
-        prof["unet_fwd"] = uev[-args.steps:]
+        prof["unet_fwd"] = uev[-nprof:]
         for name, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             kern[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
@@ -273,7 +292,9 @@ def main():
                         step_algorithmic_tflops=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world, 2),
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
                                                 / PEAK_F32_TFLOPS, 4),
-                        kernels={k: round(v["total_ms"] / args.steps, 2) for k, v in sorted(kern.items())})
+                        kernels_note="ms per step of each kernel family, HIP events on the launch stream, from %d extra "
+                                     "steps run after the timed region" % nprof,
+                        kernels={k: round(v["total_ms"] / nprof, 2) for k, v in sorted(kern.items())})
         if "gather" in kern:   # the gather stage in isolation is HBM-bound: algorithmic 1036 B per point
             g_ms = kern["gather"]["avg_ms"]
             roofline["gather_stage"] = dict(bound="hbm", achieved=round(1036.0 * min(args.chunk, n_local) / (g_ms * 1e-3) / 1e9, 1),
@@ -302,6 +323,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_hip_event_median": round(step_ms_median, 3),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -155,6 +155,16 @@ typedef struct {
 /* abar / WsT_pack: HOST arrays of nlayers device pointers. */
 int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
                            const int* cell, float* dlatent, void* stream);
+/* Deterministic variant (default of the Python host): the same xbar, but the latent channels of every corner row are
+ * written to xrows [16 * ntiles][CP] (CP = C rounded up to a multiple of 4; row = 8 * point + corner) instead of being
+ * scatter-added with fp32 atomics; stpde_lig_dlatent_reduce then sums them per NODE in a fixed order (corner 0..7, points
+ * of the owning cell in ascending index), like the reference's deterministic CPU index_put_(accumulate=True) (:65-66).
+ * perm [P] = point indices in stable cell order, start [n_nodes + 1] = first position of each cell id (cell id = linear
+ * index of the cell's corner-0 node incl. batch, as written by stpde_lig_gather); dlatent is accumulated into (+=). */
+int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+                        float* xrows, void* stream);
+int stpde_lig_dlatent_reduce(int B, int n0, int n1, int n2, int C, const float* xrows, const int* perm,
+                             const int* start, float* dlatent, void* stream);
 
 /* ---- a2/a3 for any dim 1..4: plain multilinear interpolation ---------------------------------------
  * Replaces regular_nd_grid_interpolation (src/regular_nd_grid_interpolation.py:81-104) and the three outputs

@@ -142,6 +142,8 @@ _SIGNATURES = {
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
     "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),
+    "stpde_lig_xbar_rows": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP], C.c_int),
+    "stpde_lig_dlatent_reduce": ([C.c_int] * 5 + [_VP] * 5, C.c_int),
     "stpde_interp_fwd": ([C.POINTER(InterpDesc)] + [_VP] * 7, C.c_int),
     "stpde_interp_bwd_grid": ([C.POINTER(InterpDesc)] + [_VP] * 5, C.c_int),
     "stpde_conv3d_fwd": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),

@@ -360,7 +360,11 @@ struct XbarArgs {
   const float* wst[8];  // [MT_l][XT][256]
   const int* cell;
   float* dlatent;
+  float* xrows;  // != null: per-row latent adjoints [16 * ntiles][CP] instead of atomics (deterministic path)
+  int CP;        // row length of xrows = C rounded up to a multiple of 4
 };
+
+constexpr int XPAD = 49;   // padded row length (floats) of the 16 x 48 transpose patch: odd -> conflict-free columns
 
 __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
   const int lane = threadIdx.x & 63;
@@ -403,6 +407,28 @@ __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
     }
   }
   const int g = lane >> 4, j = lane & 15;
+  if (a.xrows) {
+    // deterministic path: rows x features through a per-wave LDS patch, then row-major, fully coalesced float4 stores of
+    // the latent channels (features 3 .. 3 + C - 1); the per-node sums are taken by k_dlat_reduce in a fixed order
+    __shared__ float patch[4][16 * XPAD];
+    float* pt = patch[threadIdx.x >> 6];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[j * XPAD + 16 * xt + 4 * g + r] = acc[xt][r];
+    __builtin_amdgcn_wave_barrier();
+    const int q4 = a.CP >> 2;                       // float4 groups per row
+    float* dst = a.xrows + (size_t)tile * 16 * a.CP;
+    for (int idx = lane; idx < 16 * q4; idx += 64) {
+      const int row = idx / q4, c4 = idx - row * q4;
+      const float* src = pt + row * XPAD + 3 + 4 * c4;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (4 * c4 + r < a.d.C) ? src[r] : 0.f;
+      st4(dst + (size_t)row * a.CP + 4 * c4, v);
+    }
+    return;
+  }
   const int p = tile * 2 + (j >> 3), corner = j & 7;
   const int n1 = a.d.n1, n2 = a.d.n2, C = a.d.C;
   const size_t node =
@@ -417,11 +443,32 @@ __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
     }
 }
 
+static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+                       const int* cell, float* dlatent, float* xrows, void* stream);
+
 extern "C" int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar,
                                       const float* const* WsT_pack, const int* cell, float* dlatent, void* stream) {
-  if (!d || d->ntiles <= 0 || d->nlayers < 1 || d->nlayers > 8 || d->C < 1 || 3 + d->C + 1 > 16 * XT || !abar ||
-      !WsT_pack || !cell || !dlatent) {
+  if (!cell || !dlatent) {
     stpde_set_error("lig_xbar_scatter: bad argument");
+    return STPDE_E_BADARG;
+  }
+  return launch_xbar(d, abar, WsT_pack, cell, dlatent, nullptr, stream);
+}
+
+extern "C" int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+                                   float* xrows, void* stream) {
+  if (!xrows) {
+    stpde_set_error("lig_xbar_rows: bad argument");
+    return STPDE_E_BADARG;
+  }
+  return launch_xbar(d, abar, WsT_pack, nullptr, nullptr, xrows, stream);
+}
+
+static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+                       const int* cell, float* dlatent, float* xrows, void* stream) {
+  if (!d || d->ntiles <= 0 || d->nlayers < 1 || d->nlayers > 8 || d->C < 1 || 3 + d->C + 1 > 16 * XT || !abar ||
+      !WsT_pack) {
+    stpde_set_error("lig_xbar: bad argument");
     return STPDE_E_BADARG;
   }
   XbarArgs a{};
@@ -436,6 +483,67 @@ extern "C" int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* con
   }
   a.cell = cell;
   a.dlatent = dlatent;
+  a.xrows = xrows;
+  a.CP = (d->C + 3) / 4 * 4;
   STPDE_LAUNCH(k_xbar, dim3((d->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_xbar");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Deterministic d latent: per-NODE gather of the per-row adjoints written by k_xbar (xrows), in a fixed order
+// (corner 0..7, then the points of the owning cell in ascending point index), instead of fp32 atomics.
+// The backward of the advanced-index gather at src/regular_nd_grid_interpolation.py:65-66 is an
+// index_put_(accumulate=True), which is deterministic on the reference's CPU path; so is this.
+//   perm[q]   point index of the q-th point in (stable) cell order
+//   start[c]  first q of the points whose cell (= linear index of the cell's corner-0 node, incl. batch) is c;
+//             start has n_nodes + 1 entries
+// One group of 16 lanes per node (lane = float4 of channels), 4 nodes per wave.
+// ---------------------------------------------------------------------------------------------------------
+struct DlatArgs {
+  int B, n0, n1, n2, C, CP;
+  const float* xrows;   // [8 * P][CP]   row = 8 * point + corner
+  const int* perm;
+  const int* start;
+  float* dlatent;       // [B][n0][n1][n2][C], accumulated into (+=)
+};
+
+__global__ __launch_bounds__(256) void k_dlat_reduce(DlatArgs a) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = gid & 15;
+  const size_t node = gid >> 4;
+  const size_t nnodes = (size_t)a.B * a.n0 * a.n1 * a.n2;
+  if (node >= nnodes || 4 * c4 >= a.CP) return;
+  const int i2 = node % a.n2, i1 = (node / a.n2) % a.n1, i0 = (node / ((size_t)a.n2 * a.n1)) % a.n0;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool any = false;
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const int b0 = (corner >> 2) & 1, b1 = (corner >> 1) & 1, b2 = corner & 1;
+    const int c0 = i0 - b0, c1 = i1 - b1, c2 = i2 - b2;     // the cell for which this node is corner `corner`
+    if (c0 < 0 || c1 < 0 || c2 < 0 || c0 > a.n0 - 2 || c1 > a.n1 - 2 || c2 > a.n2 - 2) continue;
+    const size_t cell = node - ((size_t)b0 * a.n1 + b1) * a.n2 - b2;
+    const int q0 = a.start[cell], q1 = a.start[cell + 1];
+    for (int q = q0; q < q1; ++q) {
+      const size_t row = (size_t)a.perm[q] * 8 + corner;
+      acc += ld4(a.xrows + row * a.CP + 4 * c4);
+      any = true;
+    }
+  }
+  if (!any) return;
+  float* dst = a.dlatent + node * a.C + 4 * c4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * c4 + r < a.C) dst[r] += acc[r];
+}
+
+extern "C" int stpde_lig_dlatent_reduce(int B, int n0, int n1, int n2, int C, const float* xrows, const int* perm,
+                                        const int* start, float* dlatent, void* stream) {
+  if (B < 1 || n0 < 2 || n1 < 2 || n2 < 2 || C < 1 || C > 64 || !xrows || !perm || !start || !dlatent) {
+    stpde_set_error("lig_dlatent_reduce: bad argument (C <= 64)");
+    return STPDE_E_BADARG;
+  }
+  DlatArgs a{B, n0, n1, n2, C, (C + 3) / 4 * 4, xrows, perm, start, dlatent};
+  const size_t n = (size_t)B * n0 * n1 * n2 * 16;
+  STPDE_LAUNCH(k_dlat_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_dlat_reduce");
 }

@@ -407,8 +407,23 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
             xd.SP[l] = SP0 if l == 0 else S
             ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
             wt[l] = pv(packs, l, "WsT").data_ptr()
-        with _timed("xbar_scatter"):
-            check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
+        if not deterministic_dlatent:
+            with _timed("xbar_scatter"):
+                check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
+        else:
+            # deterministic scatter: per-row adjoints, then a per-node gather in fixed order over the cell-sorted points
+            cp = (plan.cin + 3) // 4 * 4
+            xrows = torch.empty(Pc * 8 * cp, device=dev)
+            with _timed("xbar_scatter"):
+                check(L.stpde_lig_xbar_rows(C.byref(xd), ab, wt, ptr(xrows), st))
+                n_nodes = meta.B * meta.grid_shape[0] * meta.grid_shape[1] * meta.grid_shape[2]
+                cl = cell.long()
+                perm = torch.sort(cl, stable=True)[1].int()
+                counts = torch.zeros(n_nodes + 1, device=dev, dtype=torch.int32)
+                counts.index_add_(0, cl + 1, torch.ones(1, device=dev, dtype=torch.int32).expand(Pc))
+                start = torch.cumsum(counts, 0, dtype=torch.int32)     # start[c] = number of points in cells < c
+                check(L.stpde_lig_dlatent_reduce(meta.B, meta.grid_shape[0], meta.grid_shape[1], meta.grid_shape[2],
+                                                 plan.cin, ptr(xrows), ptr(perm), ptr(start), ptr(dlatent), st))
 
 
 class LigJetFunction(torch.autograd.Function):
@@ -483,6 +498,10 @@ def activation_name(module):
             return name, 0.0
     return None
 
+
+# d latent: per-node gather in a fixed order (bit-reproducible, like the reference's CPU index_put_ accumulate) instead of
+# fp32 atomics.  STPDE_DLATENT_ATOMIC=1 selects the atomic scatter (kept for A/B timing).
+deterministic_dlatent = os.environ.get("STPDE_DLATENT_ATOMIC", "0") != "1"
 
 DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
 

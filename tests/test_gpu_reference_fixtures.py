@@ -226,3 +226,33 @@ def test_reference_written_checkpoint_resumes_on_hip_with_fused_adam(hiplib, gol
     assert opt.param_groups[0]["clip_grad"] == float(d["clip"])
     opt.step()
     F.check_after_step(unet, net, d, 3e-4)
+
+
+def test_dlatent_is_bit_reproducible_and_matches_atomic_scatter(hiplib, monkeypatch):
+    """d loss / d latent: per-node gather in a fixed order (k_dlat_reduce) -> two runs are bit-identical (the backward
+    of the reference's index_put_(accumulate=True), regular_nd_grid_interpolation.py:65-66, is deterministic on its CPU
+    path too); the fp32-atomic scatter kept for A/B timing agrees to rounding.  Many points per cell (coarse grid, 6000
+    points, 3 chunks) so that the summation order matters."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, nonlinearities
+    g = torch.Generator().manual_seed(31)
+    lat = 0.5 * torch.randn(2, 3, 4, 5, 32, generator=g)
+    pts = torch.rand(2, 3001, 3, generator=g)                     # odd count per batch element: padded tile
+    torch.manual_seed(5)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=16,
+                             activation=nonlinearities.NONLINEARITIES["softplus"]).to(DEV)
+    cot = None
+    grads = []
+    for mode in (True, True, False):
+        monkeypatch.setattr(lig_jet, "deterministic_dlatent", mode)
+        latd = lat.to(DEV).requires_grad_(True)
+        with _lib.dispatch_trace() as tr:
+            jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, ((1, 1), (2, 2)), chunk_points=2048)
+            if cot is None:
+                cot = torch.randn(jets.shape, generator=g).to(DEV)
+            (jets * cot).sum().backward()
+            torch.cuda.synchronize()
+        assert tr.has("k_dlat_reduce") == mode
+        grads.append(latd.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert (grads[0] - grads[2]).abs().max().item() < 1e-5 * grads[0].abs().max().item()
+    assert grads[0].abs().max().item() > 0

@@ -205,10 +205,6 @@ def test_batchnorm_at_bench_volume_vs_torch_fp64(hiplib, c, relu, res):
     bnd = torch.nn.BatchNorm3d(c).to(dev)
     bnd.load_state_dict(bn.state_dict())
     bnd.train()
-    xd = x.to(dev).requires_grad_(True)
-    rd = r.to(dev).requires_grad_(True) if res else None
-    y = unet3d._bn_act(xd, bnd, relu, residual=rd)
-    (y * cot.to(dev)).sum().backward()
     x64 = x.double().requires_grad_(True)
     r64 = r.double().requires_grad_(True) if res else None
     w64, b64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
@@ -217,18 +213,20 @@ def test_batchnorm_at_bench_volume_vs_torch_fp64(hiplib, c, relu, res):
     if res:
         h = h + r64
     y64 = F.relu(h) if relu else h
+    # elements whose pre-ReLU value is within fp32 rounding of the kink may legitimately take the other branch
+    # (~1 of 16.7 M; a single one moves a weight-gradient entry by O(1) of ~10^3): their cotangent is zeroed
+    if relu:
+        cot = cot * (h.detach().abs() > 1e-5).float()
     (y64 * cot.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True) if res else None
+    y = unet3d._bn_act(xd, bnd, relu, residual=rd)
+    (y * cot.to(dev)).sum().backward()
 
     def rel(a, b):
         return (a.double().cpu() - b).abs().max().item() / b.abs().max().item()
 
-    # elements whose pre-ReLU value is within fp32 rounding of the kink may legitimately take the other branch
-    # (~1 of 16.7 M): they are excluded from the gradient comparison
-    safe = (h.detach().abs() > 1e-5) if relu else torch.ones_like(h, dtype=torch.bool)
-
-    def relm(a, b):
-        return ((a.double().cpu() - b) * safe).abs().max().item() / b.abs().max().item()
-
+    relm = rel
     assert rel(y.detach(), y64.detach()) < 1e-5
     assert rel(bnd.running_mean, rm) < 5e-5 and rel(bnd.running_var, rv) < 5e-5   # fp32 mean of 524,288 values
     assert relm(xd.grad, x64.grad) < 2e-5
@@ -308,4 +306,4 @@ def test_unet_at_config_size_hip_vs_torch_cpu(hiplib, igres):
         assert nrm(xd.grad, xc.grad) < 2e-4 and rel(xd.grad, xc.grad) < 5e-2
         for name in ("conv_in.conv2.weight", "down_modules.0.conv2.weight", "conv_out.conv3.weight", "conv_mid.conv2.weight"):
             a, b = dict(nd.named_parameters())[name].grad, dict(net.named_parameters())[name].grad
-            assert nrm(a, b) < 5e-4, name
+            assert nrm(a, b) < 3e-3, name       # kink flips (see above) accumulate in the weight gradients
