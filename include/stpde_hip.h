@@ -46,7 +46,10 @@ extern "C" {
 /* Derivative-stream configuration shared by the jet kernels. */
 typedef struct {
   int S1;        /* 0 (value only) or 3 (value + d/dr_0..2)                         */
-  int S2;        /* number of second-order streams: 0, 1 (combined, see below), 2 or 6 compiled in */
+  int S2;        /* number of second-order streams: 0, 1 (combined, see below), 2 or 6 compiled in.
+                  * S1 == 0 with S2 == 3 is the forward-only VALUE-TILE mode of stpde_jet_layer_fwd: the 4 "streams" are
+                  * the value streams of 4 consecutive row tiles (desc.ntiles counts groups of 4 tiles), which share one
+                  * pass over the weights; buffers are laid out exactly as for S1 = S2 = 0 with 4 * ntiles tiles. */
   int pair0[6];  /* second-order stream k is d2/dr_pair0[k] dr_pair1[k]             */
   int pair1[6];
   int act;       /* STPDE_ACT_*  (src/nonlinearities.py:15-22)                       */

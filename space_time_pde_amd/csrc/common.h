@@ -137,9 +137,18 @@ __device__ __forceinline__ float sel3(int d, float a0, float a1, float a2) { ret
 // Forward jet of the activation on one fragment block: pre[S] (a, adot_d, addot_p) -> h[S].
 // S2 == 1 is the COMBINED second-order stream: cq[0..5] = per-row weights of adot_a*adot_b over the canonical pairs
 // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2); otherwise cq is unused.
+// S1 == 0 && S2 > 0 is the VALUE-TILE mode of the forward-only (inference) kernels: the 1 + S2 "streams" are the value
+// streams of 1 + S2 independent, consecutive row tiles that share one pass over the weights.
 template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h,
                                             const float* cq = nullptr) {
+  if (S1 == 0 && S2 > 0) {
+#pragma unroll
+    for (int st = 0; st < 1 + S2; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[st][r] = act_eval<ACT>(cfg.act, cfg.act_param, pre[st][r]).s0;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);

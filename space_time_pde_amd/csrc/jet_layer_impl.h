@@ -53,17 +53,21 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 // pre-activations; dgrad = activation-jet adjoint against the stored / regenerated pre-activations + R-image copies.
 template <int S1, int S2, int EPI, int ACT>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
-                                               const f32x4* xb, const float* cq, float& pacc) {
+                                               const f32x4 (*xbv)[XT], const float* cq, float& pacc) {
   constexpr int S = 1 + S1 + S2;
+  constexpr bool VT = S1 == 0 && S2 > 0;     // value-tile mode: every stream is the value stream of its own row tile
   const int lo = lane * 4;
   f32x4 (&acc)[1][S] = *reinterpret_cast<f32x4 (*)[1][S]>(accm);
+  const f32x4* xb = xbv[0];
   constexpr int mi = 0;
     if (EPI == EPI_FWD) {
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) {
         f32x4 w = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mi][0] = mfma4(w[r], xb[xt][r], acc[mi][0]);
+        for (int sv = 0; sv < (VT ? S : 1); ++sv)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][sv] = mfma4(w[r], xbv[sv][xt][r], acc[mi][sv]);
       }
       if (S1 == 3) {
 #pragma unroll
@@ -115,10 +119,14 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
   float pacc = 0.f;
 
-  f32x4 xb[XT];
+  constexpr bool VT = S1 == 0 && S2 > 0;
+  constexpr int NX = VT ? S : 1;             // value-tile mode: one raw-input tile per stream
+  f32x4 xb[NX][XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+    for (int sv = 0; sv < NX; ++sv)
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
   }
   const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
 
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   // raw (un-activated) B block and weight blocks of k-tile kt
   auto load_raw = [&](int kt, f32x4* raw) {
     if (PRO == PRO_L0) {
-      raw[0] = layer0_block(a.W0s, KT, kt, lo, xb);
+#pragma unroll
+      for (int sv = 0; sv < NX; ++sv) raw[sv] = layer0_block(a.W0s, KT, kt, lo, xb[sv]);
       if (S1 == 3) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
@@ -237,10 +246,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
   float pacc = 0.f;
 
-  f32x4 xb[XT];
+  constexpr bool VT = S1 == 0 && S2 > 0;
+  constexpr int NX = VT ? S : 1;             // value-tile mode: one raw-input tile per stream
+  f32x4 xb[NX][XT];
   if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+    for (int sv = 0; sv < NX; ++sv)
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
   }
   const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
 
@@ -248,7 +261,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   auto produce = [&](int kt, int buf, int slot) {
     f32x4 raw[S], B[S];
     if (PRO == PRO_L0) {
-      raw[0] = layer0_block(a.W0s, KT, kt, lo, xb);
+#pragma unroll
+      for (int sv = 0; sv < NX; ++sv) raw[sv] = layer0_block(a.W0s, KT, kt, lo, xb[sv]);
       if (S1 == 3) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
@@ -451,11 +465,18 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
 // mode: 0 = fwd (hidden input from stash), 1 = fwd first hidden (layer 0 on the fly), 2 = dgrad, 3 = dgrad into layer 0
 template <int S1, int S2>
 static int launch_mode(const LayerArgs& a, int mode, hipStream_t stream) {
-  switch (mode) {
-    case 0: return launch_fwd_act<S1, S2, PRO_ACT, EPI_FWD>(a, stream);
-    case 1: return launch_fwd_act<S1, S2, PRO_L0, EPI_FWD>(a, stream);
-    case 2: return launch_fwd_act<S1, S2, PRO_NONE, EPI_ADJ>(a, stream);
-    default: return launch_fwd_act<S1, S2, PRO_NONE, EPI_ADJ_L0>(a, stream);
+  if constexpr (S1 == 0 && S2 > 0) {   // value-tile mode is forward-only (inference)
+    if (mode == 0) return launch_fwd_act<S1, S2, PRO_ACT, EPI_FWD>(a, stream);
+    if (mode == 1) return launch_fwd_act<S1, S2, PRO_L0, EPI_FWD>(a, stream);
+    stpde_set_error("value-tile stream configuration (S1 = 0, S2 > 0) has no backward kernels");
+    return STPDE_E_UNSUPPORTED;
+  } else {
+    switch (mode) {
+      case 0: return launch_fwd_act<S1, S2, PRO_ACT, EPI_FWD>(a, stream);
+      case 1: return launch_fwd_act<S1, S2, PRO_L0, EPI_FWD>(a, stream);
+      case 2: return launch_fwd_act<S1, S2, PRO_NONE, EPI_ADJ>(a, stream);
+      default: return launch_fwd_act<S1, S2, PRO_NONE, EPI_ADJ_L0>(a, stream);
+    }
   }
 }
 
@@ -467,3 +488,4 @@ int stpde_layer_launch_3_0(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_1(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_2(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_6(const LayerArgs& a, int mode, hipStream_t stream);
+int stpde_layer_launch_0_3(const LayerArgs& a, int mode, hipStream_t stream);   // value-tile mode: 4 row tiles per pass

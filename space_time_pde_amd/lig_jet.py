@@ -340,11 +340,19 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     bufs = [None]
     pv = plan.pack_view
     prev = None
+    # forward-only value queries (inference): VALUE-TILE kernels -- four consecutive row tiles share one pass over the
+    # weights (the weight operand is what bounds a one-stream pass); same buffers, a quarter of the "tiles"
+    vt = S == 1 and not need_grad and not meta.packs16 and nt % 4 == 0 and value_tiles
+    lcfg, lnt = cfg, nt
+    if vt:
+        lcfg = JetCfg()
+        lcfg.S1, lcfg.S2, lcfg.act, lcfg.act_param = 0, 3, cfg.act, cfg.act_param
+        lnt = nt // 4
     for l in range(1, 6):
         lay = plan.layers[l]
         out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
         w16 = meta.packs16.get((l, "Wh")) if meta.packs16 else None
-        d = _layer_desc(nt, lay, cfg, l == 1, w16 is not None)
+        d = _layer_desc(lnt, lay, lcfg, l == 1, w16 is not None)
         with _timed("layer%d_fwd" % l):
             check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")),
                                         ptr(pv(packs, l, "Ws")), ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")),
@@ -437,7 +445,9 @@ class LigJetFunction(torch.autograd.Function):
         meta.packs16 = meta.plan.pack_bf16(packs) if meta.bf16 else None
         P = pts.shape[0]
         jets = torch.empty(meta.S_out, meta.plan.cout, P, device=pts.device)
-        need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        # grad mode is always off inside Function.forward and ctx.needs_input_grad ignores torch.no_grad(): whether a
+        # backward can follow was decided by lig_jets() before apply()
+        need_grad = meta.need_grad and any(ctx.needs_input_grad)
         saved = []
         chunk = meta.chunk
         for p0 in range(0, P, chunk):
@@ -502,6 +512,8 @@ def activation_name(module):
 # d latent: per-node gather in a fixed order (bit-reproducible, like the reference's CPU index_put_ accumulate) instead of
 # fp32 atomics.  STPDE_DLATENT_ATOMIC=1 selects the atomic scatter (kept for A/B timing).
 deterministic_dlatent = os.environ.get("STPDE_DLATENT_ATOMIC", "0") != "1"
+# forward-only value queries use the value-tile kernels (4 row tiles per weight pass); STPDE_VALUE_TILES=0 = one tile
+value_tiles = os.environ.get("STPDE_VALUE_TILES", "1") != "0"
 
 DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
 
@@ -573,15 +585,19 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     if P == 0:   # empty query set: nothing to launch (the reference returns an empty [b, 0, o] tensor as well)
         return torch.zeros(meta.S_out, plan.cout, 0, device=query_pts.device), ppairs
     pts = query_pts.detach().reshape(P, 3).contiguous()
-    pad = P & 1
+    # tiles hold 2 points; value-only queries are padded to 8 points (4 tiles) for the value-tile kernels
+    mult = 8 if meta.S == 1 else 2
+    pad = (-P) % mult
     if pad:
-        pts = torch.cat([pts, pts[-1:]], 0)
+        pts = torch.cat([pts, pts[-1:].expand(pad, 3)], 0)
     meta.P_pad = P + pad
-    meta.chunk = max(2, (chunk_points or DEFAULT_CHUNK) & ~1)
+    meta.chunk = max(mult, (chunk_points or DEFAULT_CHUNK) // mult * mult)
     lat = latent_grid.contiguous()
     params = []
     for k in range(6):
         params += [imnet.fc[k].weight, imnet.fc[k].bias]
+    meta.need_grad = torch.is_grad_enabled() and (lat.requires_grad or any(p.requires_grad for p in params)
+                                                  or (prm_tensor is not None and prm_tensor.requires_grad))
     jets = LigJetFunction.apply(meta, lat, pts, prm_tensor, *params)
     if pad:
         jets = jets[:, :, :P]

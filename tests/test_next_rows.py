@@ -134,3 +134,55 @@ def test_device_loader_generic_cpu():
 @pytest.mark.gpu
 def test_device_loader_hip(hiplib):
     _check_loader_against_scipy("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ["softplus", "leakyrelu"])
+def test_lattice_inference_matches_oracle_incl_tie_points(hiplib, act):
+    """N2 (evaluation.py:26-74, train.py:135-166): values and all RB2 residuals on a structured lattice whose end points
+    are exactly the clip bounds ``linspace(eps, 1 - eps, n)`` (train.py:136-139: clip ties -> half derivatives, quirk
+    a-Q2) against the CPU oracle (reverse-sweep restatement of the reference), and the value-only query on the same
+    lattice through the value-tile kernels."""
+    from oracle import cpu_ref as O
+    from space_time_pde_amd import _lib, lig_jet, nonlinearities
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    net = implicit_net.ImNet(nf=32, activation=nonlinearities.NONLINEARITIES[act]).to(dev)
+    g = torch.Generator().manual_seed(3)
+    lat = 0.5 * torch.randn(1, 4, 6, 7, 32, generator=g)
+    mean, std = (0.01, 0.0, 0.02, -0.01), (0.05, 0.3, 0.15, 0.12)
+    kw = dict(mean=mean, std=std, t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
+    eps = 1e-6
+    t, z, x = torch.linspace(eps, 1 - eps, 5), torch.linspace(eps, 1 - eps, 9), torch.linspace(eps, 1 - eps, 13)
+    latd = lat.to(dev)
+    layer = physics.get_rb2_pde_layer(**kw)
+    layer.update_forward_method(lambda p: lig.query_local_implicit_grid(net, latd, p, 0., 1.))
+    n0 = lig.stats["hip_jet_calls"]
+    res = inference.evaluate_feat_grid(layer, latd, t, z, x, None, None, pseudo_batch_size=200)
+    assert lig.stats["hip_jet_calls"] >= n0 + 3
+    coord = torch.stack(torch.meshgrid(t, z, x, indexing="ij"), -1).reshape(1, -1, 3)
+    params = [(net.fc[k].weight.detach().cpu(), net.fc[k].bias.detach().cpu()) for k in range(6)]
+    out = O.lig_pde_step(params, act, lat, coord, torch.zeros(1, coord.shape[1], 4), O.rb2_oracle(**kw), backward=False)
+    for cid, name in enumerate(("p", "b", "u", "w")):
+        ref = out["pred"][0, :, cid].reshape(5, 9, 13).numpy()
+        assert np.abs(res[name] - ref).max() < 2e-5 * np.abs(out["pred"]).max().item(), name
+    for name, v in out["residues"].items():
+        ref = v[0, :, 0].reshape(5, 9, 13).numpy()
+        err = np.abs(res[name] - ref) / np.abs(ref).max()
+        # piecewise-linear activation: kink flips move single lattice points (SURVEY a-Q8)
+        assert np.median(err) < 1e-5 and (err < (1e-3 if act == "leakyrelu" else 1e-4)).mean() > (0.97 if act == "leakyrelu" else 0.999), name
+    # value-only query of the same lattice: value-tile kernels (4 row tiles per weight pass), bit-identical to one tile
+    pts = coord.to(dev)
+    with torch.no_grad(), _lib.dispatch_trace() as tr:
+        y4 = lig.query_local_implicit_grid(net, latd, pts, 0., 1.)
+        torch.cuda.synchronize()
+    assert tr.has("S1 = 0, S2 = 3"), "\n".join(tr.kernels)
+    assert np.abs(y4[0].cpu().numpy() - out["pred"][0].numpy()).max() < 2e-5 * np.abs(out["pred"]).max().item()
+    prev = lig_jet.value_tiles
+    try:
+        lig_jet.value_tiles = False
+        with torch.no_grad():
+            y1 = lig.query_local_implicit_grid(net, latd, pts, 0., 1.)
+    finally:
+        lig_jet.value_tiles = prev
+    assert torch.equal(y1, y4)

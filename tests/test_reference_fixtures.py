@@ -126,7 +126,10 @@ def check_c1_step(d, act, unet, net, loss, reg, pde, pred, res, latent, slack=3.
     for name, a32, a64 in zip(names, n32, n64):
         g = got[str(name)]
         assert g is not None, name
-        floor = med32 if str(name).startswith("unet.") else 2e-4
+        # IM-NET gradients inherit the ~1e-3 fp32 noise of the latent grid (which depends on the host's thread count:
+        # the same fp32 U-Net run with 1 and with 8 threads differs by that much), although the reference's own fp32 run
+        # on the fixture's machine happens to sit within 1e-6 of its fp64 one
+        floor = med32 if str(name).startswith("unet.") else 1e-3
         lim = slack * max(abs(a32 - a64), floor * a64) + 1e-6 * n64.max()
         if abs(g.norm().item() - a64) > lim:
             bad.append((str(name), g.norm().item(), float(a64), float(a32)))
@@ -137,7 +140,7 @@ def check_c1_step(d, act, unet, net, loss, reg, pde, pred, res, latent, slack=3.
                 g64 = d[key.replace("grad/", "grad_f64/")]
                 if np.abs(g64).max() < 1e-12:      # bias in front of a training-mode BatchNorm: exactly zero gradient
                     continue
-                lim = slack * dist(d[key], g64) + 2e-4
+                lim = slack * max(dist(d[key], g64), med32 if key.startswith("grad/unet.") else 1e-3) + 2e-4
                 assert dist(got[key[5:]].detach().cpu(), g64) < lim, key
             if key.startswith("after/"):
                 a64 = d[key.replace("after/", "after_f64/")]
