@@ -118,12 +118,16 @@ int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const fl
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when
  * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise.
+ * abar0_tan (first_hidden, S1 == 3; may be NULL): layer 0's tangent streams are the constant columns W0[:, d], so their
+ * adjoints are needed only summed over rows; when given, abar0 receives the VALUE stream only ([tile][KT][256]) and
+ * abar0_tan [tile][KT][3][16] the per-tile row sums of the three tangent-stream adjoints (a quarter of the traffic);
+ * stpde_jet_tan0_reduce adds them into d W0[:, d].
  * act_param_bar (swish only, may be NULL): STPDE_PBAR_SLOTS (64) floats that ACCUMULATE partial sums of the adjoint of
  * the learnable beta (src/nonlinearities.py:5-12); the caller zero-fills them and adds the slots up. */
 int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
                         const float* X, const float* W0s_pack, const float* tanc0, float* abar0, const float* cw,
                         float* act_param_bar, const void* WhT_pack_bf16 /* as Wh_pack_bf16, of WhT_pack */,
-                        void* stream);
+                        float* abar0_tan, void* stream);
 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
@@ -146,6 +150,9 @@ int stpde_lig_reduce_fwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, 
                          const float* coef, float* jets, long ldp, void* stream);
 int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, const float* jets_bar, long ldp,
                          const float* coef, float* abar_out, void* stream);
+
+/* dW_aug[16*MT][ldw] (layer 0: ldw = 16 * XT) column d  +=  sum over tiles of abar0_tan[tile][mt][d][:]. */
+int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, void* stream);
 
 /* ---- backward of the gather: d latent (index_put accumulate, backward of :65-66) --------------------
  * xbar = sum_l W_s,l^T * abar_l(value stream); latent channels are scatter-added into dlatent

@@ -137,7 +137,8 @@ _SIGNATURES = {
     "stpde_trace_read": ([C.c_char_p, C.c_ulong], C.c_long),
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
     "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
-    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
+    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 12, C.c_int),
+    "stpde_jet_tan0_reduce": ([C.c_int, C.c_int, _VP, _VP, C.c_int, _VP], C.c_int),
     "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 9, C.c_int),
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
     "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),

@@ -250,6 +250,20 @@ __device__ __forceinline__ float swish_beta_adj(const stpde_jet_cfg& cfg, const 
   return sum;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15 = the 16 rows of a fragment block for one feature group):
+// four v_add_f32 with row_shr DPP modifiers; lane 16g+15 ends up with the full sum.
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_row_shr<1>(v);
+  v += dpp_row_shr<2>(v);
+  v += dpp_row_shr<4>(v);
+  v += dpp_row_shr<8>(v);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -72,7 +72,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
                                    float* abar0, const float* cw, float* act_param_bar,
-                                   const void* WhT_pack_bf16, void* stream) {
+                                   const void* WhT_pack_bf16, float* abar0_tan, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -99,6 +99,7 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
       return STPDE_E_BADARG;
     }
     a.Out = abar0;
+    a.Tan0 = abar0_tan;
     return dispatch_streams(a, 3, (hipStream_t)stream);
   }
   if (!in_pre) {

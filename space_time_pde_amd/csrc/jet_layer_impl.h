@@ -30,6 +30,8 @@ struct LayerArgs {
   const float* cw;     // [P][8] per-point weights of the combined second-order stream (S2 == 1), else unused
   const void* Wp16;    // [KT/2][MT][64] x 8 bf16: A operand of the bf16-MFMA variant (two k-tiles per block), or null
   float* pbar;         // dgrad, swish only: [STPDE_PBAR_SLOTS] accumulators of the adjoint of beta (nullable)
+  float* Tan0;         // EPI_ADJ_L0, nullable: [tile][MT][3][16] row sums of the tangent-stream adjoints of layer 0; when
+                       // given, Out holds the VALUE stream only: [tile][MT][256]
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   stpde_jet_cfg cfg;
@@ -93,8 +95,25 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
       if ((ACT == STPDE_ACT_SWISH || (ACT < 0 && a.cfg.act == STPDE_ACT_SWISH)) && a.pbar)
         pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc[mi], cq);
       constexpr int SO = (EPI == EPI_ADJ) ? S : 1 + S1;
+      if (EPI == EPI_ADJ_L0 && S1 == 3 && a.Tan0) {
+        // Layer 0's tangent streams are the constant columns W0[:, d], so their adjoints enter d W0[:, d] only through
+        // their sum over rows: reduce over the 16 rows of the tile here (DPP row reduction) and write 48 floats per
+        // (tile, output tile) instead of three 1 KiB blocks -- the layer-0 adjoint shrinks to its value stream.
+        st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
+        f32x4 ts[3];
 #pragma unroll
-      for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ts[d][r] = row_sum16(ab[1 + d][r]);
+        if ((lane & 15) == 15) {
+          float* tp = a.Tan0 + ((size_t)tile * MT + mt) * 48 + 4 * (lane >> 4);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) st4(tp + 16 * d, ts[d]);
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
+      }
     }
 }
 

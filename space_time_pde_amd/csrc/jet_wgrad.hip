@@ -48,3 +48,26 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   }
   return dispatch_streams(a, 0, (hipStream_t)stream);
 }
+
+
+// d W0[:, d] += sum over tiles of the row-reduced tangent-stream adjoints of layer 0 (written by the layer-1 dgrad
+// epilogue): [tile][MT][3][16] -> one column per d.  Grid-stride partial sums, one atomic per (block, element).
+__global__ __launch_bounds__(256) void k_tan0_reduce(const float* tan, float* dW, int ntiles, int MT, int ldw) {
+  const int n = MT * 48;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    float s = 0.f;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) s += tan[(size_t)t * n + e];
+    const int mt = e / 48, d = (e % 48) / 16, f = e % 16;
+    atomicAdd(dW + (size_t)(16 * mt + f) * ldw + d, s);
+  }
+}
+
+extern "C" int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, void* stream) {
+  if (ntiles <= 0 || MT <= 0 || !abar0_tan || !dW_aug || ldw < 3) {
+    stpde_set_error("jet_tan0_reduce: bad argument");
+    return STPDE_E_BADARG;
+  }
+  int grid = ntiles < 1024 ? ntiles : 1024;
+  STPDE_LAUNCH(k_tan0_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, abar0_tan, dW_aug, ntiles, MT, ldw);
+  return stpde_check_launch("k_tan0_reduce");
+}

@@ -382,7 +382,12 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     with _timed("reduce_bwd"):
         check(L.stpde_lig_reduce_bwd(C.byref(meta.cfg_out), S, Pc, plan.cout, C.c_void_p(jets_bar.data_ptr() + 4 * p0),
                                      jets_bar.shape[2], ptr(coef), ptr(bufs[5]), st))
-    abar0 = torch.empty(nt * SP0 * plan.layers[0]["MT"] * _FRAG, device=dev)
+    # layer-0 adjoint: the value stream as fragment blocks; the three tangent streams only as per-tile row sums (their
+    # layer-0 "input" is the constant column W0[:, d], so only sum_rows matters): 32 + 6 KB per tile instead of 128 KB
+    MT0 = plan.layers[0]["MT"]
+    split0 = SP0 == 4 and tan0_rowsum
+    abar0 = torch.empty(nt * (1 if split0 else SP0) * MT0 * _FRAG, device=dev)
+    tan0 = torch.empty(nt * MT0 * 48, device=dev) if split0 else None
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
@@ -396,14 +401,21 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), ptr(w16), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), ptr(w16),
+                                        ptr(tan0) if l == 1 else None, st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
         off, mp, ka = plan.dw_off[0]
         with _timed("layer0_wgrad"):
-            check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), ptr(XR), None, None,
-                                    ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
+            if split0:
+                d.cfg = meta.cfg_val      # value stream x raw input (the S = 1 weight-gradient kernels)
+                check(L.stpde_jet_wgrad(C.byref(d), 1, ptr(abar0), None, ptr(X), ptr(XR), None, None,
+                                        ptr(dw_flat[off:off + mp * ka]), None, st))
+                check(L.stpde_jet_tan0_reduce(nt, MT0, ptr(tan0), ptr(dw_flat[off:off + mp * ka]), ka, st))
+            else:
+                check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), ptr(XR), None, None,
+                                        ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
     if dlatent is not None:
         xd = XbarDesc()
         xd.ntiles, xd.nlayers, xd.C = nt, 5, plan.cin
@@ -412,7 +424,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         wt = (C.c_void_p * 5)()
         for l in range(5):
             xd.MT[l] = plan.layers[l]["MT"]
-            xd.SP[l] = SP0 if l == 0 else S
+            xd.SP[l] = (1 if split0 else SP0) if l == 0 else S
             ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
             wt[l] = pv(packs, l, "WsT").data_ptr()
         if not deterministic_dlatent:
@@ -514,6 +526,8 @@ def activation_name(module):
 deterministic_dlatent = os.environ.get("STPDE_DLATENT_ATOMIC", "0") != "1"
 # forward-only value queries use the value-tile kernels (4 row tiles per weight pass); STPDE_VALUE_TILES=0 = one tile
 value_tiles = os.environ.get("STPDE_VALUE_TILES", "1") != "0"
+# layer-0 tangent-stream adjoints as per-tile row sums (STPDE_TAN0_ROWSUM=0: full fragment blocks, for A/B timing)
+tan0_rowsum = os.environ.get("STPDE_TAN0_ROWSUM", "1") != "0"
 
 DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
 
@@ -581,6 +595,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.grid_shape = tuple(latent_grid.shape[1:4])
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)
     meta.need_wgrad = True
+    meta.cfg_val = make_cfg(act, prm, False, [])[0]
     P = B * N
     if P == 0:   # empty query set: nothing to launch (the reference returns an empty [b, 0, o] tensor as well)
         return torch.zeros(meta.S_out, plan.cout, 0, device=query_pts.device), ppairs

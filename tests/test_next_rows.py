@@ -169,8 +169,11 @@ def test_lattice_inference_matches_oracle_incl_tie_points(hiplib, act):
     for name, v in out["residues"].items():
         ref = v[0, :, 0].reshape(5, 9, 13).numpy()
         err = np.abs(res[name] - ref) / np.abs(ref).max()
-        # piecewise-linear activation: kink flips move single lattice points (SURVEY a-Q8)
-        assert np.median(err) < 1e-5 and (err < (1e-3 if act == "leakyrelu" else 1e-4)).mean() > (0.97 if act == "leakyrelu" else 0.999), name
+        # the fp32 oracle (reverse sweeps) is itself ~1e-4 off its fp64 value per point (SURVEY a-Q8: 1.7e-4 softplus,
+        # 1.4e-3 leaky-relu kink flips), and it has to run in fp32 here so that the clip ties are the same ties
+        assert np.median(err) < 1e-5 and (err < 1e-3).mean() > 0.97, name
+        if act == "softplus":
+            assert err.max() < 5e-3, name
     # value-only query of the same lattice: value-tile kernels (4 row tiles per weight pass), bit-identical to one tile
     pts = coord.to(dev)
     with torch.no_grad(), _lib.dispatch_trace() as tr:

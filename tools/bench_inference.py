@@ -1,0 +1,56 @@
+"""Per-kernel timing of the forward-only paths (value-only query and values + RB2 residuals) on 2^20 points of the
+BASELINE configs[1] latent grid: python tools/bench_inference.py [--points N] [--act softplus]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=1 << 20)
+    ap.add_argument("--act", default="softplus")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES[args.act]).to(dev)
+    g = torch.Generator().manual_seed(0)
+    latent = (0.5 * torch.randn(1, 32, 128, 128, 32, generator=g)).to(dev)
+    pts = torch.rand(1, args.points, 3, generator=g).to(dev)
+    layer = physics.get_rb2_pde_layer(mean=(0.01, 0.0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                      x_crop=1., use_continuity=True)
+    layer.update_forward_method(lambda q: lig.query_local_implicit_grid(net, latent, q, 0., 1.))
+    out = {}
+    for name, fn in (("value_only", lambda: lig.query_local_implicit_grid(net, latent, pts, 0., 1.)),
+                     ("values_and_residuals", lambda: layer(pts, return_residue=True))):
+        with torch.no_grad():
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.reps
+            lig_jet.profile = {}
+            fn()
+            torch.cuda.synchronize()
+            kern = {k: round(sum(a.elapsed_time(b) for a, b in v), 3) for k, v in lig_jet.profile.items()}
+            lig_jet.profile = None
+        flop_pt = 2 * 8 * 208928 if name == "value_only" else 2 * 8 * (208928 + (4 if args.act in ("softplus", "tanh", "elu", "swish") else 3) * 174208)
+        out[name] = dict(ms=round(ms, 3), points_per_s=round(args.points / ms * 1e3), kernels_ms=kern,
+                         executed_tflops=round(flop_pt * args.points / ms / 1e9, 1))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
