@@ -81,29 +81,45 @@ def _source_hash(paths):
     return h.hexdigest()
 
 
+def _includes(path, seen=None):
+    """Project headers (``#include "..."``) a source file pulls in, transitively."""
+    import re
+    seen = set() if seen is None else seen
+    out = []
+    try:
+        text = open(path).read()
+    except OSError:
+        return out
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', text, re.M):
+        h = os.path.normpath(os.path.join(os.path.dirname(path), m.group(1)))
+        if h not in seen and os.path.exists(h):
+            seen.add(h)
+            out.append(h)
+            out += _includes(h, seen)
+    return out
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into libstpde_hip.so (cross-compiles without a GPU).
 
     Staleness is decided by a content hash of all sources / headers / flags stored next to the library (not by file
     times, which a copy of the tree to another machine may not preserve)."""
     srcs = _sources()
-    hdrs = [os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "jet_layer_impl.h"),
-            os.path.join(_CSRC, "jet_wgrad_impl.h"), os.path.join(_HERE, "..", "include", "stpde_hip.h")]
-    deps = srcs + hdrs
+    inc = os.path.join(_HERE, "..", "include", "stpde_hip.h")
+    deps = sorted(set(srcs) | {h for s_ in srcs for h in _includes(s_)})
     stamp = LIB_PATH + ".srchash"
     want = _source_hash([p for p in deps if os.path.exists(p)])
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     objdir = os.path.join(_CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdr_hash = _source_hash([p for p in hdrs if os.path.exists(p)])
     procs = []
     objs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         ostamp = o + ".srchash"
-        owant = _source_hash([s]) + hdr_hash
+        owant = _source_hash([s] + _includes(s))        # the source and exactly the headers it (transitively) includes
         if not force and os.path.exists(o) and os.path.exists(ostamp) and open(ostamp).read().strip() == owant:
             continue
         flags = _HIPFLAGS if s.endswith(".hip") else ["-O3", "-std=c++17", "-fPIC"]

@@ -52,12 +52,15 @@ struct ActD {
   float s0, s1, s2, s3;
 };
 
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }          // v_exp_f32 path, ~2 ulp
+// Hardware transcendentals only (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each): no library call sequences, whose
+// denormal handling costs ~10 extra instructions and makes the compiler wrap them in a divergent branch -- the activation
+// jets must stay straight-line code inside the MFMA basic blocks so that the scheduler can interleave them with MFMAs.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
-// log(1 + e) for e in [0, 1]: series below 2^-10 (where log(1+e) would cancel), v_log_f32 above
+// log(1 + e) for e in [0, 1]: series below 2^-10 (where log(1+e) would cancel), v_log_f32 above (argument in [1, 2])
 __device__ __forceinline__ float log1p_unit(float e) {
   const float u = 1.f + e;
-  const float big = __logf(u);
+  const float big = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
   const float small = e * (1.f - e * (0.5f - e * 0.33333334f));
   return e < 9.765625e-4f ? small : big;
 }
@@ -92,7 +95,9 @@ __device__ __forceinline__ ActD act_eval_t(float prm, float a) {
     const float s = a >= 0.f ? inv : e * inv;   // sigmoid(a)
     const float q = e * inv * inv;              // s (1 - s)
     const bool big = a > 20.f;                  // torch threshold
-    r.s0 = big ? a : fmaxf(a, 0.f) + log1p_unit(e);
+    // above the threshold e < 2.1e-9, so max(a, 0) + log1p(e) rounds to a exactly: no select on the value (a select
+    // with the log on one side makes the compiler emit a divergent branch, which splits the MFMA basic block)
+    r.s0 = fmaxf(a, 0.f) + log1p_unit(e);
     r.s1 = big ? 1.f : s;
     r.s2 = big ? 0.f : q;
     r.s3 = big ? 0.f : q * (1.f - 2.f * s);

@@ -17,6 +17,12 @@
 
 enum { PRO_NONE = 0, PRO_ACT = 1, PRO_L0 = 2 };
 enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
+// Timing-only ablations of the cooperative kernel (tools/micro/ablate_layer.py builds a private library with
+// -DSTPDE_ABLATE=n; results are WRONG by construction): 1 = no activation jet in the produce stage, 2 = no barrier in the
+// main loop, 3 = weight fragments always from k-tile 0 (L1-resident), 4 = no epilogue, 5 = no produce stage in the loop.
+#ifndef STPDE_ABLATE
+#define STPDE_ABLATE 0
+#endif
 
 struct LayerArgs {
   const float* Bin;    // [tile][S][KT][256] B-operand source (pre-activations or adjoints)
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
       for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT + kt) * 256);
     }
-    if (PRO == PRO_NONE) {
+    if (PRO == PRO_NONE || STPDE_ABLATE == 1) {
 #pragma unroll
       for (int st = 0; st < S; ++st) B[st] = raw[st];
     } else {
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int kt = 4 * gi + q;
-          const int ktn = kt + 3 < KT ? kt + 3 : KT - 1;
+          const int ktn = STPDE_ABLATE == 3 ? (q & 1) : (kt + 3 < KT ? kt + 3 : KT - 1);
           f32x4 B[S];
 #pragma unroll
           for (int st = 0; st < S; ++st) B[st] = ld4(&hb[buf][q][st][lo]);
@@ -387,8 +393,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
-      produce_group(gi + 1 < ngroups ? gi + 1 : gi, buf ^ 1);
-      __syncthreads();
+      if (STPDE_ABLATE != 5) produce_group(gi + 1 < ngroups ? gi + 1 : gi, buf ^ 1);
+      if (STPDE_ABLATE != 2) __syncthreads();
+    }
+    if (STPDE_ABLATE == 4) {     // keep the accumulators alive without the epilogue
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+        for (int st = 0; st < S; ++st) sum += acc[mi][st];
+      if (sum[0] == 12345.678f) st4(a.Out + lo, sum);
+      continue;
     }
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)

@@ -1,0 +1,95 @@
+"""Timing-only ablations of the layer-1 kernels (forward / dgrad, S = (3,1) softplus, nf = 32): builds private copies of
+the layer library with -DSTPDE_ABLATE=n (see jet_layer_impl.h) and times stpde_jet_layer_fwd / _bwd on random buffers.
+
+    python tools/micro/ablate_layer.py build      # here (no GPU): compiles tools/micro/_abl/libabl_<n>.so
+    python tools/micro/ablate_layer.py run        # on the GPU box
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "space_time_pde_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "micro", "_abl")
+VARIANTS = [0, 1, 2, 3, 4, 5]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    procs = []
+    for n in VARIANTS:
+        so = os.path.join(OUT, "libabl_%d.so" % n)
+        srcs = [os.path.join(CSRC, f) for f in ("jet_layer.hip", "jet_layer_s31.hip", "api.cpp")]
+        # the other stream configurations are stubbed out: only (3,1) is timed
+        stub = os.path.join(OUT, "stub.cpp")
+        open(stub, "w").write('#include <hip/hip_runtime.h>\nstruct LayerArgs;\n' + "".join(
+            "int stpde_layer_launch_%s(const LayerArgs&, int, hipStream_t) { return 2; }\n" % k
+            for k in ("0_0", "0_3", "3_0", "3_2", "3_6")))
+        cmd = ["hipcc"] + FLAGS + ["-DSTPDE_ABLATE=%d" % n, "-shared", "-o", so] + srcs + [stub]
+        procs.append((n, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for n, p in procs:
+        out, _ = p.communicate()
+        print("variant", n, "rc", p.returncode, out.decode()[-300:] if p.returncode else "")
+
+
+def run():
+    import torch
+    from space_time_pde_amd import _lib
+    from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
+    dev = torch.device("cuda:0")
+    plan = ImNetPlan.get(3, 32, 4, 32)
+    nt = 1 << 17                                  # 2^18 points
+    cfg, S, _ = make_cfg("softplus", 0.0, True, [], {(1, 1): 1.0, (2, 2): 0.25})
+    torch.manual_seed(0)
+    packs = 0.05 * torch.randn(plan.n_pack, device=dev)
+    X = torch.randn(nt * 3 * 256, device=dev)
+    cw = torch.rand(nt * 2 * 8, device=dev)
+    lay = plan.layers[1]
+    out1 = torch.empty(nt * S * lay["MT"] * 256, device=dev)
+    abar0 = torch.empty(nt * 4 * plan.layers[0]["MT"] * 256, device=dev)
+    tan0 = torch.empty(nt * plan.layers[0]["MT"] * 48, device=dev)
+    pv = plan.pack_view
+    res = {}
+    for n in VARIANTS:
+        so = os.path.join(OUT, "libabl_%d.so" % n)
+        if not os.path.exists(so):
+            continue
+        L = C.CDLL(so)
+        L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 11
+        L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
+        d = _lib.LayerDesc()
+        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, 0
+        st = _lib.stream_ptr()
+        p = _lib.ptr
+
+        def fwd():
+            return L.stpde_jet_layer_fwd(C.byref(d), None, p(X), p(pv(packs, 1, "Wh")), p(pv(packs, 1, "Ws")),
+                                         p(pv(packs, 1, "tanc")), p(pv(packs, 0, "Ws")), p(pv(packs, 0, "tanc")), p(out1),
+                                         p(cw), None, st)
+
+        def bwd():
+            return L.stpde_jet_layer_bwd(C.byref(d), p(out1), p(pv(packs, 1, "WhT")), None, p(X), p(pv(packs, 0, "Ws")),
+                                         p(pv(packs, 0, "tanc")), p(abar0), p(cw), None, None, p(tan0), st)
+
+        for name, fn in (("fwd", fwd), ("dgrad", bwd)):
+            assert fn() == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[(n, name)] = e0.elapsed_time(e1) / 3
+    names = {0: "baseline", 1: "no activation jet in produce", 2: "no barrier in main loop", 3: "weights L1-resident",
+             4: "no epilogue", 5: "no produce stage in loop"}
+    for n in VARIANTS:
+        if (n, "fwd") in res:
+            print("%-32s fwd %7.3f ms   dgrad %7.3f ms" % (names[n], res[(n, "fwd")], res[(n, "dgrad")]))
+
+
+if __name__ == "__main__":
+    (build if sys.argv[1:] == ["build"] else run)()
