@@ -36,3 +36,69 @@ def test_short_training_run_reduces_the_loss(hiplib):
         assert torch.isfinite(loss)
     assert lig.stats["hip_jet_calls"] == calls0 + 30          # the HIP jet path carried every step
     assert sum(losses[-5:]) / 5 < 0.8 * sum(losses[:5]) / 5, losses
+
+
+def _rccl_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from space_time_pde_amd.train_step import sharded_step
+    unet, net, layer, crop, pts, tgt = _rccl_build(dev)
+    n = pts.shape[1] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    loss, reg, pde = sharded_step(unet, net, layer, crop, pts[:, sl].contiguous(), tgt[:, sl].contiguous(), pts.shape[1],
+                                  1.0, 0.0125, sync_unet_grads=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save(dict(loss=loss.cpu(), reg=reg.cpu(), pde=pde.cpu(), g_im=[p.grad.cpu() for p in net.parameters()],
+                        g_un=[p.grad.cpu() for p in unet.parameters()]), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rccl_build(dev):
+    from space_time_pde_amd import implicit_net, nonlinearities, physics, unet3d
+    torch.manual_seed(0)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(4, 16, 16), nf=16, mf=64).to(dev).eval()
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=16,
+                             activation=nonlinearities.NONLINEARITIES["softplus"]).to(dev)
+    layer = physics.get_rb2_pde_layer(mean=(0.01, 0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                      x_crop=1., use_continuity=True)
+    g = torch.Generator().manual_seed(1)
+    crop = torch.randn(1, 4, 4, 16, 16, generator=g).to(dev)
+    pts = (0.02 + 0.96 * torch.rand(1, 2048, 3, generator=g)).to(dev)
+    tgt = torch.randn(1, 2048, 4, generator=g).to(dev)
+    return unet, net, layer, crop, pts, tgt
+
+
+@pytest.mark.gpu
+def test_two_rank_rccl_step_equals_single_gpu(hiplib, tmp_path):
+    """BASELINE configs[2] in miniature: the point-sharded step over RCCL (backend "nccl") on 2 devices equals the
+    single-device step (losses, IM-NET and U-Net gradients).  Skipped where fewer than 2 devices are visible (the 1-GPU
+    test box); the same host logic runs on CPU with gloo in tests/test_distributed_cpu.py."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible devices")
+    import socket
+    import torch.multiprocessing as mp
+    from space_time_pde_amd.train_step import sharded_step
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_rccl_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    dev = torch.device("cuda:0")
+    unet, net, layer, crop, pts, tgt = _rccl_build(dev)
+    loss, reg, pde = sharded_step(unet, net, layer, crop, pts, tgt, pts.shape[1], 1.0, 0.0125, distributed=False)
+    assert abs(float(got["loss"]) - float(loss)) < 1e-5 * abs(float(loss))
+    assert abs(float(got["pde"]) - float(pde)) < 1e-5 * abs(float(pde))
+    for a, p in zip(got["g_im"], net.parameters()):
+        assert (a - p.grad.cpu()).abs().max().item() < 2e-4 * p.grad.abs().max().item() + 1e-9
+    for a, p in zip(got["g_un"], unet.parameters()):
+        assert (a - p.grad.cpu()).abs().max().item() < 2e-3 * p.grad.abs().max().item() + 1e-8
