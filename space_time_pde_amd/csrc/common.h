@@ -52,6 +52,13 @@ struct ActD {
   float s0, s1, s2, s3;
 };
 
+// The activation jets are straight-line fp32 polynomial arithmetic that runs on the SAME vector FMA lanes as the fp32
+// MFMAs (tools/micro/mfma_valu_coissue.hip: on gfx950 every VALU instruction adds its ~5 issue cycles to a 33-cycle
+// v_mfma_f32_16x16x4_f32, there is no co-execution), so their instruction count is paid in MFMA time.  Fused multiply-adds
+// halve it; they are enabled HERE only (the library is built with -ffp-contract=off because the cell index / weights of the
+// gather stage reproduce the reference's rounding bit by bit, which the jets do not need: they are compared to tolerance).
+#define STPDE_JET_FMA _Pragma("clang fp contract(fast)")
+
 // Hardware transcendentals only (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each): no library call sequences, whose
 // denormal handling costs ~10 extra instructions and makes the compiler wrap them in a divergent branch -- the activation
 // jets must stay straight-line code inside the MFMA basic blocks so that the scheduler can interleave them with MFMAs.
@@ -59,14 +66,17 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
 // log(1 + e) for e in [0, 1]: series below 2^-10 (where log(1+e) would cancel), v_log_f32 above (argument in [1, 2])
 __device__ __forceinline__ float log1p_unit(float e) {
+  STPDE_JET_FMA
   const float u = 1.f + e;
   const float big = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
   const float small = e * (1.f - e * (0.5f - e * 0.33333334f));
   return e < 9.765625e-4f ? small : big;
 }
 
+
 template <int ACT>
 __device__ __forceinline__ ActD act_eval_t(float prm, float a) {
+  STPDE_JET_FMA
   ActD r;
   if (ACT == STPDE_ACT_TANH) {
     const float e = fast_exp(-2.f * fabsf(a));
@@ -147,6 +157,7 @@ __device__ __forceinline__ float sel3(int d, float a0, float a1, float a2) { ret
 template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h,
                                             const float* cq = nullptr) {
+  STPDE_JET_FMA
   if (S1 == 0 && S2 > 0) {
 #pragma unroll
     for (int st = 0; st < 1 + S2; ++st)
@@ -181,6 +192,7 @@ __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x
 template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
                                             f32x4* abar, const float* cq = nullptr) {
+  STPDE_JET_FMA
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
@@ -226,6 +238,7 @@ __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x
 template <int S1, int S2>
 __device__ __forceinline__ float swish_beta_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
                                                 const float* cq) {
+  STPDE_JET_FMA
   float sum = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -257,15 +270,15 @@ __device__ __forceinline__ float swish_beta_adj(const stpde_jet_cfg& cfg, const 
 
 // Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15 = the 16 rows of a fragment block for one feature group):
 // four v_add_f32 with row_shr DPP modifiers; lane 16g+15 ends up with the full sum.
-template <int N>
-__device__ __forceinline__ float dpp_row_shr(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
-}
+// one v_add_f32 with a DPP row-shift on its first operand (lanes shifted in from outside the 16-lane row read 0); written
+// as inline assembly because the compiler otherwise emits v_mov_b32_dpp + v_add_f32 (two VALU issues, and on gfx950 VALU
+// issue cycles are MFMA cycles)
+#define STPDE_DPP_ADD(v, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v))
 __device__ __forceinline__ float row_sum16(float v) {
-  v += dpp_row_shr<1>(v);
-  v += dpp_row_shr<2>(v);
-  v += dpp_row_shr<4>(v);
-  v += dpp_row_shr<8>(v);
+  STPDE_DPP_ADD(v, "row_shr:1");
+  STPDE_DPP_ADD(v, "row_shr:2");
+  STPDE_DPP_ADD(v, "row_shr:4");
+  STPDE_DPP_ADD(v, "row_shr:8");
   return v;
 }
 
