@@ -19,7 +19,7 @@ def parse(path):
 
 
 def bench_name(sym):
-    if re.match(r"k_\w+<0,0,", sym):      # value-only kernels of bench.py's inference side figure, not the training step
+    if re.match(r"k_\w+<0,\d,", sym):      # value-only / value-tile kernels of bench.py's inference side figure, not the training step
         return None
     m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?(?:,[\w,]+)?>", sym)
     if m and m.group(8) in (None, "false"):
@@ -48,4 +48,4 @@ if __name__ == "__main__":
             kernels[name] = dict(symbol=sym, fetch_bytes_corrected=f, write_bytes=w, hbm_bytes_per_launch=f + w)
     json.dump(dict(chunk=int(sys.argv[3]), act=sys.argv[4], kernels=kernels,
                    source="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
-                          "profiles/r1_pmc_*.txt"), open(sys.argv[5], "w"), indent=1)
+                          "profiles/r2_pmc_fetch_size.txt / r2_pmc_write_size.txt"), open(sys.argv[5], "w"), indent=1)
