@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20)
     ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
     ap.add_argument("--chunk", type=int, default=1 << 18, help="points per launch chunk")
-    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="fp32 = the headline / parity path; bf16 = BASELINE configs[3]: bf16 MFMA operands in the "
                          "wide IM-NET layers, fp32 accumulation (NOT the headline metric)")
     ap.add_argument("--igres", type=int, nargs=3, default=[32, 128, 128], metavar=("T", "Z", "X"),
@@ -327,7 +327,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16 MFMA operands (wide IM-NET layers) / f32 accumulate, stash, epilogues, UNet" if bf16 else "f32",
+            "dtype": ("bf16 MFMA operands (wide IM-NET layers) / f32 accumulate, stash, epilogues, UNet" if bf16 else
+                      "f32 (forward / input-gradient GEMMs of the wide IM-NET layers: fp32 operands split 3-way onto the "
+                      "bf16 MFMA pipe, 6 products, fp32-accurate; everything else exact fp32)"
+                      if args.mlp_precision == "fp32x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: latent [1,%d,%d,%d,32], 2^%d query points, RB2 "
                                    "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + UNet3d parameters"

@@ -105,6 +105,12 @@ typedef struct {
    * by the workgroup-cooperative kernels: KT % 4 == 0, KT >= 8, MT % 8 == 0) on v_mfma_f32_16x16x32_bf16 -- operands
    * rounded to bf16 (round-to-nearest-even), fp32 accumulation; layer-0 regeneration, skip/bias GEMM, activation
    * jets, stash and epilogues stay fp32.  Narrow layers (HBM-bound) keep the fp32 kernels. */
+  /* mfma_bf16 == 3 ("fp32x3", forward and input-gradient kernels only): fp32-ACCURATE products on the bf16 pipe -- every
+   * fp32 operand is split exactly into three bf16 terms (hi + mid + lo = 8 + 8 + 8 mantissa bits; the weights on the
+   * host: Wh_pack_bf16 is then [3][KT/2][MT][64] blocks, the activations in the kernel's produce stage) and the six
+   * partial products of weight >= 2^-16 are accumulated in fp32; bf16 x bf16 is exact in fp32 and the dropped products are
+   * below 2^-24 of the result, i.e. below fp32 rounding.  6 bf16 MFMAs (K = 32) replace 8 fp32 MFMAs at 1/16 of the
+   * per-instruction time. */
   int mfma_bf16;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =

@@ -25,6 +25,12 @@ __device__ __forceinline__ bf16x4 to_bf4(f32x4 v) {
   for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
   return r;
 }
+__device__ __forceinline__ f32x4 bf4_to_f32(bf16x4 v) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (float)v[i];
+  return r;
+}
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }

@@ -47,6 +47,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
   a.Out = out_pre;
   a.cw = cw;
   a.Wp16 = d->mfma_bf16 ? Wh_pack_bf16 : nullptr;
+  a.nsplit = d->mfma_bf16 == 3 ? 3 : 1;
   a.KT = d->KT;
   a.MT = d->MT;
   a.ntiles = d->ntiles;
@@ -85,6 +86,7 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
   a.cw = cw;
   a.pbar = act_param_bar;
   a.Wp16 = d->mfma_bf16 ? WhT_pack_bf16 : nullptr;
+  a.nsplit = d->mfma_bf16 == 3 ? 3 : 1;
   a.KT = d->MT;
   a.MT = d->KT;
   a.ntiles = d->ntiles;

@@ -34,7 +34,8 @@ struct LayerArgs {
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
   float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
   const float* cw;     // [P][8] per-point weights of the combined second-order stream (S2 == 1), else unused
-  const void* Wp16;    // [KT/2][MT][64] x 8 bf16: A operand of the bf16-MFMA variant (two k-tiles per block), or null
+  const void* Wp16;    // [nsplit][KT/2][MT][64] x 8 bf16: A operand of the bf16-MFMA variants (two k-tiles per block), or null
+  int nsplit;          // 1: operands rounded to bf16 (configs[3]);  3: fp32 operands split into three bf16 terms each
   float* pbar;         // dgrad, swish only: [STPDE_PBAR_SLOTS] accumulators of the adjoint of beta (nullable)
   float* Tan0;         // EPI_ADJ_L0, nullable: [tile][MT][3][16] row sums of the tangent-stream adjoints of layer 0; when
                        // given, Out holds the VALUE stream only: [tile][MT][256]
@@ -247,11 +248,20 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // k-tiles.  Layer-0 regeneration, skip GEMM, activation jets and epilogues stay fp32.
 // PK (bf16 variant only): k-tiles produced per wave and group -- the bf16 MFMAs of a k-tile take 1/16 of the fp32
 // time, so twice the k-tiles per barrier halve the number of exposed load -> activation -> LDS -> barrier chains.
-template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1, bool WRING = false>
+// SPL = 3 (with BF): fp32-ACCURATE product on the bf16 pipe.  Every fp32 operand is split exactly into three bf16 terms
+// (x = hi + mid + lo, 8 + 8 + 8 mantissa bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), the residuals
+// are exact in fp32) and the six partial products of weight 2^0, 2^-8, 2^-16 are accumulated in fp32
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are below 2^-24 of the product = below fp32 rounding).
+// bf16 x bf16 products are exact in fp32, so the result carries fp32 accuracy, at 6 bf16 MFMAs (6 x 16 cycles for K = 32)
+// instead of 8 fp32 MFMAs (8 x 33 cycles): the fp32 matrix pipe of gfx950 runs at the VECTOR fp32 rate, the bf16 pipe 16 x
+// faster.  The split of the activations is done once per workgroup in the produce stage, that of the weights on the host.
+template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1, bool WRING = false,
+          int SPL = 1>
 __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, GK = NW * PK;
   static_assert(!WRING || (!BF && GK == 4), "the weight ring is written for 4 k-tiles per group, fp32");
-  __shared__ __attribute__((aligned(16))) float hb[2][GK][S][BF ? 128 : 256];
+  static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");
+  __shared__ __attribute__((aligned(16))) float hb[2][GK][S][BF ? 128 * SPL : 256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int KT = a.KT, MT = a.MT;
@@ -306,10 +316,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     }
 #pragma unroll
     for (int st = 0; st < S; ++st) {
-      if constexpr (BF)
-        *reinterpret_cast<bf16x4*>(&hb[buf][slot][st][lane * 2]) = to_bf4(B[st]);
-      else
+      if constexpr (BF) {
+        f32x4 v = B[st];
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+          const bf16x4 h = to_bf4(v);
+          *reinterpret_cast<bf16x4*>(&hb[buf][slot][st][128 * t + lane * 2]) = h;
+          if (t + 1 < SPL) v -= bf4_to_f32(h);      // exact: the residual of a round-to-nearest bf16 fits in fp32
+        }
+      } else {
         st4(&hb[buf][slot][st][lo], B[st]);
+      }
     }
   };
   auto produce_group = [&](int g, int buf) {      // this wave's PK k-tiles of group g
@@ -342,17 +359,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
         for (int q = 0; q < GK / 2; ++q) {
           const int kp = GK / 2 * gi + q;       // pair of k-tiles (2 kp, 2 kp + 1)
-          bf16x8 B8[S], w8[MCg];
+          bf16x8 B8[S][SPL], w8[MCg][SPL];
 #pragma unroll
           for (int st = 0; st < S; ++st)
-            B8[st] = cat8(*reinterpret_cast<const bf16x4*>(&hb[buf][2 * q][st][lane * 2]),
-                          *reinterpret_cast<const bf16x4*>(&hb[buf][2 * q + 1][st][lane * 2]));
 #pragma unroll
-          for (int mi = 0; mi < MCg; ++mi) w8[mi] = wp16[((size_t)kp * MT + mi) * 64];
+            for (int t = 0; t < SPL; ++t)
+              B8[st][t] = cat8(*reinterpret_cast<const bf16x4*>(&hb[buf][2 * q][st][128 * t + lane * 2]),
+                               *reinterpret_cast<const bf16x4*>(&hb[buf][2 * q + 1][st][128 * t + lane * 2]));
 #pragma unroll
           for (int mi = 0; mi < MCg; ++mi)
 #pragma unroll
-            for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(w8[mi], B8[st], acc[mi][st]);
+            for (int t = 0; t < SPL; ++t)
+              w8[mi][t] = wp16[(((size_t)t * (KT / 2) + kp) * MT + mi) * 64];
+          if constexpr (SPL == 3) {
+            // six partial products, smallest first: (weight term, activation term)
+            constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+              for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+                for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(w8[mi][TW[c]], B8[st][TB[c]], acc[mi][st]);
+          } else {
+#pragma unroll
+            for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+              for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(w8[mi][0], B8[st][0], acc[mi][st]);
+          }
         }
       } else if constexpr (WRING) {
         // weight fragments through a register ring three k-tiles deep that runs straight across the group barriers
@@ -419,7 +452,14 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
   a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
   const int nblocks = a.split ? (a.ntiles + 7) / 8 * 8 * a.split : a.ntiles;
-  if (a.Wp16 && a.KT % (2 * NW) == 0)
+  if (a.Wp16 && a.nsplit == 3) {
+    if constexpr (S1 + S2 <= 4 && NW == 4)     // split mode: compiled for the wide-layer shapes of the training stream sets
+      STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 1, false, 3>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+    else {
+      stpde_set_error("bf16x3 split mode is not compiled for this stream set / workgroup shape");
+      return STPDE_E_UNSUPPORTED;
+    }
+  } else if (a.Wp16 && a.KT % (2 * NW) == 0)
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 2>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   else if (a.Wp16)
     STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);

@@ -163,16 +163,24 @@ class ImNetPlan:
         theta = torch.cat([p.detach().reshape(-1).float() for p in params] + [torch.zeros(1, device=dev)])
         return theta[pidx]
 
-    def pack_bf16(self, packs):
-        """bf16 A-operand packs of the hidden-to-hidden weights (config-4 path): block (q, mt) = the fp32 blocks
-        (2q, mt) and (2q+1, mt) lane by lane, rounded to bf16.  Returns {(l, "Wh"|"WhT"): tensor}."""
+    def pack_bf16(self, packs, nsplit=1):
+        """bf16 A-operand packs of the hidden-to-hidden weights: block (q, mt) = the fp32 blocks (2q, mt) and (2q+1, mt)
+        lane by lane.  nsplit = 1 (config-4 path): rounded to bf16.  nsplit = 3 ("fp32x3"): each weight split exactly
+        into three bf16 terms hi + mid + lo (8 + 8 + 8 mantissa bits), stacked [3][...] -- the weight side of the
+        fp32-accurate six-product scheme of k_layer_coop<..., SPL = 3>.  Returns {(l, "Wh"|"WhT"): tensor}."""
         out = {}
         for l in range(1, 6):
             kt, mt = self.layers[l]["KT"], self.layers[l]["MT"]
             for name, (ka, ma) in (("Wh", (kt, mt)), ("WhT", (mt, kt))):
                 if ka % 2 == 0:
-                    w = self.pack_view(packs, l, name).view(ka // 2, 2, ma, 64, 4)
-                    out[(l, name)] = w.permute(0, 2, 3, 1, 4).to(torch.bfloat16).contiguous()
+                    w = self.pack_view(packs, l, name).view(ka // 2, 2, ma, 64, 4).permute(0, 2, 3, 1, 4)
+                    terms, r = [], w
+                    for t in range(nsplit):
+                        h = r.to(torch.bfloat16)
+                        terms.append(h)
+                        if t + 1 < nsplit:
+                            r = r - h.float()
+                    out[(l, name)] = (torch.stack(terms, 0) if nsplit > 1 else terms[0]).contiguous()
         return out
 
     def pack_view(self, packs, l, name):
@@ -306,7 +314,7 @@ class _Meta:
     pass
 
 
-def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=False):
+def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=0):
     d = LayerDesc()
     d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg = ntiles, lay["KT"], lay["MT"], int(first_hidden), cfg
     d.mfma_bf16 = int(bf16)
@@ -352,7 +360,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         lay = plan.layers[l]
         out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
         w16 = meta.packs16.get((l, "Wh")) if meta.packs16 else None
-        d = _layer_desc(lnt, lay, lcfg, l == 1, w16 is not None)
+        d = _layer_desc(lnt, lay, lcfg, l == 1, meta.nsplit if w16 is not None else 0)
         with _timed("layer%d_fwd" % l):
             check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")),
                                         ptr(pv(packs, l, "Ws")), ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")),
@@ -391,11 +399,14 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
-        d = _layer_desc(nt, lay, cfg, l == 1, w16 is not None)
+        d = _layer_desc(nt, lay, cfg, l == 1, meta.nsplit if w16 is not None else 0)
+        # weight gradient: bf16 operands in "bf16" mode; in "fp32x3" mode it stays on the exact-fp32 MFMA kernels (its
+        # second operand would have to be split per consumer wave, which costs more VALU time than the bf16 pipe saves)
+        dwg = _layer_desc(nt, lay, cfg, l == 1, 1 if (w16 is not None and meta.nsplit == 1) else 0)
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
-                check(L.stpde_jet_wgrad(C.byref(d), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
+                check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
                                         ptr(XR), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
                                         ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
         with _timed("layer%d_dgrad" % l):
@@ -454,7 +465,7 @@ class LigJetFunction(torch.autograd.Function):
     def forward(ctx, meta, latent, pts, act_param, *params):
         # act_param: the learnable swish beta (a tensor input so that autograd routes its gradient) or None
         packs = meta.plan.pack(params)
-        meta.packs16 = meta.plan.pack_bf16(packs) if meta.bf16 else None
+        meta.packs16 = meta.plan.pack_bf16(packs, meta.nsplit) if meta.bf16 else None
         P = pts.shape[0]
         jets = torch.empty(meta.S_out, meta.plan.cout, P, device=pts.device)
         # grad mode is always off inside Function.forward and ctx.needs_input_grad ignores torch.no_grad(): whether a
@@ -539,8 +550,8 @@ mlp_precision = os.environ.get("STPDE_MLP_PRECISION", "fp32")
 def set_mlp_precision(precision):
     """Select "fp32" or "bf16" MFMA operands for subsequent HIP jet calls; returns the previous setting."""
     global mlp_precision
-    if precision not in ("fp32", "bf16"):
-        raise ValueError("mlp precision must be 'fp32' or 'bf16'")
+    if precision not in ("fp32", "bf16", "fp32x3"):
+        raise ValueError("mlp precision must be 'fp32', 'bf16' or 'fp32x3'")
     prev, mlp_precision = mlp_precision, precision
     return prev
 
@@ -579,9 +590,10 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta = _Meta()
     meta.plan = plan
     precision = precision or mlp_precision
-    if precision not in ("fp32", "bf16"):
-        raise ValueError("mlp precision must be 'fp32' or 'bf16'")
-    meta.bf16 = precision == "bf16"
+    if precision not in ("fp32", "bf16", "fp32x3"):
+        raise ValueError("mlp precision must be 'fp32', 'bf16' or 'fp32x3'")
+    meta.bf16 = precision in ("bf16", "fp32x3")
+    meta.nsplit = 3 if precision == "fp32x3" else 1
     meta.packs16 = None
     # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
     # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams

@@ -256,3 +256,60 @@ def test_dlatent_is_bit_reproducible_and_matches_atomic_scatter(hiplib, monkeypa
     assert torch.equal(grads[0], grads[1])
     assert (grads[0] - grads[2]).abs().max().item() < 1e-5 * grads[0].abs().max().item()
     assert grads[0].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("act", ["softplus", "leakyrelu", "tanh"])
+def test_fp32x3_split_mode_keeps_fp32_tolerances(hiplib, act):
+    """"fp32x3": forward / input-gradient GEMMs of the wide layers on the bf16 MFMA pipe with every fp32 operand split
+    exactly into three bf16 terms and six partial products accumulated in fp32.  Judged with the SAME tolerances as the
+    exact-fp32 MFMA path (test_benchmarked_instantiations_backward_vs_fp64_oracle): it is an fp32-accurate product, not
+    a reduced-precision mode (the plain "bf16" mode needs 3e-2 here)."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, nonlinearities
+    g = torch.Generator().manual_seed(15)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(2, 150, 3, generator=g)
+    combo = {(1, 1): 1.0, (2, 2): 0.25}
+    pairs = tuple(sorted(combo))
+    torch.manual_seed(3)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES[act]).to(DEV)
+    res = {}
+    for prec in ("fp32", "fp32x3"):
+        for p in net.parameters():
+            p.grad = None
+        latd = lat.to(DEV).requires_grad_(True)
+        with _lib.dispatch_trace() as tr:
+            jets, pp = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=128, combo=combo,
+                                        precision=prec)
+            if "cot" not in res:
+                res["cot"] = torch.randn(jets.shape, generator=g)
+            (jets * res["cot"].to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+        if prec == "fp32x3":      # the split kernels (last template argument 3) carried layers 1 and 2, forward and dgrad
+            assert tr.has("k_layer_coop", "1, false, 3>)", "PRO = 2", "EPI = 0"), "\n".join(tr.kernels)
+            assert tr.has("k_layer_coop", "1, false, 3>)", "PRO = 0", "EPI = 2"), "\n".join(tr.kernels)
+            assert tr.has("k_layer_coop", "1, false, 3>)", "PRO = 1", "EPI = 0"), "\n".join(tr.kernels)
+            assert tr.has("k_layer_coop", "1, false, 3>)", "PRO = 0", "EPI = 1"), "\n".join(tr.kernels)
+        res[prec] = (jets.detach().clone(), latd.grad.clone(), [p.grad.clone() for p in net.parameters()])
+    cot = res["cot"]
+    p64 = [(net.fc[k].weight.detach().double().cpu().requires_grad_(True),
+            net.fc[k].bias.detach().double().cpu().requires_grad_(True)) for k in range(6)]
+    lat64 = lat.double().requires_grad_(True)
+    full = J.lig_jets(p64, act, lat64, pts.double(), 0., 1., second=pairs)
+    full = full.permute(0, 3, 1, 2).reshape(full.shape[0], 4, -1)
+    L = sum(combo[p] * full[4 + k] for k, p in enumerate(pairs))
+    ref = torch.cat([full[:4], L[None]], 0)
+    (ref * cot.double()).sum().backward()
+    jets, dlat, grads = res["fp32x3"]
+    for s in range(5):
+        assert _relerr(jets[s], ref[s].detach()) < 2e-5, "stream %d" % s
+    err = _normerr if act == "leakyrelu" else _relerr
+    assert err(dlat, lat64.grad) < 2e-4
+    for k in range(6):
+        assert err(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
+        assert err(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
+    # and it is as close to the fp64 oracle as the exact-fp32 MFMA path is (within a factor 3 of its error)
+    j32 = res["fp32"][0]
+    e32 = max(_relerr(j32[s], ref[s].detach()) for s in range(5))
+    e3 = max(_relerr(jets[s], ref[s].detach()) for s in range(5))
+    assert e3 < 3 * e32 + 1e-6, (e3, e32)
