@@ -58,11 +58,21 @@ __device__ __forceinline__ f32x4 lds_get_R(const float* blk, int lane) {
 
 // BF: one v_mfma_f32_16x16x32_bf16 contracts over the 16 rows of the tile for TWO derivative streams (k-slot e of a
 // lane = stream parity e >> 2, row 4g + (e & 3)), operands rounded to bf16 when they leave LDS / the patch.
-template <int S1, int S2, int MODE, int ACT, int KC, bool HASX, bool BF = false>
+// SPL = 3 (with BF): fp32-accurate contraction on the bf16 pipe -- both operands are split exactly into three bf16 terms
+// (hi + mid + lo) and the six partial products of weight >= 2^-16 are accumulated (see k_layer_coop); the abar blocks are
+// split once per tile when they are packed, the activated-input blocks when they leave the LDS ring (up to two VALU
+// instructions issue for free behind every bf16 MFMA).
+template <int S1, int S2, int MODE, int ACT, int KC, bool HASX, bool BF = false, int SPL = 1>
 __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
+  static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");
   constexpr int S = 1 + S1 + S2, MCW = 2, NW = 8, RS = 8;
   constexpr int NM = KC;                    // m-slots per workgroup; k-slots = NW / NM, each KC ring slots wide
-  constexpr int BLK = MODE == 1 ? 256 : TBLK;
+  // SPLP (split mode): the ring holds the three bf16 terms of every activated-input fragment, split ONCE by the producing
+  // wave: block = [term][feature][16 rows] bf16 (1536 B); a consumer lane (g, c) reads rows 4g..4g+3 of feature c of term t
+  // with one ds_read_b64 -- the same layout serves the column-major producers (transposing ds_write_b16) and the
+  // row-major ones (ds_write_b64).
+  constexpr bool SPLP = BF && SPL == 3;
+  constexpr int BLK = SPLP ? 384 : (MODE == 1 ? 256 : TBLK);
   constexpr int NBUF = (2 * RS * S * BLK * 4 + NW * 2 * TBLK * 4 <= 150 * 1024) ? 2 : 1;
   constexpr int SX = S1 == 3 ? 4 : 1;       // raw-input tiles only feed the value and tangent streams
   __shared__ __attribute__((aligned(16))) float hl[NBUF][RS][S][BLK];
@@ -86,7 +96,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     for (int ki = 0; ki < KC; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto put = [&](float* blk, f32x4 v, bool row_major) {
-    if (MODE == 1) {
+    if constexpr (SPLP) {
+      __bf16* hb16 = reinterpret_cast<__bf16*>(blk);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const bf16x4 h = to_bf4(v);
+        if (MODE == 1 || row_major) {       // lane (g, c) holds rows 4g..4g+3 of feature c
+          *reinterpret_cast<bf16x4*>(hb16 + (t * 16 + (lane & 15)) * 16 + 4 * (lane >> 4)) = h;
+        } else {                             // lane (g, j) holds features 4g..4g+3 of row j
+#pragma unroll
+          for (int i = 0; i < 4; ++i) hb16[(t * 16 + 4 * (lane >> 4) + i) * 16 + (lane & 15)] = h[i];
+        }
+        if (t < 2) v -= bf4_to_f32(h);
+      }
+    } else if (MODE == 1) {
       st4(blk + lo, v);                      // ring holds plain row-major images
     } else if (row_major) {
       lds_put_R(blk, lane, v);
@@ -95,6 +118,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     }
   };
   auto get = [&](const float* blk) -> f32x4 { return MODE == 1 ? ld4(blk + lo) : lds_get_R(blk, lane); };
+  auto get16 = [&](const float* blk, int t) -> bf16x4 {     // SPLP: term t of this lane's row-major fragment
+    return *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(blk) + (t * 16 + (lane & 15)) * 16 +
+                                            4 * (lane >> 4));
+  };
 
   // produce ring slot `wv` (k-tile kq0 + wv) of row tile `tile` into buffer `buf`
   auto produce = [&](int tile, int buf) {
@@ -167,15 +194,38 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   };
 
   constexpr int SH = (S + 1) / 2, SXH = (SX + 1) / 2;
-  bf16x8 pa8[BF ? SH : 1][MCW];
+  bf16x8 pa8[BF ? SPL : 1][BF ? SH : 1][MCW];
   const bf16x4 zero4 = to_bf4(f32x4{0.f, 0.f, 0.f, 0.f});
+  // the SPL bf16 terms of an fp32 fragment (SPL = 1: plain rounding)
+  auto split = [&](f32x4 v, bf16x4* t) {
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      t[k] = to_bf4(v);
+      if (k + 1 < SPL) v -= bf4_to_f32(t[k]);
+    }
+  };
   auto pack_p = [&](f32x4 (*pa_)[MCW]) {
     if constexpr (BF) {
 #pragma unroll
       for (int sp = 0; sp < SH; ++sp)
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi)
-          pa8[sp][mi] = cat8(to_bf4(pa_[2 * sp][mi]), 2 * sp + 1 < S ? to_bf4(pa_[2 * sp + 1][mi]) : zero4);
+        for (int mi = 0; mi < MCW; ++mi) {
+          bf16x4 t0[SPL], t1[SPL];
+          split(pa_[2 * sp][mi], t0);
+          if (2 * sp + 1 < S) split(pa_[2 * sp + 1][mi], t1);
+#pragma unroll
+          for (int k = 0; k < SPL; ++k) pa8[k][sp][mi] = cat8(t0[k], 2 * sp + 1 < S ? t1[k] : zero4);
+        }
+    }
+  };
+  // acc += P^T H for one pair of streams: one bf16 MFMA (SPL = 1) or the six partial products, smallest first
+  auto mma16 = [&](f32x4& c, int sp, int mi, const bf16x8* H8) {
+    if constexpr (SPL == 3) {
+      constexpr int TP[6] = {1, 0, 2, 0, 1, 0}, TH[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int q6 = 0; q6 < 6; ++q6) c = mfma_bf(pa8[TP[q6]][sp][mi], H8[TH[q6]], c);
+    } else {
+      c = mfma_bf(pa8[0][sp][mi], H8[0], c);
     }
   };
 
@@ -196,20 +246,61 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     const int nx = next < a.ntiles ? next : tile;   // branch-free tail: the last iteration re-produces its own tile
     f32x4 raw[S][MCW];
     load_p_raw(nx, raw);                           // lands while the MFMAs below run
+    if constexpr (SPLP && !HASX && KC % 2 == 0) {
+      // split mode, hidden k-tiles: two k-tiles at a time and the six partial products outermost, so that consecutive
+      // MFMAs go to 2 x MCW different accumulators (six back-to-back MFMAs into ONE accumulator stall on each other)
+#pragma unroll
+      for (int ki = 0; ki < KC; ki += 2) {
+        const int q = ks * KC + ki;
+#pragma unroll
+        for (int sp = 0; sp < SH; ++sp) {
+          bf16x8 H8[2][3];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              H8[kk][k] = cat8(get16(&hl[buf][q + kk][2 * sp][0], k),
+                               2 * sp + 1 < S ? get16(&hl[buf][q + kk][2 * sp + 1 < S ? 2 * sp + 1 : 0][0], k) : zero4);
+          constexpr int TP[6] = {1, 0, 2, 0, 1, 0}, TH[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+          for (int q6 = 0; q6 < 6; ++q6)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+              for (int mi = 0; mi < MCW; ++mi)
+                acc[mi][ki + kk] = mfma_bf(pa8[TP[q6]][sp][mi], H8[kk][TH[q6]], acc[mi][ki + kk]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int ki = 0; ki < KC; ++ki) {
       const int q = ks * KC + ki;
       const int kq = kq0 + q;
       if (!HASX || kq < KT) {
         f32x4 H[S];
+        if constexpr (!SPLP) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) H[st] = get(&hl[buf][q][st][0]);
+          for (int st = 0; st < S; ++st) H[st] = get(&hl[buf][q][st][0]);
+        }
         if constexpr (BF) {
 #pragma unroll
           for (int sp = 0; sp < SH; ++sp) {
-            const bf16x8 H8 = cat8(to_bf4(H[2 * sp]), 2 * sp + 1 < S ? to_bf4(H[2 * sp + 1]) : zero4);
+            bf16x4 t0[SPL], t1[SPL];
+            bf16x8 H8[SPL];
+            if constexpr (SPLP) {
 #pragma unroll
-            for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma_bf(pa8[sp][mi], H8, acc[mi][ki]);
+              for (int k = 0; k < SPL; ++k) {
+                t0[k] = get16(&hl[buf][q][2 * sp][0], k);
+                if (2 * sp + 1 < S) t1[k] = get16(&hl[buf][q][2 * sp + 1 < S ? 2 * sp + 1 : 0][0], k);
+              }
+            } else {
+            split(H[2 * sp], t0);
+            if (2 * sp + 1 < S) split(H[2 * sp + 1], t1);
+            }
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) H8[k] = cat8(t0[k], 2 * sp + 1 < S ? t1[k] : zero4);
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi) mma16(acc[mi][ki], sp, mi, H8);
           }
         } else {
 #pragma unroll
@@ -221,14 +312,29 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         }
       } else if (kq < KT + XT) {
         f32x4 H[SX];
+        if constexpr (!SPLP) {
 #pragma unroll
-        for (int st = 0; st < SX; ++st) H[st] = get(&hl[buf][q][st][0]);
+          for (int st = 0; st < SX; ++st) H[st] = get(&hl[buf][q][st][0]);
+        }
         if constexpr (BF) {
 #pragma unroll
           for (int sp = 0; sp < SXH; ++sp) {
-            const bf16x8 H8 = cat8(to_bf4(H[2 * sp]), 2 * sp + 1 < SX ? to_bf4(H[2 * sp + 1]) : zero4);
+            bf16x4 t0[SPL], t1[SPL];
+            bf16x8 H8[SPL];
+            if constexpr (SPLP) {
 #pragma unroll
-            for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma_bf(pa8[sp][mi], H8, acc[mi][ki]);
+              for (int k = 0; k < SPL; ++k) {
+                t0[k] = get16(&hl[buf][q][2 * sp][0], k);
+                if (2 * sp + 1 < SX) t1[k] = get16(&hl[buf][q][2 * sp + 1 < SX ? 2 * sp + 1 : 0][0], k);
+              }
+            } else {
+            split(H[2 * sp], t0);
+            if (2 * sp + 1 < SX) split(H[2 * sp + 1], t1);
+            }
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) H8[k] = cat8(t0[k], 2 * sp + 1 < SX ? t1[k] : zero4);
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi) mma16(acc[mi][ki], sp, mi, H8);
           }
         } else {
 #pragma unroll
@@ -239,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
             for (int st = 0; st < SX; ++st) acc[mi][ki] = mfma4(pa[st][mi][r], H[st][r], acc[mi][ki]);
         }
       }
+    }
     }
     if (NBUF == 2) {
       produce(nx, buf ^ 1);
@@ -426,7 +533,17 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
     a.gx = gx;
     constexpr bool HAS_BF = KC >= 4;          // bf16 variant compiled for the wide layers only (MT >= 8)
     const dim3 grid(gx * a.gy * a.gz);
-    if (HAS_BF && a.bf16) {
+    if (HAS_BF && a.bf16 == 3) {
+      if constexpr (HAS_BF && S1 + S2 <= 4) {
+        if (part == 0)
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 3>), grid, dim3(512), 0, stream, a);
+        else
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, true, 3>), grid, dim3(512), 0, stream, a);
+      } else {
+        stpde_set_error("bf16x3 split mode is not compiled for this stream set / layer width");
+        return STPDE_E_UNSUPPORTED;
+      }
+    } else if (HAS_BF && a.bf16) {
       if constexpr (HAS_BF) {
         if (part == 0)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true>), grid, dim3(512), 0, stream, a);

@@ -400,9 +400,12 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
         d = _layer_desc(nt, lay, cfg, l == 1, meta.nsplit if w16 is not None else 0)
-        # weight gradient: bf16 operands in "bf16" mode; in "fp32x3" mode it stays on the exact-fp32 MFMA kernels (its
-        # second operand would have to be split per consumer wave, which costs more VALU time than the bf16 pipe saves)
-        dwg = _layer_desc(nt, lay, cfg, l == 1, 1 if (w16 is not None and meta.nsplit == 1) else 0)
+        # weight gradient: same operand mode as the layer kernels (STPDE_WGRAD_SPLIT=0 keeps it on exact-fp32 MFMA in
+        # "fp32x3" mode, for A/B timing)
+        # (only the wide layers, MT >= 8, have bf16-pipe weight-gradient kernels; flagging a narrow layer would take it off
+        # its per-wave kernel)
+        dwg = _layer_desc(nt, lay, cfg, l == 1, (meta.nsplit if wgrad_split or meta.nsplit == 1 else 0)
+                          if (w16 is not None and lay["MT"] >= 8) else 0)
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
@@ -539,6 +542,7 @@ deterministic_dlatent = os.environ.get("STPDE_DLATENT_ATOMIC", "0") != "1"
 value_tiles = os.environ.get("STPDE_VALUE_TILES", "1") != "0"
 # layer-0 tangent-stream adjoints as per-tile row sums (STPDE_TAN0_ROWSUM=0: full fragment blocks, for A/B timing)
 tan0_rowsum = os.environ.get("STPDE_TAN0_ROWSUM", "1") != "0"
+wgrad_split = os.environ.get("STPDE_WGRAD_SPLIT", "1") != "0"
 
 DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
 
