@@ -136,6 +136,12 @@ def main():
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON record): libraries that print to file descriptor 1 (RCCL announces its
+    # path there when the process group comes up) are sent to stderr until the record is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -342,7 +348,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.act)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -481,6 +481,7 @@ class LigJetFunction(torch.autograd.Function):
             if need_grad:
                 saved.append(s)
         ctx.meta, ctx.packs, ctx.saved = meta, packs, saved
+        ctx.inputs = (latent, pts) if need_grad else None   # to rebuild the stash if backward runs again (retain_graph)
         ctx.n_params = len(params)
         ctx.prm_shape = act_param.shape if act_param is not None else None
         ctx.lat_shape = latent.shape
@@ -491,11 +492,17 @@ class LigJetFunction(torch.autograd.Function):
     @staticmethod
     @_lib.guarded
     def backward(ctx, jets_bar):
-        if ctx.used:
-            raise RuntimeError("LigJetFunction.backward ran twice: the activation stash is consumed in place "
-                               "(retain_graph is not supported on the HIP jet path)")
-        ctx.used = True
         meta = ctx.meta
+        if ctx.used:
+            # backward(retain_graph=True) followed by another backward: the dgrad kernels overwrote the stash in place, so
+            # the forward of every chunk is simply run again (same kernels, same inputs -> the same stash, bit for bit)
+            if ctx.inputs is None:
+                raise RuntimeError("LigJetFunction.backward: no stash was kept for this call")
+            latent, pts = ctx.inputs
+            scratch = torch.empty(meta.S_out, meta.plan.cout, pts.shape[0], device=pts.device)
+            ctx.saved = [_forward_chunk(meta, ctx.packs, latent, pts[p0:p0 + meta.chunk], scratch, p0, True)
+                         for p0 in range(0, pts.shape[0], meta.chunk)]
+        ctx.used = True
         jets_bar = jets_bar.contiguous()
         dev = jets_bar.device
         meta.need_wgrad = any(ctx.needs_input_grad[4:])

@@ -356,3 +356,26 @@ def test_backward_all_six_second_order_streams(hiplib, nf):
     for k in range(6):
         assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
         assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
+
+
+def test_retain_graph_second_backward_rebuilds_the_stash(hiplib):
+    """``loss.backward(retain_graph=True)`` followed by another backward (the reference's autograd graph allows it): the
+    dgrad kernels consumed the stash in place, so the forward kernels are run again -- the second gradient equals the
+    first bit for bit (same kernels, same inputs; d latent is deterministic), parameters accumulate 2x."""
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    lat = 0.5 * torch.randn(1, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(1, 130, 3, generator=g)
+    net = _net("softplus").to(dev)
+    latd = lat.to(dev).requires_grad_(True)
+    jets, _ = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, ((1, 1), (2, 2)), chunk_points=64)
+    cot = torch.randn(jets.shape, generator=g).to(dev)
+    loss = (jets * cot).sum()
+    loss.backward(retain_graph=True)
+    g1 = latd.grad.clone()
+    w1 = net.fc[1].weight.grad.clone()
+    latd.grad = None
+    loss.backward()
+    assert torch.equal(latd.grad, g1)
+    assert torch.allclose(net.fc[1].weight.grad, 2 * w1, rtol=1e-5, atol=1e-7 * float(w1.abs().max()))
