@@ -350,7 +350,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     prev = None
     # forward-only value queries (inference): VALUE-TILE kernels -- four consecutive row tiles share one pass over the
     # weights (the weight operand is what bounds a one-stream pass); same buffers, a quarter of the "tiles"
-    vt = S == 1 and not need_grad and not meta.packs16 and nt % 4 == 0 and value_tiles
+    vt = S == 1 and not need_grad and (not meta.packs16 or meta.nsplit == 3) and nt % 4 == 0 and value_tiles
     lcfg, lnt = cfg, nt
     if vt:
         lcfg = JetCfg()

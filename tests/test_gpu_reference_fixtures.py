@@ -313,3 +313,15 @@ def test_fp32x3_split_mode_keeps_fp32_tolerances(hiplib, act):
     e32 = max(_relerr(j32[s], ref[s].detach()) for s in range(5))
     e3 = max(_relerr(jets[s], ref[s].detach()) for s in range(5))
     assert e3 < 3 * e32 + 1e-6, (e3, e32)
+    # forward-only value query in the same mode: value-tile kernels with split operands (S1 = 0, S2 = 3, last argument 3)
+    from space_time_pde_amd import local_implicit_grid as lig
+    prev = lig_jet.set_mlp_precision("fp32x3")
+    try:
+        with torch.no_grad(), _lib.dispatch_trace() as tr:
+            y = lig.query_local_implicit_grid(net, lat.to(DEV), pts.to(DEV), 0., 1.)
+            torch.cuda.synchronize()
+    finally:
+        lig_jet.set_mlp_precision(prev)
+    assert tr.has("k_layer_coop", "1, false, 3>)", "S1 = 0, S2 = 3"), "\n".join(tr.kernels)
+    yref = ref[0].detach().reshape(4, 2, 150).permute(1, 2, 0)
+    assert _relerr(y, yref) < 2e-5

@@ -16,9 +16,11 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20)
     ap.add_argument("--act", default="softplus")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "fp32x3"])
     args = ap.parse_args()
     from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics
     dev = torch.device("cuda:0")
+    lig_jet.set_mlp_precision(args.mlp_precision)
     torch.manual_seed(1)
     net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
                              activation=nonlinearities.NONLINEARITIES[args.act]).to(dev)
