@@ -35,6 +35,12 @@ struct WgradArgs {
   stpde_jet_cfg cfg;
 };
 
+// Timing-only ablations (tools/micro/ablate_wgrad.py, private builds with -DSTPDE_ABLATE_W=n; results are WRONG):
+// 1 = one partial product instead of six, 2 = abar blocks transposed / split for the first tile only, 3 = no produce stage
+// in the loop, 4 = consumer operands not read from the LDS ring, 5 = no barrier in the loop.
+#ifndef STPDE_ABLATE_W
+#define STPDE_ABLATE_W 0
+#endif
 constexpr int TPAD = 20;             // padded row length of a transposed (feature-major) LDS block
 constexpr int TBLK = 16 * TPAD;      // floats per transposed block
 
@@ -259,11 +265,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
           for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-              H8[kk][k] = cat8(get16(&hl[buf][q + kk][2 * sp][0], k),
+              H8[kk][k] = STPDE_ABLATE_W == 4 ? pa8[k][sp][kk] :
+                          cat8(get16(&hl[buf][q + kk][2 * sp][0], k),
                                2 * sp + 1 < S ? get16(&hl[buf][q + kk][2 * sp + 1 < S ? 2 * sp + 1 : 0][0], k) : zero4);
           constexpr int TP[6] = {1, 0, 2, 0, 1, 0}, TH[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-          for (int q6 = 0; q6 < 6; ++q6)
+          for (int q6 = (STPDE_ABLATE_W == 1 ? 5 : 0); q6 < 6; ++q6)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -348,10 +355,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     }
     }
     if (NBUF == 2) {
-      produce(nx, buf ^ 1);
-      transpose_p(raw, pa);
-      pack_p(pa);
-      __syncthreads();
+      if (STPDE_ABLATE_W != 3) produce(nx, buf ^ 1);
+      if (STPDE_ABLATE_W != 2) {
+        transpose_p(raw, pa);
+        pack_p(pa);
+      }
+      if (STPDE_ABLATE_W != 5) __syncthreads();
       buf ^= 1;
     } else {
       __syncthreads();
