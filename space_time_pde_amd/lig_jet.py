@@ -451,10 +451,9 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
             with _timed("xbar_scatter"):
                 check(L.stpde_lig_xbar_rows(C.byref(xd), ab, wt, ptr(xrows), st))
                 n_nodes = meta.B * meta.grid_shape[0] * meta.grid_shape[1] * meta.grid_shape[2]
-                cl = cell.long()
-                perm = torch.sort(cl, stable=True)[1].int()
+                perm = torch.sort(cell, stable=True)[1].int()          # int32 keys: radix sort
                 counts = torch.zeros(n_nodes + 1, device=dev, dtype=torch.int32)
-                counts.index_add_(0, cl + 1, torch.ones(1, device=dev, dtype=torch.int32).expand(Pc))
+                counts.index_add_(0, cell + 1, torch.ones(1, device=dev, dtype=torch.int32).expand(Pc))
                 start = torch.cumsum(counts, 0, dtype=torch.int32)     # start[c] = number of points in cells < c
                 check(L.stpde_lig_dlatent_reduce(meta.B, meta.grid_shape[0], meta.grid_shape[1], meta.grid_shape[2],
                                                  plan.cin, ptr(xrows), ptr(perm), ptr(start), ptr(dlatent), st))
