@@ -120,6 +120,15 @@ int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const fl
                         float* out_pre, const float* cw /* combined-stream weights or NULL */,
                         const void* Wh_pack_bf16, void* stream);
 
+/* Fused forward of the three narrowest layers fc3 -> fc4 -> fc5 (src/implicit_net.py:48-54) for nf = 16 * nf16, nf16 in
+ * {1, 2}: equivalent to three stpde_jet_layer_fwd calls, but the inter-layer data stays in registers (the accumulator
+ * tiles of one layer are the B operand of the next); the pre-activations of all three layers are written for the backward.
+ * Wh_pack / Ws_pack / tanc / out_pre: HOST arrays of 3 device pointers (layers 3, 4, 5).  Stream sets (0,0) (3,0)
+ * (3,1 combined) (3,2). */
+int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
+                       const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
+                       float* const* out_pre, const float* cw, void* stream);
+
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
@@ -154,6 +154,8 @@ _SIGNATURES = {
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
     "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
     "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 12, C.c_int),
+    "stpde_jet_tail_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, _VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP),
+                            C.POINTER(_VP), _VP, _VP], C.c_int),
     "stpde_jet_tan0_reduce": ([C.c_int, C.c_int, _VP, _VP, C.c_int, _VP], C.c_int),
     "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 9, C.c_int),
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),

@@ -1,0 +1,180 @@
+// Fused forward of the three narrowest IM-NET layers (fc3 -> fc4 -> fc5 of src/implicit_net.py:48-54) on all derivative
+// streams: one wave owns a row tile, runs fc3 from the stashed layer-2 pre-activations, and then feeds the accumulator
+// tiles of each layer -- whose C/D register image is the B-operand image -- through the activation jet straight into the
+// next layer's MFMAs: the inter-layer data never leaves the registers.  The pre-activations of all three layers are still
+// written (the backward needs them), but each is written once and never read back in the forward pass: 78 KB per tile
+// instead of 114 KB for the three separate kernels, two launches fewer.
+// Compiled for the reference widths nf = 32 (NFT = 2: 128 -> 64 -> 32 -> out) and nf = 16 (NFT = 1) and for the training
+// stream sets; every other shape keeps the per-layer kernels (jet_layer_impl.h).
+#include "jet_layer_impl.h"
+
+struct TailArgs {
+  const float* in2;              // [tile][S][KT3][256] pre-activations of the layer in front (layer 2)
+  const float* X;                // [tile][XT][256]
+  const float *Wh[3], *Ws[3], *tanc[3];
+  float* out[3];                 // [tile][S][MT_l][256]
+  const float* cw;
+  int ntiles;
+  stpde_jet_cfg cfg;
+};
+
+template <int S1, int S2, int ACT, int NFT>
+__global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
+  constexpr int S = 1 + S1 + S2;
+  constexpr int KT3 = 4 * NFT, MT3 = 2 * NFT, MT4 = NFT, MT5 = 1;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.ntiles) return;
+  const int lo = lane * 4;
+  float cq[6];
+  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  f32x4 xb[XT];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+
+  // epilogue of one layer: skip GEMM with the raw input (bias through its ones column), tangent constants, store
+  auto finish = [&](int l, int MT, int mt, f32x4* acc) {
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+      const f32x4 w = ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
+    }
+    if (S1 == 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[1 + d] += ld4(a.tanc[l] + ((size_t)d * MT + mt) * 256 + lo);
+    }
+#pragma unroll
+    for (int st = 0; st < S; ++st) st4(a.out[l] + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[st]);
+  };
+
+  // ---- fc3: B operand from the stash (one k-tile prefetched ahead), all MT3 output tiles in registers
+  f32x4 acc3[MT3][S];
+#pragma unroll
+  for (int mi = 0; mi < MT3; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc3[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* bin = a.in2 + (size_t)tile * S * KT3 * 256 + lo;
+    f32x4 raw[S], w[MT3];
+#pragma unroll
+    for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT3) * 256);
+#pragma unroll
+    for (int mi = 0; mi < MT3; ++mi) w[mi] = ld4(a.Wh[0] + ((size_t)mi) * 256 + lo);
+#pragma unroll
+    for (int kt = 0; kt < KT3; ++kt) {
+      const int kn = kt + 1 < KT3 ? kt + 1 : kt;
+      f32x4 rawn[S], wn[MT3], B[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) rawn[st] = ld4(bin + ((size_t)st * KT3 + kn) * 256);
+#pragma unroll
+      for (int mi = 0; mi < MT3; ++mi) wn[mi] = ld4(a.Wh[0] + ((size_t)kn * MT3 + mi) * 256 + lo);
+      act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
+#pragma unroll
+      for (int mi = 0; mi < MT3; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int st = 0; st < S; ++st) acc3[mi][st] = mfma4(w[mi][r], B[st][r], acc3[mi][st]);
+#pragma unroll
+      for (int st = 0; st < S; ++st) raw[st] = rawn[st];
+#pragma unroll
+      for (int mi = 0; mi < MT3; ++mi) w[mi] = wn[mi];
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT3; ++mi) finish(0, MT3, mi, acc3[mi]);
+
+  // ---- fc4: the k-tiles are the accumulator tiles of fc3 (C/D image == B image)
+  f32x4 acc4[MT4][S];
+#pragma unroll
+  for (int mi = 0; mi < MT4; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc4[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < MT3; ++kt) {
+    f32x4 B[S];
+    act_jet_fwd<S1, S2, ACT>(a.cfg, acc3[kt], B, cq);
+#pragma unroll
+    for (int mi = 0; mi < MT4; ++mi) {
+      const f32x4 w = ld4(a.Wh[1] + ((size_t)kt * MT4 + mi) * 256 + lo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int st = 0; st < S; ++st) acc4[mi][st] = mfma4(w[r], B[st][r], acc4[mi][st]);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT4; ++mi) finish(1, MT4, mi, acc4[mi]);
+
+  // ---- fc5 (no activation after it, src/implicit_net.py:54)
+  f32x4 acc5[S];
+#pragma unroll
+  for (int st = 0; st < S; ++st) acc5[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < MT4; ++kt) {
+    f32x4 B[S];
+    act_jet_fwd<S1, S2, ACT>(a.cfg, acc4[kt], B, cq);
+    const f32x4 w = ld4(a.Wh[2] + ((size_t)kt * MT5) * 256 + lo);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int st = 0; st < S; ++st) acc5[st] = mfma4(w[r], B[st][r], acc5[st]);
+  }
+  finish(2, MT5, 0, acc5);
+}
+
+template <int S1, int S2, int ACT>
+static int launch_tail_nft(const TailArgs& a, int nft, hipStream_t stream) {
+  const dim3 grid((a.ntiles + 3) / 4);
+  if (nft == 2)
+    STPDE_LAUNCH((k_tail_fwd<S1, S2, ACT, 2>), grid, dim3(256), 0, stream, a);
+  else
+    STPDE_LAUNCH((k_tail_fwd<S1, S2, ACT, 1>), grid, dim3(256), 0, stream, a);
+  return stpde_check_launch("k_tail_fwd");
+}
+
+template <int S1, int S2>
+static int launch_tail_act(const TailArgs& a, int nft, hipStream_t stream) {
+  switch (a.cfg.act) {
+    case STPDE_ACT_TANH: return launch_tail_nft<S1, S2, STPDE_ACT_TANH>(a, nft, stream);
+    case STPDE_ACT_RELU: return launch_tail_nft<S1, S2, STPDE_ACT_RELU>(a, nft, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_tail_nft<S1, S2, STPDE_ACT_SOFTPLUS>(a, nft, stream);
+    case STPDE_ACT_ELU: return launch_tail_nft<S1, S2, STPDE_ACT_ELU>(a, nft, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_tail_nft<S1, S2, STPDE_ACT_LEAKYRELU>(a, nft, stream);
+    default: return launch_tail_nft<S1, S2, STPDE_ACT_SWISH>(a, nft, stream);
+  }
+}
+
+extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
+                                  const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
+                                  float* const* out_pre, const float* cw, void* stream) {
+  if (!cfg || ntiles <= 0 || (nf16 != 1 && nf16 != 2) || !in_pre2 || !X || !Wh_pack || !Ws_pack || !tanc || !out_pre ||
+      cfg->act < 0 || cfg->act > 5) {
+    stpde_set_error("jet_tail_fwd: bad argument (nf must be 16 or 32)");
+    return STPDE_E_BADARG;
+  }
+  TailArgs a{};
+  a.in2 = in_pre2;
+  a.X = X;
+  for (int l = 0; l < 3; ++l) {
+    if (!Wh_pack[l] || !Ws_pack[l] || !out_pre[l] || (cfg->S1 && !tanc[l])) {
+      stpde_set_error("jet_tail_fwd: null pointer for layer %d", 3 + l);
+      return STPDE_E_BADARG;
+    }
+    a.Wh[l] = Wh_pack[l];
+    a.Ws[l] = Ws_pack[l];
+    a.tanc[l] = tanc[l];
+    a.out[l] = out_pre[l];
+  }
+  a.cw = cw;
+  a.ntiles = ntiles;
+  a.cfg = *cfg;
+  const int S1 = cfg->S1, S2 = cfg->S2;
+  if (S1 == 0 && S2 == 0) return launch_tail_act<0, 0>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 0) return launch_tail_act<3, 0>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 1 && cfg->combo && cw) return launch_tail_act<3, 1>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 2) return launch_tail_act<3, 2>(a, nf16, (hipStream_t)stream);
+  stpde_set_error("jet_tail_fwd: stream configuration S1=%d S2=%d not compiled", S1, S2);
+  return STPDE_E_UNSUPPORTED;
+}

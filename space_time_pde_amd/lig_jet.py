@@ -356,8 +356,21 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         lcfg = JetCfg()
         lcfg.S1, lcfg.S2, lcfg.act, lcfg.act_param = 0, 3, cfg.act, cfg.act_param
         lnt = nt // 4
+    # fc3 -> fc4 -> fc5 in one kernel (inter-layer data in registers) for the reference widths and the training stream sets
+    tail = (fused_tail and not vt and plan.nf in (16, 32) and (cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
+            and (cfg.S2 != 1 or cw is not None))
     for l in range(1, 6):
         lay = plan.layers[l]
+        if tail and l == 3:
+            outs = [torch.empty(nt * S * plan.layers[k]["MT"] * _FRAG, device=dev) for k in (3, 4, 5)]
+            arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            with _timed("tail_fwd"):
+                check(L.stpde_jet_tail_fwd(C.byref(cfg), nt, plan.nf // 16, ptr(prev), ptr(X),
+                                           arr([pv(packs, k, "Wh") for k in (3, 4, 5)]),
+                                           arr([pv(packs, k, "Ws") for k in (3, 4, 5)]),
+                                           arr([pv(packs, k, "tanc") for k in (3, 4, 5)]), arr(outs), ptr(cw), st))
+            bufs += outs
+            break
         out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
         w16 = meta.packs16.get((l, "Wh")) if meta.packs16 else None
         d = _layer_desc(lnt, lay, lcfg, l == 1, meta.nsplit if w16 is not None else 0)
@@ -549,6 +562,8 @@ value_tiles = os.environ.get("STPDE_VALUE_TILES", "1") != "0"
 # layer-0 tangent-stream adjoints as per-tile row sums (STPDE_TAN0_ROWSUM=0: full fragment blocks, for A/B timing)
 tan0_rowsum = os.environ.get("STPDE_TAN0_ROWSUM", "1") != "0"
 wgrad_split = os.environ.get("STPDE_WGRAD_SPLIT", "1") != "0"
+# forward of fc3 -> fc4 -> fc5 in one kernel (STPDE_FUSED_TAIL=0: three per-layer kernels)
+fused_tail = os.environ.get("STPDE_FUSED_TAIL", "1") != "0"
 
 DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
 
