@@ -129,6 +129,16 @@ int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
                        const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
                        float* const* out_pre, const float* cw, void* stream);
 
+/* Fused input-gradient chain of the same three layers: abar5 (adjoint of fc5's output rows, from stpde_lig_reduce_bwd)
+ * -> abar4 -> abar3 -> abar2; equivalent to stpde_jet_layer_bwd on layers 5, 4, 3, but the adjoints of layers 4 and 3 feed
+ * the next GEMM from the registers.  pre[0..2]: stashed pre-activations of the outputs of fc2, fc3, fc4; abar_out[0..2]:
+ * where their adjoints go -- abar_out[l] may be pre[l] (in place) when no later kernel needs those pre-activations: the
+ * weight gradient of layer l+1 reads pre[l], so either it runs first or abar_out[l] is a separate buffer.
+ * WhT_pack: HOST array of the 3 transposed packs of layers 3, 4, 5. */
+int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
+                       const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar,
+                       void* stream);
+
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when

@@ -178,3 +178,165 @@ extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16
   stpde_set_error("jet_tail_fwd: stream configuration S1=%d S2=%d not compiled", S1, S2);
   return STPDE_E_UNSUPPORTED;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused input-gradient chain of the same three layers (what loss.backward(), experiments/rb2d/train.py:77, does through
+// fc5 -> fc4 -> fc3): abar_5 (from the corner-reduction adjoint) -> W5^T -> activation-jet adjoint with the stashed
+// pre-activations of fc4's output -> abar_4 -> W4^T -> ... -> abar_2, written over the layer-2 stash.  The adjoints of
+// layers 4 and 3 are the B operand of the next GEMM straight from the registers (C/D image == B image); they are still
+// written once (weight gradients and the latent-gradient GEMM read them), but not read back by this chain.
+// ------------------------------------------------------------------------------------------------------------
+struct TailBwdArgs {
+  const float* abar5;            // [tile][S][1][256]
+  const float* WhT[3];           // layers 3, 4, 5: [MT_l][KT_l][256] transposed packs
+  const float* pre[3];           // stashed pre-activations of the outputs of layers 2, 3, 4
+  float* out[3];                 // their adjoints (may alias pre[l]: each block is read before it is written)
+  const float* cw;
+  float* pbar;
+  int ntiles;
+  stpde_jet_cfg cfg;
+};
+
+template <int S1, int S2, int ACT, int NFT>
+__global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
+  constexpr int S = 1 + S1 + S2;
+  constexpr int T2 = 4 * NFT, T3 = 2 * NFT, T4 = NFT;     // feature tiles of the outputs of layers 2, 3, 4
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.ntiles) return;
+  const int lo = lane * 4;
+  float cq[6];
+  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  float pacc = 0.f;
+  const bool swish = (ACT == STPDE_ACT_SWISH) && a.pbar;
+
+  // hbar (accumulator tile) + stored pre-activations -> adjoint, written over the pre-activations and returned in acc
+  auto adjoint = [&](int l, int MT, int mt, f32x4* acc) {
+    const float* buf_in = a.pre[l];
+    float* buf = a.out[l];
+    f32x4 pre[S], ab[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) pre[st] = ld4(buf_in + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+    act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc, ab, cq);
+    if (swish) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc, cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      st4(buf + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
+      acc[st] = ab[st];
+    }
+  };
+
+  // ---- through fc5: abar_5 [1 tile] -> hbar_4 [T4 tiles] -> abar_4
+  f32x4 b5[S];
+#pragma unroll
+  for (int st = 0; st < S; ++st) b5[st] = ld4(a.abar5 + ((size_t)tile * S + st) * 256 + lo);
+  f32x4 a4[T4][S];
+#pragma unroll
+  for (int mi = 0; mi < T4; ++mi) {
+    const f32x4 w = ld4(a.WhT[2] + ((size_t)mi) * 256 + lo);          // [MT5 = 1][KT = T4]: block (0, mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) a4[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int st = 0; st < S; ++st) a4[mi][st] = mfma4(w[r], b5[st][r], a4[mi][st]);
+    adjoint(2, T4, mi, a4[mi]);
+  }
+  // ---- through fc4: abar_4 -> hbar_3 [T3 tiles] -> abar_3
+  f32x4 a3[T3][S];
+#pragma unroll
+  for (int mi = 0; mi < T3; ++mi) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) a3[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < T4; ++kt) {
+      const f32x4 w = ld4(a.WhT[1] + ((size_t)kt * T3 + mi) * 256 + lo);   // [MT4 = T4][KT = T3]
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int st = 0; st < S; ++st) a3[mi][st] = mfma4(w[r], a4[kt][st][r], a3[mi][st]);
+    }
+    adjoint(1, T3, mi, a3[mi]);
+  }
+  // ---- through fc3: abar_3 -> hbar_2 [T2 tiles] -> abar_2, two output tiles at a time
+#pragma unroll
+  for (int m0 = 0; m0 < T2; m0 += 2) {
+    f32x4 a2[2][S];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int st = 0; st < S; ++st) a2[e][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < T3; ++kt) {
+      f32x4 w[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) w[e] = ld4(a.WhT[0] + ((size_t)kt * T2 + m0 + e) * 256 + lo);   // [MT3 = T3][KT = T2]
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int st = 0; st < S; ++st) a2[e][st] = mfma4(w[e][r], a3[kt][st][r], a2[e][st]);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) adjoint(0, T2, m0 + e, a2[e]);
+  }
+  if (swish) {
+    const float v = wave_sum(pacc);
+    if (lane == 0) atomicAdd(a.pbar + (blockIdx.x % STPDE_PBAR_SLOTS), v);
+  }
+}
+
+template <int S1, int S2, int ACT>
+static int launch_tailb_nft(const TailBwdArgs& a, int nft, hipStream_t stream) {
+  const dim3 grid((a.ntiles + 3) / 4);
+  if (nft == 2)
+    STPDE_LAUNCH((k_tail_bwd<S1, S2, ACT, 2>), grid, dim3(256), 0, stream, a);
+  else
+    STPDE_LAUNCH((k_tail_bwd<S1, S2, ACT, 1>), grid, dim3(256), 0, stream, a);
+  return stpde_check_launch("k_tail_bwd");
+}
+
+template <int S1, int S2>
+static int launch_tailb_act(const TailBwdArgs& a, int nft, hipStream_t stream) {
+  switch (a.cfg.act) {
+    case STPDE_ACT_TANH: return launch_tailb_nft<S1, S2, STPDE_ACT_TANH>(a, nft, stream);
+    case STPDE_ACT_RELU: return launch_tailb_nft<S1, S2, STPDE_ACT_RELU>(a, nft, stream);
+    case STPDE_ACT_SOFTPLUS: return launch_tailb_nft<S1, S2, STPDE_ACT_SOFTPLUS>(a, nft, stream);
+    case STPDE_ACT_ELU: return launch_tailb_nft<S1, S2, STPDE_ACT_ELU>(a, nft, stream);
+    case STPDE_ACT_LEAKYRELU: return launch_tailb_nft<S1, S2, STPDE_ACT_LEAKYRELU>(a, nft, stream);
+    default: return launch_tailb_nft<S1, S2, STPDE_ACT_SWISH>(a, nft, stream);
+  }
+}
+
+extern "C" int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5,
+                                  const float* const* WhT_pack, const float* const* pre, float* const* abar_out,
+                                  const float* cw, float* act_param_bar, void* stream) {
+  if (!cfg || ntiles <= 0 || (nf16 != 1 && nf16 != 2) || !abar5 || !WhT_pack || !pre || !abar_out || cfg->act < 0 ||
+      cfg->act > 5) {
+    stpde_set_error("jet_tail_bwd: bad argument (nf must be 16 or 32)");
+    return STPDE_E_BADARG;
+  }
+  TailBwdArgs a{};
+  a.abar5 = abar5;
+  for (int l = 0; l < 3; ++l) {
+    if (!WhT_pack[l] || !pre[l] || !abar_out[l]) {
+      stpde_set_error("jet_tail_bwd: null pointer for layer %d", 3 + l);
+      return STPDE_E_BADARG;
+    }
+    a.WhT[l] = WhT_pack[l];
+    a.pre[l] = pre[l];
+    a.out[l] = abar_out[l];
+  }
+  a.cw = cw;
+  a.pbar = act_param_bar;
+  a.ntiles = ntiles;
+  a.cfg = *cfg;
+  const int S1 = cfg->S1, S2 = cfg->S2;
+  if (S1 == 0 && S2 == 0) return launch_tailb_act<0, 0>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 0) return launch_tailb_act<3, 0>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 1 && cfg->combo && cw) return launch_tailb_act<3, 1>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 2) return launch_tailb_act<3, 2>(a, nf16, (hipStream_t)stream);
+  stpde_set_error("jet_tail_bwd: stream configuration S1=%d S2=%d not compiled", S1, S2);
+  return STPDE_E_UNSUPPORTED;
+}

@@ -409,24 +409,39 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     split0 = SP0 == 4 and tan0_rowsum
     abar0 = torch.empty(nt * (1 if split0 else SP0) * MT0 * _FRAG, device=dev)
     tan0 = torch.empty(nt * MT0 * 48, device=dev) if split0 else None
+    # fc5 -> fc4 -> fc3 input gradients in one kernel (adjoints of layers 4 and 3 feed the next GEMM from the registers).
+    # Order: wgrad_5 (needs the pre-activations of fc4's output intact), the chain (abar4 in place; abar3 / abar2 into
+    # fresh buffers because wgrad_4 / wgrad_3 still need the pre-activations they would overwrite), wgrad_4, wgrad_3.
+    tail = (fused_tail and plan.nf in (16, 32) and (cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
+            and (cfg.S2 != 1 or cw is not None))
+    abar = {l: bufs[l] for l in range(1, 6)}      # where the adjoint of layer l's output rows lives once it exists
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
         d = _layer_desc(nt, lay, cfg, l == 1, meta.nsplit if w16 is not None else 0)
         # weight gradient: same operand mode as the layer kernels (STPDE_WGRAD_SPLIT=0 keeps it on exact-fp32 MFMA in
-        # "fp32x3" mode, for A/B timing)
-        # (only the wide layers, MT >= 8, have bf16-pipe weight-gradient kernels; flagging a narrow layer would take it off
-        # its per-wave kernel)
+        # "fp32x3" mode, for A/B timing); only the wide layers, MT >= 8, have bf16-pipe weight-gradient kernels --
+        # flagging a narrow layer would take it off its per-wave kernel
         dwg = _layer_desc(nt, lay, cfg, l == 1, (meta.nsplit if wgrad_split or meta.nsplit == 1 else 0)
                           if (w16 is not None and lay["MT"] >= 8) else 0)
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
-                check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(bufs[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
+                check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(abar[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
                                         ptr(XR), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
                                         ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
+        if tail and l >= 3:
+            if l == 5:
+                abar[3], abar[2] = torch.empty_like(bufs[3]), torch.empty_like(bufs[2])
+                arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+                with _timed("tail_dgrad"):
+                    check(L.stpde_jet_tail_bwd(C.byref(cfg), nt, plan.nf // 16, ptr(bufs[5]),
+                                               arr([pv(packs, k, "WhT") for k in (3, 4, 5)]),
+                                               arr([bufs[2], bufs[3], bufs[4]]), arr([abar[2], abar[3], abar[4]]),
+                                               ptr(cw), ptr(pbar), st))
+            continue
         with _timed("layer%d_dgrad" % l):
-            check(L.stpde_jet_layer_bwd(C.byref(d), ptr(bufs[l]), ptr(pv(packs, l, "WhT")),
+            check(L.stpde_jet_layer_bwd(C.byref(d), ptr(abar[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
                                         ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), ptr(w16),
                                         ptr(tan0) if l == 1 else None, st))
@@ -452,7 +467,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         for l in range(5):
             xd.MT[l] = plan.layers[l]["MT"]
             xd.SP[l] = (1 if split0 else SP0) if l == 0 else S
-            ab[l] = (abar0 if l == 0 else bufs[l]).data_ptr()
+            ab[l] = (abar0 if l == 0 else abar[l]).data_ptr()
             wt[l] = pv(packs, l, "WsT").data_ptr()
         if not deterministic_dlatent:
             with _timed("xbar_scatter"):
