@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=1 << 20)
     ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
-    ap.add_argument("--chunk", type=int, default=1 << 18, help="points per launch chunk")
+    ap.add_argument("--chunk", type=int, default=1 << 20, help="points per launch chunk")
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="fp32 = the headline / parity path; bf16 = BASELINE configs[3]: bf16 MFMA operands in the "
                          "wide IM-NET layers, fp32 accumulation (NOT the headline metric)")
@@ -285,8 +285,13 @@ def main():
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (same chunk size)
             tj = json.load(open(args.traffic_json))
-            if tj.get("chunk") == min(args.chunk, n_local) and tj.get("act") == args.act and dom in tj["kernels"]:
-                traffic, traffic_src = tj["kernels"][dom]["hbm_bytes_per_launch"], tj.get("source")
+            if tj.get("act") == args.act and dom in tj["kernels"]:
+                # the counter passes were taken on a 2^18-point launch; these kernels stream every row tile exactly once,
+                # so the bytes of a launch scale with its number of tiles
+                scale = min(args.chunk, n_local) / float(tj["chunk"])
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"] * scale
+                traffic_src = tj.get("source") + ("" if scale == 1 else "; measured on a %d-point launch, scaled x%g to "
+                                                  "this launch's tile count" % (tj["chunk"], scale))
         except (OSError, ValueError, KeyError):
             pass
         roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",

@@ -580,7 +580,8 @@ wgrad_split = os.environ.get("STPDE_WGRAD_SPLIT", "1") != "0"
 # forward of fc3 -> fc4 -> fc5 in one kernel (STPDE_FUSED_TAIL=0: three per-layer kernels)
 fused_tail = os.environ.get("STPDE_FUSED_TAIL", "1") != "0"
 
-DEFAULT_CHUNK = 1 << 18   # query points per launch chunk (bounds the per-chunk backward scratch: 17 GB at 2^18)
+DEFAULT_CHUNK = 1 << 20   # query points per launch chunk (per-chunk backward scratch: ~50 GB at 2^20; measured on
+                          # MI355X: 2^17 / 2^18 / 2^19 / 2^20 points per chunk -> 459.8 / 458.7 / 455.5 / 454.3 ms per step)
 
 # MFMA operand precision of the hidden-to-hidden GEMMs of the wide layers: "fp32" (exact-fp32 MFMA, the default and
 # the parity path) or "bf16" (BASELINE config 4: bf16 operands, fp32 accumulation, everything else fp32).
