@@ -114,11 +114,13 @@ typedef struct {
   int mfma_bf16;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
- * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16. */
+ * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16.
+ * z0 (first_hidden only, may be NULL = not kept; ignored in the value-tile mode): [tile][KT][256] receives the value
+ * stream of the layer-0 pre-activations the kernel regenerates from X -- the stash stpde_jet_layer_bwd(first_hidden) reads. */
 int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X, const float* Wh_pack,
                         const float* Ws_pack, const float* tanc, const float* W0s_pack, const float* tanc0,
                         float* out_pre, const float* cw /* combined-stream weights or NULL */,
-                        const void* Wh_pack_bf16, void* stream);
+                        const void* Wh_pack_bf16, float* z0, void* stream);
 
 /* Fused forward of the three narrowest layers fc3 -> fc4 -> fc5 (src/implicit_net.py:48-54) for nf = 16 * nf16, nf16 in
  * {1, 2}: equivalent to three stpde_jet_layer_fwd calls, but the inter-layer data stays in registers (the accumulator
@@ -142,7 +144,10 @@ int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):
  *   hbar = W_h^T * abar_out ; abar_in = act_jet_adjoint(hbar, in_pre)   written over in_pre (in place) when
- * first_hidden == 0, or into abar0[tile][1+S1][KT] (layer 0, pre-activations regenerated from X) otherwise.
+ * first_hidden == 0, or into abar0[tile][1+S1][KT] otherwise (layer 0; its pre-activations are read from z0
+ * [tile][KT][256], the value-stream stash written by stpde_jet_layer_fwd(first_hidden) -- round 2: regenerating them from X
+ * cost 3.5 % of this kernel's MFMAs; X and W0s_pack are no longer read and may be NULL).  z0 may be the same buffer as abar0
+ * when abar0 holds the value stream only (abar0_tan given, or S1 == 0): every lane reads its element before it writes it.
  * abar0_tan (first_hidden, S1 == 3; may be NULL): layer 0's tangent streams are the constant columns W0[:, d], so their
  * adjoints are needed only summed over rows; when given, abar0 receives the VALUE stream only ([tile][KT][256]) and
  * abar0_tan [tile][KT][3][16] the per-tile row sums of the three tangent-stream adjoints (a quarter of the traffic);
@@ -152,7 +157,7 @@ int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
 int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, float* in_pre,
                         const float* X, const float* W0s_pack, const float* tanc0, float* abar0, const float* cw,
                         float* act_param_bar, const void* WhT_pack_bf16 /* as Wh_pack_bf16, of WhT_pack */,
-                        float* abar0_tan, void* stream);
+                        float* abar0_tan, const float* z0, void* stream);
 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
@@ -187,8 +192,10 @@ typedef struct {
   int MT[8];
   int SP[8];
 } stpde_xbar_desc;
-/* abar / WsT_pack: HOST arrays of nlayers device pointers. */
-int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+/* abar / WsL_pack: HOST arrays of nlayers device pointers.  WsL_pack[l] = [MT_l][XL][64 lanes][4]: A operand of W_s,l^T
+ * restricted to the latent channels, XL = ceil(C / 16) tiles of 16 channels (lane (g, j), register r holds
+ * W_s,l[16 mt + 4 g + r][dim + 16 xl + j], zero beyond channel C - 1); the coordinate / bias columns get no adjoint. */
+int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsL_pack,
                            const int* cell, float* dlatent, void* stream);
 /* Deterministic variant (default of the Python host): the same xbar, but the latent channels of every corner row are
  * written to xrows [16 * ntiles][CP] (CP = C rounded up to a multiple of 4; row = 8 * point + corner) instead of being
@@ -196,7 +203,7 @@ int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar, c
  * of the owning cell in ascending index), like the reference's deterministic CPU index_put_(accumulate=True) (:65-66).
  * perm [P] = point indices in stable cell order, start [n_nodes + 1] = first position of each cell id (cell id = linear
  * index of the cell's corner-0 node incl. batch, as written by stpde_lig_gather); dlatent is accumulated into (+=). */
-int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsL_pack,
                         float* xrows, void* stream);
 int stpde_lig_dlatent_reduce(int B, int n0, int n1, int n2, int C, const float* xrows, const int* perm,
                              const int* start, float* dlatent, void* stream);

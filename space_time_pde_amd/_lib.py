@@ -152,8 +152,8 @@ _SIGNATURES = {
     "stpde_trace_enable": ([C.c_int], C.c_int),
     "stpde_trace_read": ([C.c_char_p, C.c_ulong], C.c_long),
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
-    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
-    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 12, C.c_int),
+    "stpde_jet_layer_fwd": ([C.POINTER(LayerDesc)] + [_VP] * 12, C.c_int),
+    "stpde_jet_layer_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 13, C.c_int),
     "stpde_jet_tail_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, _VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP),
                             C.POINTER(_VP), _VP, _VP], C.c_int),
     "stpde_jet_tail_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _VP,

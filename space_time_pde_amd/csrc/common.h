@@ -41,6 +41,20 @@ __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Optional 16-byte stores without a branch: a raw buffer descriptor over [base, base + bytes) -- built from wave-uniform
+// values only -- drops every store that falls outside it, so bytes = 0 switches the stores off in hardware and the
+// surrounding basic block stays in one piece (a uniform `if (ptr)` would split the MFMA / VALU interleaving of the loop).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t opt_store_rsrc(float* base, unsigned bytes) {
+  const unsigned long long u = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(base ? bytes : 0u), 0x00020000);
+}
+__device__ __forceinline__ void opt_st4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+
 // Store a column-major ("D") fragment block held in registers (lane 16g+j: features 4g..4g+3 of row j) into the
 // row-major ("R") image of the same 16x16 block (lane 16g'+c: rows 4g'..4g'+3 of feature c): pure addressing.
 __device__ __forceinline__ void st_R(float* block, int lane, f32x4 v) {

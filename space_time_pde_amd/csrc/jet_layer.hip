@@ -33,7 +33,7 @@ static int check_cfg(const stpde_layer_desc* d) {
 extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const float* X,
                                    const float* Wh_pack, const float* Ws_pack, const float* tanc,
                                    const float* W0s_pack, const float* tanc0, float* out_pre, const float* cw,
-                                   const void* Wh_pack_bf16, void* stream) {
+                                   const void* Wh_pack_bf16, float* z0, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   LayerArgs a{};
@@ -61,6 +61,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
       stpde_set_error("jet_layer_fwd: first_hidden needs W0s_pack/tanc0");
       return STPDE_E_BADARG;
     }
+    a.Z0 = z0;
     return dispatch_streams(a, 1, (hipStream_t)stream);
   }
   if (d->KT > 0 && (!in_pre || !Wh_pack)) {
@@ -73,7 +74,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
                                    float* abar0, const float* cw, float* act_param_bar,
-                                   const void* WhT_pack_bf16, float* abar0_tan, void* stream) {
+                                   const void* WhT_pack_bf16, float* abar0_tan, const float* z0, void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -96,12 +97,17 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
     return STPDE_E_BADARG;
   }
   if (d->first_hidden) {
-    if (!X || !W0s_pack || !abar0 || (d->cfg.S1 && !tanc0)) {
-      stpde_set_error("jet_layer_bwd: first_hidden needs X/W0s_pack/tanc0/abar0");
+    if (!z0 || !abar0 || (d->cfg.S1 && !tanc0)) {
+      stpde_set_error("jet_layer_bwd: first_hidden needs z0/tanc0/abar0");
+      return STPDE_E_BADARG;
+    }
+    if (z0 == abar0 && d->cfg.S1 && !abar0_tan) {
+      stpde_set_error("jet_layer_bwd: z0 may alias abar0 only when abar0 holds the value stream alone");
       return STPDE_E_BADARG;
     }
     a.Out = abar0;
     a.Tan0 = abar0_tan;
+    a.Z0 = const_cast<float*>(z0);
     return dispatch_streams(a, 3, (hipStream_t)stream);
   }
   if (!in_pre) {

@@ -39,6 +39,9 @@ struct LayerArgs {
   float* pbar;         // dgrad, swish only: [STPDE_PBAR_SLOTS] accumulators of the adjoint of beta (nullable)
   float* Tan0;         // EPI_ADJ_L0, nullable: [tile][MT][3][16] row sums of the tangent-stream adjoints of layer 0; when
                        // given, Out holds the VALUE stream only: [tile][MT][256]
+  float* Z0;           // [tile][KT or MT][256] value stream of the layer-0 pre-activations: written by the PRO_L0 forward
+                       // (nullable there: the stores are dropped), read by EPI_ADJ_L0 instead of regenerating it from X
+                       // (may alias Out when Out holds the value stream only: each lane reads its element before it writes it)
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   stpde_jet_cfg cfg;
@@ -90,7 +93,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
 #pragma unroll
         for (int st = 0; st < S; ++st) pre[st] = ld4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
       } else {
-        pre[0] = layer0_block(a.W0s, MT, mt, lo, xb);
+        pre[0] = ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
@@ -148,13 +151,14 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
   constexpr bool VT = S1 == 0 && S2 > 0;
   constexpr int NX = VT ? S : 1;             // value-tile mode: one raw-input tile per stream
   f32x4 xb[NX][XT];
-  if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
+  if (PRO == PRO_L0 || EPI == EPI_FWD) {
 #pragma unroll
     for (int sv = 0; sv < NX; ++sv)
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
   }
   const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
+  const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
 
   // the wave walks all output chunks of its tile: the B blocks it re-reads stay hot in this CU's L1/L2
   for (int mt0 = 0; mt0 < MT; mt0 += MC) {
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
     if (PRO == PRO_L0) {
 #pragma unroll
       for (int sv = 0; sv < NX; ++sv) raw[sv] = layer0_block(a.W0s, KT, kt, lo, xb[sv]);
+      if (!VT) opt_st4(z0r, kt * 1024 + lane * 16, raw[0]);      // stash for the dgrad epilogue (dropped when Z0 is null)
       if (S1 == 3) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
@@ -284,13 +289,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr bool VT = S1 == 0 && S2 > 0;
   constexpr int NX = VT ? S : 1;             // value-tile mode: one raw-input tile per stream
   f32x4 xb[NX][XT];
-  if (PRO == PRO_L0 || EPI == EPI_FWD || EPI == EPI_ADJ_L0) {
+  if (PRO == PRO_L0 || EPI == EPI_FWD) {
 #pragma unroll
     for (int sv = 0; sv < NX; ++sv)
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
   }
   const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
+  const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
 
   // produce the B block of k-tile kt (this wave's turn) into ring slot (buf, slot)
   auto produce = [&](int kt, int buf, int slot) {
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     if (PRO == PRO_L0) {
 #pragma unroll
       for (int sv = 0; sv < NX; ++sv) raw[sv] = layer0_block(a.W0s, KT, kt, lo, xb[sv]);
+      if (!VT) opt_st4(z0r, kt * 1024 + lane * 16, raw[0]);      // stash for the dgrad epilogue (dropped when Z0 is null)
       if (S1 == 3) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);

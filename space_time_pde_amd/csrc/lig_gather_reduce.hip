@@ -357,7 +357,7 @@ extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int S_mlp, int P, 
 struct XbarArgs {
   stpde_xbar_desc d;
   const float* abar[8];
-  const float* wst[8];  // [MT_l][XT][256]
+  const float* wsl[8];  // [MT_l][XL][256]: A operand of W_s,l^T restricted to the latent channels (row m = channel 16 xl + m)
   const int* cell;
   float* dlatent;
   float* xrows;  // != null: per-row latent adjoints [16 * ntiles][CP] instead of atomics (deterministic path)
@@ -365,127 +365,162 @@ struct XbarArgs {
 };
 
 constexpr int XPAD = 49;   // padded row length (floats) of the 16 x 48 transpose patch: odd -> conflict-free columns
+constexpr int XR = 4;      // row tiles per wave: every weight fragment fetched from L2 feeds XR * XL * 4 MFMAs
 
+// XL = number of 16-channel output tiles (C <= 16 XL).  The coordinate / bias columns of the augmented input get no
+// adjoint (query points carry no gradient), so only the latent channels are contracted.  Round 2: one row tile per wave
+// and all 3 augmented-input tiles made the kernel L2-bound on the weight fragments (3 KB of weights per 1 KB of abar).
+template <int XL>
 __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= a.d.ntiles) return;
+  const int tile0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * XR;
+  if (tile0 >= a.d.ntiles) return;
   const int lo = lane * 4;
-  f32x4 acc[XT];
+  int tl[XR];
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) acc[xt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < XR; ++t) tl[t] = tile0 + t < a.d.ntiles ? tile0 + t : a.d.ntiles - 1;   // clamp, stores are guarded
+  f32x4 acc[XR][XL];
+#pragma unroll
+  for (int t = 0; t < XR; ++t)
+#pragma unroll
+    for (int xl = 0; xl < XL; ++xl) acc[t][xl] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < a.d.nlayers; ++l) {
     const int MT = a.d.MT[l], SP = a.d.SP[l];
-    const float* ab = a.abar[l] + (size_t)tile * SP * MT * 256 + lo;  // stream 0
-    const float* w = a.wst[l] + lo;
+    const float* ab = a.abar[l] + lo;  // stream 0 of tile t starts at (size_t)t * SP * MT * 256
+    const float* w = a.wsl[l] + lo;
+    const size_t tstride = (size_t)SP * MT * 256;
     // two output tiles per iteration (MT is even for every hidden layer): their loads are issued together
     for (int mt = 0; mt + 1 < MT; mt += 2) {
-      f32x4 B0 = ld4(ab + (size_t)mt * 256), B1 = ld4(ab + (size_t)(mt + 1) * 256);
-      f32x4 w0[XT], w1[XT];
+      f32x4 B0[XR], B1[XR], w0[XL], w1[XL];
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) {
-        w0[xt] = ld4(w + ((size_t)mt * XT + xt) * 256);
-        w1[xt] = ld4(w + ((size_t)(mt + 1) * XT + xt) * 256);
+      for (int t = 0; t < XR; ++t) {
+        B0[t] = ld4(ab + tl[t] * tstride + (size_t)mt * 256);
+        B1[t] = ld4(ab + tl[t] * tstride + (size_t)(mt + 1) * 256);
       }
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[xt] = mfma4(w0[xt][r], B0[r], acc[xt]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[xt] = mfma4(w1[xt][r], B1[r], acc[xt]);
+      for (int xl = 0; xl < XL; ++xl) {
+        w0[xl] = ld4(w + ((size_t)mt * XL + xl) * 256);
+        w1[xl] = ld4(w + ((size_t)(mt + 1) * XL + xl) * 256);
       }
+#pragma unroll
+      for (int t = 0; t < XR; ++t)
+#pragma unroll
+        for (int xl = 0; xl < XL; ++xl) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][xl] = mfma4(w0[xl][r], B0[t][r], acc[t][xl]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][xl] = mfma4(w1[xl][r], B1[t][r], acc[t][xl]);
+        }
     }
     if (MT & 1) {
       const int mt = MT - 1;
-      f32x4 B = ld4(ab + (size_t)mt * 256);
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) {
-        f32x4 wv = ld4(w + ((size_t)mt * XT + xt) * 256);
+      for (int xl = 0; xl < XL; ++xl) {
+        f32x4 wv = ld4(w + ((size_t)mt * XL + xl) * 256);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[xt] = mfma4(wv[r], B[r], acc[xt]);
+        for (int t = 0; t < XR; ++t) {
+          f32x4 B = ld4(ab + tl[t] * tstride + (size_t)mt * 256);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][xl] = mfma4(wv[r], B[r], acc[t][xl]);
+        }
       }
     }
   }
   const int g = lane >> 4, j = lane & 15;
   if (a.xrows) {
-    // deterministic path: rows x features through a per-wave LDS patch, then row-major, fully coalesced float4 stores of
-    // the latent channels (features 3 .. 3 + C - 1); the per-node sums are taken by k_dlat_reduce in a fixed order
+    // deterministic path: rows x channels through a per-wave LDS patch, then row-major, fully coalesced float4 stores;
+    // the per-node sums are taken by k_dlat_reduce in a fixed order
     __shared__ float patch[4][16 * XPAD];
     float* pt = patch[threadIdx.x >> 6];
-#pragma unroll
-    for (int xt = 0; xt < XT; ++xt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pt[j * XPAD + 16 * xt + 4 * g + r] = acc[xt][r];
-    __builtin_amdgcn_wave_barrier();
     const int q4 = a.CP >> 2;                       // float4 groups per row
-    float* dst = a.xrows + (size_t)tile * 16 * a.CP;
-    for (int idx = lane; idx < 16 * q4; idx += 64) {
-      const int row = idx / q4, c4 = idx - row * q4;
-      const float* src = pt + row * XPAD + 3 + 4 * c4;
-      f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (4 * c4 + r < a.d.C) ? src[r] : 0.f;
-      st4(dst + (size_t)row * a.CP + 4 * c4, v);
+    for (int t = 0; t < XR; ++t) {
+      if (tile0 + t >= a.d.ntiles) break;
+#pragma unroll
+      for (int xl = 0; xl < XL; ++xl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pt[j * XPAD + 16 * xl + 4 * g + r] = acc[t][xl][r];
+      __builtin_amdgcn_wave_barrier();
+      float* dst = a.xrows + (size_t)(tile0 + t) * 16 * a.CP;
+      for (int idx = lane; idx < 16 * q4; idx += 64) {
+        const int row = idx / q4, c4 = idx - row * q4;
+        const float* src = pt + row * XPAD + 4 * c4;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (4 * c4 + r < a.d.C) ? src[r] : 0.f;
+        st4(dst + (size_t)row * a.CP + 4 * c4, v);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     return;
   }
-  const int p = tile * 2 + (j >> 3), corner = j & 7;
   const int n1 = a.d.n1, n2 = a.d.n2, C = a.d.C;
-  const size_t node =
-      (size_t)a.cell[p] + ((size_t)((corner >> 2) & 1) * n1 + ((corner >> 1) & 1)) * n2 + (corner & 1);
-  float* dst = a.dlatent + node * C;
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt)
+  for (int t = 0; t < XR; ++t) {
+    if (tile0 + t >= a.d.ntiles) break;
+    const int p = (tile0 + t) * 2 + (j >> 3), corner = j & 7;
+    const size_t node =
+        (size_t)a.cell[p] + ((size_t)((corner >> 2) & 1) * n1 + ((corner >> 1) & 1)) * n2 + (corner & 1);
+    float* dst = a.dlatent + node * C;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 16 * xt + 4 * g + r;
-      if (f >= 3 && f < 3 + C) atomicAdd(dst + (f - 3), acc[xt][r]);
-    }
+    for (int xl = 0; xl < XL; ++xl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * xl + 4 * g + r;
+        if (ch < C) atomicAdd(dst + ch, acc[t][xl][r]);
+      }
+  }
 }
 
-static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsL_pack,
                        const int* cell, float* dlatent, float* xrows, void* stream);
 
 extern "C" int stpde_lig_xbar_scatter(const stpde_xbar_desc* d, const float* const* abar,
-                                      const float* const* WsT_pack, const int* cell, float* dlatent, void* stream) {
+                                      const float* const* WsL_pack, const int* cell, float* dlatent, void* stream) {
   if (!cell || !dlatent) {
     stpde_set_error("lig_xbar_scatter: bad argument");
     return STPDE_E_BADARG;
   }
-  return launch_xbar(d, abar, WsT_pack, cell, dlatent, nullptr, stream);
+  return launch_xbar(d, abar, WsL_pack, cell, dlatent, nullptr, stream);
 }
 
-extern "C" int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+extern "C" int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsL_pack,
                                    float* xrows, void* stream) {
   if (!xrows) {
     stpde_set_error("lig_xbar_rows: bad argument");
     return STPDE_E_BADARG;
   }
-  return launch_xbar(d, abar, WsT_pack, nullptr, nullptr, xrows, stream);
+  return launch_xbar(d, abar, WsL_pack, nullptr, nullptr, xrows, stream);
 }
 
-static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsT_pack,
+static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsL_pack,
                        const int* cell, float* dlatent, float* xrows, void* stream) {
   if (!d || d->ntiles <= 0 || d->nlayers < 1 || d->nlayers > 8 || d->C < 1 || 3 + d->C + 1 > 16 * XT || !abar ||
-      !WsT_pack) {
+      !WsL_pack) {
     stpde_set_error("lig_xbar: bad argument");
     return STPDE_E_BADARG;
   }
   XbarArgs a{};
   a.d = *d;
   for (int l = 0; l < d->nlayers; ++l) {
-    if (!abar[l] || !WsT_pack[l] || d->MT[l] < 1 || d->SP[l] < 1) {
+    if (!abar[l] || !WsL_pack[l] || d->MT[l] < 1 || d->SP[l] < 1) {
       stpde_set_error("lig_xbar_scatter: bad layer %d", l);
       return STPDE_E_BADARG;
     }
     a.abar[l] = abar[l];
-    a.wst[l] = WsT_pack[l];
+    a.wsl[l] = WsL_pack[l];
   }
   a.cell = cell;
   a.dlatent = dlatent;
   a.xrows = xrows;
   a.CP = (d->C + 3) / 4 * 4;
-  STPDE_LAUNCH(k_xbar, dim3((d->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((d->ntiles + 4 * XR - 1) / (4 * XR));
+  if (d->C <= 16)
+    STPDE_LAUNCH(k_xbar<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (d->C <= 32)
+    STPDE_LAUNCH(k_xbar<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    STPDE_LAUNCH(k_xbar<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_xbar");
 }
 

@@ -71,6 +71,7 @@ class ImNetPlan:
         if out_features > 16:
             raise ValueError("out_features > 16 not supported by the HIP jet path")
         self.dim, self.cin, self.cout, self.nf = dim, in_features, out_features, nf
+        self.xl = (in_features + 15) // 16      # 16-channel tiles of the latent adjoint (k_xbar<XL>)
         widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf, out_features]
         self.layers = []
         theta_off = 0
@@ -133,8 +134,13 @@ class ImNetPlan:
             xt = np.arange(XT)
             add("Ws", aug[(16 * mt[None, :, None, None] + j[None, None, :, None]),
                           (16 * (KT + xt)[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :])])
-            add("WsT", aug[(16 * mt[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
-                           (16 * (KT + xt)[None, :, None, None] + j[None, None, :, None])])
+            # A operand of W_s^T restricted to the latent channels (the only columns of the augmented input that receive
+            # an adjoint): [MT][XL][lane][r] = aug[16mt + 4g + r, 16KT + dim + 16xl + j], zero beyond channel cin - 1
+            xl = np.arange(self.xl)
+            ch = 16 * xl[None, :, None, None] + j[None, None, :, None] + 0 * r[None, None, None, :]
+            wsl = aug[(16 * mt[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
+                      (16 * KT + self.dim + np.minimum(ch, self.cin - 1))]
+            add("WsL", np.where(ch < self.cin, wsl, zero))
             d = np.arange(3)
             add("tanc", aug[(16 * mt[None, :, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
                             (16 * KT + d)[:, None, None, None] + 0 * mt[None, :, None, None]])
@@ -348,6 +354,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     bufs = [None]
     pv = plan.pack_view
     prev = None
+    z0 = None
     # forward-only value queries (inference): VALUE-TILE kernels -- four consecutive row tiles share one pass over the
     # weights (the weight operand is what bounds a one-stream pass); same buffers, a quarter of the "tiles"
     vt = S == 1 and not need_grad and (not meta.packs16 or meta.nsplit == 3) and nt % 4 == 0 and value_tiles
@@ -374,16 +381,21 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
         w16 = meta.packs16.get((l, "Wh")) if meta.packs16 else None
         d = _layer_desc(lnt, lay, lcfg, l == 1, meta.nsplit if w16 is not None else 0)
+        if l == 1 and need_grad:
+            # value stream of the layer-0 pre-activations, kept for the layer-1 input-gradient kernel (which then writes
+            # the layer-0 adjoint over it): reading 2 KB per row back is cheaper than regenerating it on the fp32 MFMA
+            z0 = torch.empty(nt * plan.layers[0]["MT"] * _FRAG, device=dev)
         with _timed("layer%d_fwd" % l):
             check(L.stpde_jet_layer_fwd(C.byref(d), ptr(prev), ptr(X), ptr(pv(packs, l, "Wh")),
                                         ptr(pv(packs, l, "Ws")), ptr(pv(packs, l, "tanc")), ptr(pv(packs, 0, "Ws")),
-                                        ptr(pv(packs, 0, "tanc")), ptr(out), ptr(cw), ptr(w16), st))
+                                        ptr(pv(packs, 0, "tanc")), ptr(out), ptr(cw), ptr(w16),
+                                        ptr(z0) if l == 1 else None, st))
         bufs.append(out)
         prev = out
     with _timed("reduce_fwd"):
         check(L.stpde_lig_reduce_fwd(C.byref(meta.cfg_out), S, Pc, plan.cout, ptr(bufs[5]), ptr(coef),
                                      C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
-    return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw)
+    return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw, z0=z0)
 
 
 def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
@@ -407,7 +419,9 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     # layer-0 "input" is the constant column W0[:, d], so only sum_rows matters): 32 + 6 KB per tile instead of 128 KB
     MT0 = plan.layers[0]["MT"]
     split0 = SP0 == 4 and tan0_rowsum
-    abar0 = torch.empty(nt * (1 if split0 else SP0) * MT0 * _FRAG, device=dev)
+    z0 = saved["z0"]
+    # the value-stream-only layer-0 adjoint goes over the z0 stash (same shape; each lane reads before it writes)
+    abar0 = z0 if (split0 or SP0 == 1) else torch.empty(nt * SP0 * MT0 * _FRAG, device=dev)
     tan0 = torch.empty(nt * MT0 * 48, device=dev) if split0 else None
     # fc5 -> fc4 -> fc3 input gradients in one kernel (adjoints of layers 4 and 3 feed the next GEMM from the registers).
     # Order: wgrad_5 (needs the pre-activations of fc4's output intact), the chain (abar4 in place; abar3 / abar2 into
@@ -444,7 +458,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(abar[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
                                         ptr(pv(packs, 0, "tanc")), ptr(abar0), ptr(cw), ptr(pbar), ptr(w16),
-                                        ptr(tan0) if l == 1 else None, st))
+                                        ptr(tan0) if l == 1 else None, ptr(z0) if l == 1 else None, st))
     if meta.need_wgrad:
         lay = plan.layers[0]
         d = _layer_desc(nt, lay, cfg, False)
@@ -468,7 +482,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
             xd.MT[l] = plan.layers[l]["MT"]
             xd.SP[l] = (1 if split0 else SP0) if l == 0 else S
             ab[l] = (abar0 if l == 0 else abar[l]).data_ptr()
-            wt[l] = pv(packs, l, "WsT").data_ptr()
+            wt[l] = pv(packs, l, "WsL").data_ptr()
         if not deterministic_dlatent:
             with _timed("xbar_scatter"):
                 check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
@@ -539,7 +553,7 @@ class LigJetFunction(torch.autograd.Function):
         pbar = torch.zeros(_lib.PBAR_SLOTS, device=dev) if ctx.needs_input_grad[3] else None
         for s in ctx.saved:
             _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar)
-            s["bufs"] = None  # release the stash chunk by chunk
+            s["bufs"] = s["z0"] = None  # release the stash chunk by chunk
         ctx.saved = []
         grads = [None] * ctx.n_params
         if meta.need_wgrad:

@@ -37,7 +37,7 @@ def test_abi_rejects_bad_arguments_without_gpu(hiplib):
     d = _lib.LayerDesc()
     d.ntiles, d.KT, d.MT = 0, 1, 1
     with pytest.raises(ValueError):
-        _lib.check(hiplib.stpde_jet_layer_fwd(ctypes.byref(d), *([None] * 11)))
+        _lib.check(hiplib.stpde_jet_layer_fwd(ctypes.byref(d), *([None] * 12)))
     g = _lib.GatherDesc()
     g.P = 3   # odd
     with pytest.raises(ValueError):

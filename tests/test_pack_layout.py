@@ -75,9 +75,9 @@ def test_layer0_pack_and_transposed_packs():
         W = params[2 * l].double().numpy()
         MT = lay["MT"]
         ab = rng.standard_normal((16, lay["M"]))
-        wt = plan.pack_view(packs, l, "WsT").reshape(MT, XT, 64, 4)
-        got = E.from_frag(E.gemm_frag(wt, E.to_frag(ab), MT, XT))[:, :35]
-        np.testing.assert_allclose(got, ab @ W[:, lay["Kh"]:], rtol=1e-10, atol=1e-10)
+        wt = plan.pack_view(packs, l, "WsL").reshape(MT, plan.xl, 64, 4)      # latent channels only
+        got = E.from_frag(E.gemm_frag(wt, E.to_frag(ab), MT, plan.xl))[:, :32]
+        np.testing.assert_allclose(got, ab @ W[:, lay["Kh"] + 3:lay["Kh"] + 35], rtol=1e-10, atol=1e-10)
 
 
 def test_wgrad_transpose_and_unpack():

@@ -58,8 +58,8 @@ def run():
         if not os.path.exists(so):
             continue
         L = C.CDLL(so)
-        L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 11
-        L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
+        L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
+        L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 13
         d = _lib.LayerDesc()
         d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, 0
         st = _lib.stream_ptr()
@@ -68,11 +68,11 @@ def run():
         def fwd():
             return L.stpde_jet_layer_fwd(C.byref(d), None, p(X), p(pv(packs, 1, "Wh")), p(pv(packs, 1, "Ws")),
                                          p(pv(packs, 1, "tanc")), p(pv(packs, 0, "Ws")), p(pv(packs, 0, "tanc")), p(out1),
-                                         p(cw), None, st)
+                                         p(cw), None, p(abar0), st)
 
         def bwd():
             return L.stpde_jet_layer_bwd(C.byref(d), p(out1), p(pv(packs, 1, "WhT")), None, p(X), p(pv(packs, 0, "Ws")),
-                                         p(pv(packs, 0, "tanc")), p(abar0), p(cw), None, None, p(tan0), st)
+                                         p(pv(packs, 0, "tanc")), p(abar0), p(cw), None, None, p(tan0), p(abar0), st)
 
         for name, fn in (("fwd", fwd), ("dgrad", bwd)):
             assert fn() == 0
