@@ -162,13 +162,14 @@ int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const 
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
  * and in_pre [tile][S][KT] are the ordinary (column-major) layer buffers -- call it BEFORE stpde_jet_layer_bwd of the
- * same layer overwrites in_pre.  first_hidden: in_pre is ignored, the activated layer-0 output is regenerated from X
- * with W0s_pack and tanc0R (layer-0 tangent constants in the row-major image).  XR = row-major augmented input from
+ * same layer overwrites in_pre.  first_hidden: in_pre is the z0 stash [tile][KT][256] written by
+ * stpde_jet_layer_fwd(first_hidden) (value stream of layer 0's pre-activations; the tangent streams are the constant
+ * columns tanc0 [3][KT][256] = W0[:, d] in the column-major image, the second-order streams are zero) -- call it before
+ * stpde_jet_layer_bwd(first_hidden) writes the layer-0 adjoint over the stash.  XR = row-major augmented input from
  * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug.  d->mfma_bf16: layers with MT >= 8 contract with
  * bf16-rounded operands (two derivative streams per v_mfma_f32_16x16x32_bf16), fp32 accumulation. */
-int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* X,
-                    const float* XR, const float* W0s_pack, const float* tanc0R, float* dW_aug, const float* cw,
-                    void* stream);
+int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* XR,
+                    const float* tanc0, float* dW_aug, const float* cw, void* stream);
 
 /* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
  * jets[(s*n_out + ch)*ldp + p] (ldp >= P lets a chunk of points write into a larger [S][n_out][Ptotal] array)

@@ -159,7 +159,7 @@ _SIGNATURES = {
     "stpde_jet_tail_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _VP,
                             _VP, _VP], C.c_int),
     "stpde_jet_tan0_reduce": ([C.c_int, C.c_int, _VP, _VP, C.c_int, _VP], C.c_int),
-    "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 9, C.c_int),
+    "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 7, C.c_int),
     "stpde_lig_reduce_fwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_long, _VP], C.c_int),
     "stpde_lig_reduce_bwd": ([C.POINTER(JetCfg), C.c_int, C.c_int, C.c_int, _VP, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),

@@ -13,8 +13,7 @@ static int dispatch_streams(const WgradArgs& a, int mode, hipStream_t stream) {
 }
 
 extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre,
-                               const float* X, const float* XR, const float* W0s_pack, const float* tanc0R,
-                               float* dW_aug, const float* cw, void* stream) {
+                               const float* XR, const float* tanc0, float* dW_aug, const float* cw, void* stream) {
   if (!d || d->ntiles <= 0 || d->MT <= 0 || d->KT < 0 || !abar_out || !XR || !dW_aug || SP < 1 ||
       SP > 1 + d->cfg.S1 + d->cfg.S2) {
     stpde_set_error("jet_wgrad: bad argument");
@@ -23,10 +22,8 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   WgradArgs a{};
   a.P = abar_out;
   a.Q = in_pre;
-  a.X = X;
   a.XR = XR;
-  a.W0s = W0s_pack;
-  a.tancR = tanc0R;
+  a.tanc0 = tanc0;
   a.dW = dW_aug;
   a.cw = cw;
   a.SP = SP;
@@ -35,16 +32,16 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   a.ntiles = d->ntiles;
   a.cfg = d->cfg;
   a.bf16 = d->mfma_bf16;
-  if (d->first_hidden) {
-    if (!X || !W0s_pack || (d->cfg.S1 && !tanc0R)) {
-      stpde_set_error("jet_wgrad: first_hidden needs X/W0s_pack/tanc0R");
-      return STPDE_E_BADARG;
-    }
-    return dispatch_streams(a, 1, (hipStream_t)stream);
-  }
   if (d->KT > 0 && !in_pre) {
     stpde_set_error("jet_wgrad: null in_pre");
     return STPDE_E_BADARG;
+  }
+  if (d->first_hidden) {
+    if (d->cfg.S1 && !tanc0) {
+      stpde_set_error("jet_wgrad: first_hidden needs tanc0");
+      return STPDE_E_BADARG;
+    }
+    return dispatch_streams(a, 1, (hipStream_t)stream);
   }
   return dispatch_streams(a, 0, (hipStream_t)stream);
 }

@@ -21,11 +21,10 @@
 
 struct WgradArgs {
   const float* P;      // abar_out, column-major image [tile][SP][MT][256]
-  const float* Q;      // pre-activations of the layer input, column-major image [tile][S][KT][256]   (MODE 0)
-  const float* X;      // column-major augmented input [tile][XT][256]   (MODE 1: operand of the layer-0 regeneration)
+  const float* Q;      // pre-activations of the layer input, column-major image [tile][S][KT][256]   (MODE 0);
+                       // MODE 1 (first hidden layer): the z0 stash [tile][KT][256] = value stream of layer 0's pre-activations
   const float* XR;     // row-major augmented input [tile][XT][256]
-  const float* W0s;    // [XT][KT][256]  (MODE 1)
-  const float* tancR;  // [3][KT][256] layer-0 tangent constants, row-major image (MODE 1)
+  const float* tanc0;  // [3][KT][256] layer-0 tangent constants W0[:, d], column-major image (MODE 1)
   float* dW;           // [16*MT][16*(KT+XT)]
   const float* cw;     // [P][8] weights of the combined second-order stream (S2 == 1)
   int SP, KT, MT, ntiles;
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // with one ds_read_b64 -- the same layout serves the column-major producers (transposing ds_write_b16) and the
   // row-major ones (ds_write_b64).
   constexpr bool SPLP = BF && SPL == 3;
-  constexpr int BLK = SPLP ? 384 : (MODE == 1 ? 256 : TBLK);
+  constexpr int BLK = SPLP ? 384 : TBLK;
   constexpr int NBUF = (2 * RS * S * BLK * 4 + NW * 2 * TBLK * 4 <= 150 * 1024) ? 2 : 1;
   constexpr int SX = S1 == 3 ? 4 : 1;       // raw-input tiles only feed the value and tangent streams
   __shared__ __attribute__((aligned(16))) float hl[NBUF][RS][S][BLK];
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const bf16x4 h = to_bf4(v);
-        if (MODE == 1 || row_major) {       // lane (g, c) holds rows 4g..4g+3 of feature c
+        if (row_major) {                     // lane (g, c) holds rows 4g..4g+3 of feature c
           *reinterpret_cast<bf16x4*>(hb16 + (t * 16 + (lane & 15)) * 16 + 4 * (lane >> 4)) = h;
         } else {                             // lane (g, j) holds features 4g..4g+3 of row j
 #pragma unroll
@@ -115,15 +114,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         }
         if (t < 2) v -= bf4_to_f32(h);
       }
-    } else if (MODE == 1) {
-      st4(blk + lo, v);                      // ring holds plain row-major images
     } else if (row_major) {
       lds_put_R(blk, lane, v);
     } else {
       lds_put_T(blk, lane, v);
     }
   };
-  auto get = [&](const float* blk) -> f32x4 { return MODE == 1 ? ld4(blk + lo) : lds_get_R(blk, lane); };
+  auto get = [&](const float* blk) -> f32x4 { return lds_get_R(blk, lane); };
   auto get16 = [&](const float* blk, int t) -> bf16x4 {     // SPLP: term t of this lane's row-major fragment
     return *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(blk) + (t * 16 + (lane & 15)) * 16 +
                                             4 * (lane >> 4));
@@ -136,23 +133,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     if (!HASX || kq < KT) {
       f32x4 pre[S];
       float cq[6];
-      // rows of this lane: column-major image (MODE 0) row = lane & 15; row-major image (MODE 1) rows 4g..4g+3
-      load_cq<S2>(a.cw, tile * 2 + (MODE == 1 ? (g >> 1) : (c >> 3)), cq);
+      // rows of this lane (column-major image): row = lane & 15
+      load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
       if (MODE == 1) {
-        f32x4 part[XT];
-#pragma unroll
-        for (int xt = 0; xt < XT; ++xt) {
-          f32x4 xd = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
-          f32x4 w = ld4(a.W0s + ((size_t)xt * KT + kq) * 256 + lo);
-          f32x4 cc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cc = mfma4(xd[r], w[r], cc);   // rows x features: row-major image
-          part[xt] = cc;
-        }
-        pre[0] = (part[0] + part[1]) + part[2];
+        // first hidden layer: value stream from the z0 stash (written by the forward; round 2 regenerated it here with
+        // 12 MFMAs per k-tile), tangent streams = the constant columns W0[:, d], second-order streams = 0
+        pre[0] = ld4(a.Q + ((size_t)tile * KT + kq) * 256 + lo);
         if (S1 == 3) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tancR + ((size_t)d * KT + kq) * 256 + lo);
+          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * KT + kq) * 256 + lo);
 #pragma unroll
           for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }

@@ -144,9 +144,6 @@ class ImNetPlan:
             d = np.arange(3)
             add("tanc", aug[(16 * mt[None, :, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
                             (16 * KT + d)[:, None, None, None] + 0 * mt[None, :, None, None]])
-            # the same constants in the row-major (R) fragment image: [d][mt][lane][r] = aug[16mt + (lane&15), 16KT + d]
-            add("tancR", aug[(16 * mt[None, :, None, None] + j[None, None, :, None] + 0 * r[None, None, None, :]),
-                             (16 * KT + d)[:, None, None, None] + 0 * mt[None, :, None, None]])
             self.pack_off.append(offs)
             self.dw_off.append((dwo, Mp, Ka))
             dwo += Mp * Ka
@@ -441,9 +438,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
-                check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(abar[l]), ptr(bufs[l - 1]) if l > 1 else None, ptr(X),
-                                        ptr(XR), ptr(pv(packs, 0, "Ws")), ptr(pv(packs, 0, "tancR")),
-                                        ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
+                check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(abar[l]), ptr(bufs[l - 1]) if l > 1 else ptr(saved["z0"]),
+                                        ptr(XR), ptr(pv(packs, 0, "tanc")), ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
         if tail and l >= 3:
             if l == 5:
                 abar[3], abar[2] = torch.empty_like(bufs[3]), torch.empty_like(bufs[2])
@@ -466,11 +462,11 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
         with _timed("layer0_wgrad"):
             if split0:
                 d.cfg = meta.cfg_val      # value stream x raw input (the S = 1 weight-gradient kernels)
-                check(L.stpde_jet_wgrad(C.byref(d), 1, ptr(abar0), None, ptr(X), ptr(XR), None, None,
+                check(L.stpde_jet_wgrad(C.byref(d), 1, ptr(abar0), None, ptr(XR), None,
                                         ptr(dw_flat[off:off + mp * ka]), None, st))
                 check(L.stpde_jet_tan0_reduce(nt, MT0, ptr(tan0), ptr(dw_flat[off:off + mp * ka]), ka, st))
             else:
-                check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(X), ptr(XR), None, None,
+                check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(XR), None,
                                         ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
     if dlatent is not None:
         xd = XbarDesc()

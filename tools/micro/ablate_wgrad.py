@@ -46,6 +46,7 @@ def run():
     packs = 0.05 * torch.randn(plan.n_pack, device=dev)
     X = torch.randn(nt * 3 * 256, device=dev)
     XR = torch.randn(nt * 3 * 256, device=dev)
+    z0 = torch.randn(nt * plan.layers[0]["MT"] * 256, device=dev)
     cw = torch.rand(nt * 2 * 8, device=dev)
     lay = plan.layers[1]
     abar1 = torch.randn(nt * S * lay["MT"] * 256, device=dev)
@@ -60,15 +61,14 @@ def run():
             if not os.path.exists(so) or (mode != 3 and n not in (0, 2, 3, 5)):
                 continue
             L = C.CDLL(so)
-            L.stpde_jet_wgrad.argtypes = [C.POINTER(_lib.LayerDesc), C.c_int] + [C.c_void_p] * 9
+            L.stpde_jet_wgrad.argtypes = [C.POINTER(_lib.LayerDesc), C.c_int] + [C.c_void_p] * 7
             d = _lib.LayerDesc()
             d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, mode
             st = _lib.stream_ptr()
             p = _lib.ptr
 
             def fn():
-                return L.stpde_jet_wgrad(C.byref(d), S, p(abar1), None, p(X), p(XR), p(pv(packs, 0, "Ws")),
-                                         p(pv(packs, 0, "tancR")), p(dw), p(cw), st)
+                return L.stpde_jet_wgrad(C.byref(d), S, p(abar1), p(z0), p(XR), p(pv(packs, 0, "tanc")), p(dw), p(cw), st)
 
             assert fn() == 0
             torch.cuda.synchronize()
