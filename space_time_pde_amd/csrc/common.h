@@ -7,6 +7,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define XT STPDE_XT
+// Augmented raw input of a corner row (coordinates, latent channels, the ones column of the bias): XT = 3 fragment tiles of
+// 16 slots.  Tiles 0 and 1 hold features 0..31 in order; tile 2 is SPARSE -- only register 0 of its fragment is populated
+// (slots 32, 36, 40, 44 = features 32..35) -- so a GEMM over the augmented input takes 9 k-steps instead of 12 (3 + 32 + 1
+// = 36 features is exactly what the reference's 32 latent channels need; wider latents take the generic path).
+__host__ __device__ constexpr int x_live(int xt) { return xt == XT - 1 ? 1 : 4; }
 
 // One v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[l&15][l>>4], B[l>>4][l&15],
 // D rows 4*(l>>4)+r (r = register), column l&15.  Exact fp32 (k-ordered fma chain).

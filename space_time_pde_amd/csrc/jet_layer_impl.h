@@ -55,7 +55,7 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
     f32x4 w = ld4(W0s + ((size_t)xt * nblk + blk) * 256 + lo);
     f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c = mfma4(w[r], xb[xt][r], c);
+    for (int r = 0; r < x_live(xt); ++r) c = mfma4(w[r], xb[xt][r], c);
     part[xt] = c;
   }
   return (part[0] + part[1]) + part[2];
@@ -79,7 +79,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
 #pragma unroll
         for (int sv = 0; sv < (VT ? S : 1); ++sv)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mi][sv] = mfma4(w[r], xbv[sv][xt][r], acc[mi][sv]);
+          for (int r = 0; r < x_live(xt); ++r) acc[mi][sv] = mfma4(w[r], xbv[sv][xt][r], acc[mi][sv]);
       }
       if (S1 == 3) {
 #pragma unroll

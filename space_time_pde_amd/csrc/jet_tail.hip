@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
     for (int xt = 0; xt < XT; ++xt) {
       const f32x4 w = ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
+      for (int r = 0; r < x_live(xt); ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
     }
     if (S1 == 3) {
 #pragma unroll

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   f32x4 v;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int f = 16 * xt + 4 * g + r;
+    // feature held by slot (xt, g, r): tiles 0 / 1 in order, tile 2 sparse (register 0 only: features 32 + g)
+    const int f = xt < XT - 1 ? 16 * xt + 4 * g + r : (r == 0 ? 16 * xt + g : 16 * XT);
     float val = 0.f;
     if (f < 3) {
       const float r0 = bit[0] ? gm.rel[1][0] : gm.rel[0][0];
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
 extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X,
                                 float* XR, float* coef, int* cell, float* cw, void* stream) {
   if (!d || d->P <= 0 || (d->P & 1) || d->N <= 0 || d->p_base < 0 || d->B <= 0 || d->n0 < 2 || d->n1 < 2 || d->n2 < 2 || d->C < 1 ||
-      3 + d->C + 1 > 16 * XT || !pts || !latent || !X || !coef || !cell) {
-    stpde_set_error("lig_gather: bad argument (P even, grid >= 2 per dim, C <= %d)", 16 * XT - 4);
+      3 + d->C + 1 > 16 * (XT - 1) + 4 || !pts || !latent || !X || !coef || !cell) {
+    stpde_set_error("lig_gather: bad argument (P even, grid >= 2 per dim, C <= %d)", 16 * (XT - 1));
     return STPDE_E_BADARG;
   }
   if ((size_t)d->B * d->n0 * d->n1 * d->n2 >= (1u << 31)) {
@@ -495,7 +496,7 @@ extern "C" int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const*
 
 static int launch_xbar(const stpde_xbar_desc* d, const float* const* abar, const float* const* WsL_pack,
                        const int* cell, float* dlatent, float* xrows, void* stream) {
-  if (!d || d->ntiles <= 0 || d->nlayers < 1 || d->nlayers > 8 || d->C < 1 || 3 + d->C + 1 > 16 * XT || !abar ||
+  if (!d || d->ntiles <= 0 || d->nlayers < 1 || d->nlayers > 8 || d->C < 1 || 3 + d->C + 1 > 16 * (XT - 1) + 4 || !abar ||
       !WsL_pack) {
     stpde_set_error("lig_xbar: bad argument");
     return STPDE_E_BADARG;

@@ -66,12 +66,17 @@ class ImNetPlan:
         if nf % 16 != 0:
             raise ValueError("the HIP jet path needs nf to be a multiple of 16 (hidden widths are MFMA tiles)")
         self.dz = dim + in_features
-        if self.dz + 1 > 16 * XT:
-            raise ValueError("in_features too large for the 3-tile augmented input (max 44)")
+        if self.dz + 1 > 16 * (XT - 1) + 4:
+            raise ValueError("in_features too large for the augmented input of the HIP jet path (max 32 latent channels)")
         if out_features > 16:
             raise ValueError("out_features > 16 not supported by the HIP jet path")
         self.dim, self.cin, self.cout, self.nf = dim, in_features, out_features, nf
         self.xl = (in_features + 15) // 16      # 16-channel tiles of the latent adjoint (k_xbar<XL>)
+        # slot of augmented-input feature f (r, latent channels, ones column) in the XT fragment tiles: tiles 0 / 1 in
+        # order, tile 2 sparse -- features 32.. sit in register 0 of its fragment (slots 32, 36, 40, 44), so the GEMMs
+        # over the augmented input take 9 k-steps instead of 12 (x_live() in csrc/common.h, k_gather)
+        f = np.arange(self.dz + 1)
+        self.slot = np.where(f < 16 * (XT - 1), f, 16 * (XT - 1) + 4 * (f - 16 * (XT - 1)))
         widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf, out_features]
         self.layers = []
         theta_off = 0
@@ -104,16 +109,17 @@ class ImNetPlan:
             rows = np.arange(M)[:, None]
             if Kh:
                 aug[:M, :Kh] = lay["w_off"] + rows * Kin + np.arange(Kh)[None, :]
+            slot = self.slot
             if lay["skip"]:
-                aug[:M, 16 * KT:16 * KT + self.dz] = lay["w_off"] + rows * Kin + Kh + np.arange(self.dz)[None, :]
-            aug[:M, 16 * KT + self.dz] = lay["b_off"] + np.arange(M)
+                aug[:M, 16 * KT + slot[:self.dz]] = lay["w_off"] + rows * Kin + Kh + np.arange(self.dz)[None, :]
+            aug[:M, 16 * KT + slot[self.dz]] = lay["b_off"] + np.arange(M)
             # unpack map: theta element -> position in the flat dW_aug buffer
             if Kh:
                 unpack[lay["w_off"] + rows * Kin + np.arange(Kh)[None, :]] = dwo + rows * Ka + np.arange(Kh)[None, :]
             if lay["skip"]:
                 unpack[lay["w_off"] + rows * Kin + Kh + np.arange(self.dz)[None, :]] = \
-                    dwo + rows * Ka + 16 * KT + np.arange(self.dz)[None, :]
-            unpack[lay["b_off"] + np.arange(M)] = dwo + np.arange(M) * Ka + 16 * KT + self.dz
+                    dwo + rows * Ka + 16 * KT + slot[:self.dz][None, :]
+            unpack[lay["b_off"] + np.arange(M)] = dwo + np.arange(M) * Ka + 16 * KT + slot[self.dz]
             offs = {}
 
             def add(name, arr):
@@ -139,7 +145,7 @@ class ImNetPlan:
             xl = np.arange(self.xl)
             ch = 16 * xl[None, :, None, None] + j[None, None, :, None] + 0 * r[None, None, None, :]
             wsl = aug[(16 * mt[:, None, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),
-                      (16 * KT + self.dim + np.minimum(ch, self.cin - 1))]
+                      (16 * KT + slot[self.dim + np.minimum(ch, self.cin - 1)])]
             add("WsL", np.where(ch < self.cin, wsl, zero))
             d = np.arange(3)
             add("tanc", aug[(16 * mt[None, :, None, None] + 4 * g[None, None, :, None] + r[None, None, None, :]),

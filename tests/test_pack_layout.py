@@ -18,9 +18,11 @@ def _plan_and_params(nf=16, cout=4, seed=0):
 
 
 def _x_aug(rows, cin, rng):
+    """Augmented input rows in SLOT order (what k_gather writes): tiles 0 / 1 in feature order, tile 2 sparse."""
+    slot = ImNetPlan.get(3, cin, 4, 16).slot
     x = np.zeros((16, 16 * XT))
-    x[:, :3 + cin] = rows
-    x[:, 3 + cin] = 1.0
+    x[:, slot[:3 + cin]] = rows
+    x[:, slot[3 + cin]] = 1.0
     return x
 
 
@@ -36,6 +38,7 @@ def test_forward_packs_reproduce_linear_layers():
         xr = rng.standard_normal((16, 35))
         wh = plan.pack_view(packs, l, "Wh").reshape(KT, MT, 64, 4)
         ws = plan.pack_view(packs, l, "Ws").reshape(XT, MT, 64, 4)
+        assert np.all(ws[XT - 1, :, :, 1:] == 0) and np.any(ws[XT - 1, :, :, 0] != 0)   # sparse third tile: register 0 only
         out = E.gemm_frag(wh, E.to_frag(h), KT, MT) + E.gemm_frag(ws, E.to_frag(_x_aug(xr, 32, rng)), XT, MT)
         got = E.from_frag(out)[:, :lay["M"]]
         inp = np.concatenate([h, xr], 1) if lay["skip"] else h
@@ -122,4 +125,6 @@ def test_plan_rejects_unsupported_architectures():
     with pytest.raises(ValueError):
         ImNetPlan(4, 32, 4, 16)       # dim != 3
     with pytest.raises(ValueError):
-        ImNetPlan(3, 64, 4, 16)       # latent too wide for the 3-tile augmented input
+        ImNetPlan(3, 64, 4, 16)       # latent too wide for the augmented input
+    with pytest.raises(ValueError):
+        ImNetPlan(3, 33, 4, 16)       # the sparse third tile holds features 32..35 only
