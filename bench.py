@@ -148,12 +148,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                          % (args.gpus, args.gpus))
+    # test hooks for the 1-GPU box (never set by the driver): all ranks on device 0 / another backend than RCCL, so that
+    # `--gpus 2` can be dry-run through gloo where RCCL would refuse two ranks on one device
+    if os.environ.get("STPDE_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("STPDE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     force_dist = os.environ.get("STPDE_BENCH_FORCE_DIST") == "1"   # exercise the RCCL code path with a single rank
     if world > 1 or (force_dist and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
 

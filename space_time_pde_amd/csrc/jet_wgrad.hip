@@ -51,12 +51,21 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
 // epilogue): [tile][MT][3][16] -> one column per d.  Grid-stride partial sums, one atomic per (block, element).
 __global__ __launch_bounds__(256) void k_tan0_reduce(const float* tan, float* dW, int ntiles, int MT, int ldw) {
   const int n = MT * 48;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    float s = 0.f;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) s += tan[(size_t)t * n + e];
-    const int mt = e / 48, d = (e % 48) / 16, f = e % 16;
-    atomicAdd(dW + (size_t)(16 * mt + f) * ldw + d, s);
+  const int e = blockIdx.y * 256 + threadIdx.x;     // grid.y covers the n elements of a tile, grid.x strides the tiles
+  if (e >= n) return;
+  // four independent partial sums: four loads in flight per thread (a single running sum serialises on the HBM latency)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int G = gridDim.x;
+  int t = blockIdx.x;
+  for (; t + 3 * G < ntiles; t += 4 * G) {
+    s0 += tan[(size_t)t * n + e];
+    s1 += tan[(size_t)(t + G) * n + e];
+    s2 += tan[(size_t)(t + 2 * G) * n + e];
+    s3 += tan[(size_t)(t + 3 * G) * n + e];
   }
+  for (; t < ntiles; t += G) s0 += tan[(size_t)t * n + e];
+  const int mt = e / 48, d = (e % 48) / 16, f = e % 16;
+  atomicAdd(dW + (size_t)(16 * mt + f) * ldw + d, (s0 + s1) + (s2 + s3));
 }
 
 extern "C" int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, void* stream) {
@@ -64,7 +73,9 @@ extern "C" int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan,
     stpde_set_error("jet_tan0_reduce: bad argument");
     return STPDE_E_BADARG;
   }
-  int grid = ntiles < 1024 ? ntiles : 1024;
-  STPDE_LAUNCH(k_tan0_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, abar0_tan, dW_aug, ntiles, MT, ldw);
+  const int gy = (MT * 48 + 255) / 256;
+  int gx = 4096 / gy;                        // ~16 blocks per CU
+  if (gx > ntiles) gx = ntiles;
+  STPDE_LAUNCH(k_tan0_reduce, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, abar0_tan, dW_aug, ntiles, MT, ldw);
   return stpde_check_launch("k_tan0_reduce");
 }

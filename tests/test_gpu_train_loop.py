@@ -38,15 +38,19 @@ def test_short_training_run_reduces_the_loss(hiplib):
     assert sum(losses[-5:]) / 5 < 0.8 * sum(losses[:5]) / 5, losses
 
 
-def _rccl_worker(rank, world, port, out):
+def _rccl_worker(rank, world, port, out, backend="nccl", one_device=False):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    idx = 0 if one_device else rank
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from space_time_pde_amd.train_step import sharded_step
     unet, net, layer, crop, pts, tgt = _rccl_build(dev)
     n = pts.shape[1] // world
@@ -92,7 +96,11 @@ def test_two_rank_rccl_step_equals_single_gpu(hiplib, tmp_path):
     s.close()
     out = str(tmp_path / "rank0.pt")
     mp.spawn(_rccl_worker, args=(2, port, out), nprocs=2, join=True)
-    got = torch.load(out)
+    _compare_with_single_device(torch.load(out))
+
+
+def _compare_with_single_device(got):
+    from space_time_pde_amd.train_step import sharded_step
     dev = torch.device("cuda:0")
     unet, net, layer, crop, pts, tgt = _rccl_build(dev)
     loss, reg, pde = sharded_step(unet, net, layer, crop, pts, tgt, pts.shape[1], 1.0, 0.0125, distributed=False)
@@ -102,3 +110,19 @@ def test_two_rank_rccl_step_equals_single_gpu(hiplib, tmp_path):
         assert (a - p.grad.cpu()).abs().max().item() < 2e-4 * p.grad.abs().max().item() + 1e-9
     for a, p in zip(got["g_un"], unet.parameters()):
         assert (a - p.grad.cpu()).abs().max().item() < 2e-3 * p.grad.abs().max().item() + 1e-8
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_gloo_step_equals_single_rank(hiplib, tmp_path):
+    """The same point-sharded step with world_size 2 on the 1-GPU test box: both ranks run the HIP path on cuda:0 and
+    exchange the partial d loss / d latent and the IM-NET / U-Net gradients over gloo (RCCL refuses two ranks on one
+    device) -- every line of the N > 1 path except the transport itself runs on device tensors here."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "rank0_gloo.pt")
+    mp.spawn(_rccl_worker, args=(2, port, out, "gloo", True), nprocs=2, join=True)
+    _compare_with_single_device(torch.load(out))
