@@ -36,6 +36,14 @@ __device__ __forceinline__ f32x4 bf4_to_f32(bf16x4 v) {
   for (int i = 0; i < 4; ++i) r[i] = (float)v[i];
   return r;
 }
+// ds_read_b64_tr_b16 (gfx950): hardware 4 x 16 -> 16 x 4 transpose of 16-bit elements inside a 16-lane group.  Lane i of a
+// group passes the address of 4 contiguous elements -- row i / 4, columns 4 (i % 4) .. +3 of a [4][16] block with a free row
+// stride -- and receives column i of the block (rows 0..3).  Measured: tools/micro/tr16_probe.hip.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 lds_read_tr16(const __bf16* p) {
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                         (__attribute__((address_space(3))) s16x4*)(const_cast<__bf16*>(p))));
+}
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }

@@ -77,11 +77,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // with one ds_read_b64 -- the same layout serves the column-major producers (transposing ds_write_b16) and the
   // row-major ones (ds_write_b64).
   constexpr bool SPLP = BF && SPL == 3;
-  constexpr int BLK = SPLP ? 384 : TBLK;
-  constexpr int NBUF = (2 * RS * S * BLK * 4 + NW * 2 * TBLK * 4 <= 150 * 1024) ? 2 : 1;
+  // bf16-pipe modes: every LDS block (ring slots and the private abar patches) holds the SPL bf16 terms of a fragment as
+  // [term][16][16] bf16 (512 B per term), written with ONE ds_write_b64 per lane and term at (lane & 15) * 16 + 4 * (lane >> 4)
+  // -- which is [row][feature] for a column-major source and [feature][row] for a row-major one -- and read back as the
+  // row-major operand fragment with the hardware transpose read ds_read_b64_tr_b16 (column-major sources) or a plain
+  // ds_read_b64 (row-major sources).  (First half of round 2: fp32 blocks transposed with four ds_write_b32 per lane and
+  // converted / split by every consumer; in plain bf16 mode those transposes were 44 % of the kernel.)
+  constexpr int BLK = BF ? 128 * SPL : TBLK;
+  constexpr int NBUF = (2 * RS * S * BLK * 4 + NW * 2 * BLK * 4 <= 150 * 1024) ? 2 : 1;
   constexpr int SX = S1 == 3 ? 4 : 1;       // raw-input tiles only feed the value and tangent streams
   __shared__ __attribute__((aligned(16))) float hl[NBUF][RS][S][BLK];
-  __shared__ __attribute__((aligned(16))) float pp[NW][2][TBLK];
+  __shared__ __attribute__((aligned(16))) float pp[NW][2][BLK];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int lo = lane * 4;
@@ -101,18 +107,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     for (int ki = 0; ki < KC; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto put = [&](float* blk, f32x4 v, bool row_major) {
-    if constexpr (SPLP) {
+    if constexpr (BF) {
       __bf16* hb16 = reinterpret_cast<__bf16*>(blk);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < SPL; ++t) {
         const bf16x4 h = to_bf4(v);
-        if (row_major) {                     // lane (g, c) holds rows 4g..4g+3 of feature c
-          *reinterpret_cast<bf16x4*>(hb16 + (t * 16 + (lane & 15)) * 16 + 4 * (lane >> 4)) = h;
-        } else {                             // lane (g, j) holds features 4g..4g+3 of row j
-#pragma unroll
-          for (int i = 0; i < 4; ++i) hb16[(t * 16 + 4 * (lane >> 4) + i) * 16 + (lane & 15)] = h[i];
-        }
-        if (t < 2) v -= bf4_to_f32(h);
+        *reinterpret_cast<bf16x4*>(hb16 + (t * 16 + (lane & 15)) * 16 + 4 * (lane >> 4)) = h;
+        if (t + 1 < SPL) v -= bf4_to_f32(h);   // exact: the residual of a round-to-nearest bf16 fits in fp32
       }
     } else if (row_major) {
       lds_put_R(blk, lane, v);
@@ -121,9 +122,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     }
   };
   auto get = [&](const float* blk) -> f32x4 { return lds_get_R(blk, lane); };
-  auto get16 = [&](const float* blk, int t) -> bf16x4 {     // SPLP: term t of this lane's row-major fragment
-    return *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(blk) + (t * 16 + (lane & 15)) * 16 +
-                                            4 * (lane >> 4));
+  // bf16-pipe modes: term t of this lane's row-major operand fragment (rows 4g..4g+3 of feature c) out of a block written
+  // by put(); cm = the block came from a column-major source ([row][feature] image -> transpose read)
+  auto get16 = [&](const float* blk, int t, bool cm = true) -> bf16x4 {
+    const __bf16* b16 = reinterpret_cast<const __bf16*>(blk) + t * 256;
+    if (cm) return lds_read_tr16(b16 + (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + 4 * (lane & 3));
+    return *reinterpret_cast<const bf16x4*>(b16 + (lane & 15) * 16 + 4 * (lane >> 4));
   };
 
   // produce ring slot `wv` (k-tile kq0 + wv) of row tile `tile` into buffer `buf`
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       }
   };
   auto transpose_p = [&](f32x4 (*raw)[MCW], f32x4 (*pa)[MCW]) {
+    if constexpr (BF) return;      // bf16-pipe modes: pack_p transposes the bf16 terms (hardware transpose read)
 #pragma unroll
     for (int st = 0; st < S; ++st)
 #pragma unroll
@@ -199,15 +204,27 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       if (k + 1 < SPL) v -= bf4_to_f32(t[k]);
     }
   };
-  auto pack_p = [&](f32x4 (*pa_)[MCW]) {
+  // bf16-pipe modes: the column-major abar blocks `raw_` of the tile -> split into bf16 terms, transposed through this
+  // wave's private patch (one ds_write_b64 + one transpose read per term), packed two streams per MFMA operand
+  auto pack_p = [&](f32x4 (*raw_)[MCW]) {
     if constexpr (BF) {
+      int flip = 0;
+      auto terms = [&](f32x4 v, bf16x4* t) {
+        float* patch = pp[wv][flip];
+        flip ^= 1;
+        put(patch, v, false);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) t[k] = get16(patch, k, true);
+        __builtin_amdgcn_wave_barrier();
+      };
 #pragma unroll
       for (int sp = 0; sp < SH; ++sp)
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) {
           bf16x4 t0[SPL], t1[SPL];
-          split(pa_[2 * sp][mi], t0);
-          if (2 * sp + 1 < S) split(pa_[2 * sp + 1][mi], t1);
+          terms(raw_[2 * sp][mi], t0);
+          if (2 * sp + 1 < S) terms(raw_[2 * sp + 1][mi], t1);
 #pragma unroll
           for (int k = 0; k < SPL; ++k) pa8[k][sp][mi] = cat8(t0[k], 2 * sp + 1 < S ? t1[k] : zero4);
         }
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     produce(tile, 0);
     load_p_raw(tile, raw);
     transpose_p(raw, pa);
-    pack_p(pa);
+    pack_p(raw);
   }
   __syncthreads();
   int buf = 0;
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       const int kq = kq0 + q;
       if (!HASX || kq < KT) {
         f32x4 H[S];
-        if constexpr (!SPLP) {
+        if constexpr (!BF) {
 #pragma unroll
           for (int st = 0; st < S; ++st) H[st] = get(&hl[buf][q][st][0]);
         }
@@ -283,15 +300,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
           for (int sp = 0; sp < SH; ++sp) {
             bf16x4 t0[SPL], t1[SPL];
             bf16x8 H8[SPL];
-            if constexpr (SPLP) {
 #pragma unroll
-              for (int k = 0; k < SPL; ++k) {
-                t0[k] = get16(&hl[buf][q][2 * sp][0], k);
-                if (2 * sp + 1 < S) t1[k] = get16(&hl[buf][q][2 * sp + 1 < S ? 2 * sp + 1 : 0][0], k);
-              }
-            } else {
-            split(H[2 * sp], t0);
-            if (2 * sp + 1 < S) split(H[2 * sp + 1], t1);
+            for (int k = 0; k < SPL; ++k) {
+              t0[k] = get16(&hl[buf][q][2 * sp][0], k, true);
+              if (2 * sp + 1 < S) t1[k] = get16(&hl[buf][q][2 * sp + 1 < S ? 2 * sp + 1 : 0][0], k, true);
             }
 #pragma unroll
             for (int k = 0; k < SPL; ++k) H8[k] = cat8(t0[k], 2 * sp + 1 < S ? t1[k] : zero4);
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         }
       } else if (kq < KT + XT) {
         f32x4 H[SX];
-        if constexpr (!SPLP) {
+        if constexpr (!BF) {
 #pragma unroll
           for (int st = 0; st < SX; ++st) H[st] = get(&hl[buf][q][st][0]);
         }
@@ -317,15 +329,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
           for (int sp = 0; sp < SXH; ++sp) {
             bf16x4 t0[SPL], t1[SPL];
             bf16x8 H8[SPL];
-            if constexpr (SPLP) {
 #pragma unroll
-              for (int k = 0; k < SPL; ++k) {
-                t0[k] = get16(&hl[buf][q][2 * sp][0], k);
-                if (2 * sp + 1 < SX) t1[k] = get16(&hl[buf][q][2 * sp + 1 < SX ? 2 * sp + 1 : 0][0], k);
-              }
-            } else {
-            split(H[2 * sp], t0);
-            if (2 * sp + 1 < SX) split(H[2 * sp + 1], t1);
+            for (int k = 0; k < SPL; ++k) {         // raw-input k-tiles were written from the row-major image: plain read
+              t0[k] = get16(&hl[buf][q][2 * sp][0], k, false);
+              if (2 * sp + 1 < SX) t1[k] = get16(&hl[buf][q][2 * sp + 1 < SX ? 2 * sp + 1 : 0][0], k, false);
             }
 #pragma unroll
             for (int k = 0; k < SPL; ++k) H8[k] = cat8(t0[k], 2 * sp + 1 < SX ? t1[k] : zero4);
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       if (STPDE_ABLATE_W != 3) produce(nx, buf ^ 1);
       if (STPDE_ABLATE_W != 2) {
         transpose_p(raw, pa);
-        pack_p(pa);
+        pack_p(raw);
       }
       if (STPDE_ABLATE_W != 5) __syncthreads();
       buf ^= 1;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       __syncthreads();
       produce(nx, 0);
       transpose_p(raw, pa);
-      pack_p(pa);
+      pack_p(raw);
       __syncthreads();
     }
   }
