@@ -249,6 +249,8 @@ typedef struct {
   long N;
   int C, training, relu;
   float eps, momentum;
+  int scratch_zeroed;   /* != 0: the caller hands over zero-filled sums / bsum scratch (e.g. slices of one buffer cleared once
+                           per step), so no memset is queued in front of the reduction kernels */
 } stpde_bn_desc;
 int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float* residual, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float* sums, float* stat, float* y, void* stream);

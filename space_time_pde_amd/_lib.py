@@ -53,7 +53,7 @@ class ResampleDesc(C.Structure):
 
 class BnDesc(C.Structure):
     _fields_ = [("N", C.c_long), ("C", C.c_int), ("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float),
-                ("momentum", C.c_float)]
+                ("momentum", C.c_float), ("scratch_zeroed", C.c_int)]
 
 
 class AdamDesc(C.Structure):

@@ -222,7 +222,7 @@ extern "C" int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float*
   a.y = y;
   const unsigned grid = bn_grid(d);
   if (d->training) {
-    (void)hipMemsetAsync(sums, 0, 3 * d->C * sizeof(float), (hipStream_t)stream);
+    if (!d->scratch_zeroed) (void)hipMemsetAsync(sums, 0, 3 * d->C * sizeof(float), (hipStream_t)stream);
     STPDE_LAUNCH(k_bn_stats, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     rc = stpde_check_launch("k_bn_stats");
     if (rc) return rc;
@@ -253,7 +253,7 @@ extern "C" int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float*
   a.dgamma = dgamma;
   a.dbeta = dbeta;
   const unsigned grid = bn_grid(d);
-  (void)hipMemsetAsync(bsum, 0, 2 * d->C * sizeof(float), (hipStream_t)stream);
+  if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, 2 * d->C * sizeof(float), (hipStream_t)stream);
   STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   rc = stpde_check_launch("k_bn_bwd_reduce");
   if (rc) return rc;

@@ -91,6 +91,9 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if loss_type not in _LOSS_SUMS:
         raise KeyError(loss_type)
+    if hasattr(unet, "deferred_weight_grads"):
+        # this step calls loss.backward(): the U-Net's weight gradients may run beside its input-gradient chain
+        unet.deferred_weight_grads = unet.training
     latent_grid = unet(input_grid).permute(0, 2, 3, 4, 1)            # train.py:58-60
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)

@@ -64,6 +64,81 @@ def _desc(x, ci, co, k):
     return d
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+class _DeferredGrads:
+    """Weight / bias gradients of the U-Net convolutions off the critical path of the backward pass (opt-in:
+    ``UNet3d.deferred_weight_grads``; ``train_step.sharded_step`` turns it on).
+
+    The backward of a convolution needs its input gradient for the next node, but nothing downstream needs its weight
+    gradient before the optimizer step.  In this mode ``_Conv3dHip.backward`` launches the weight-gradient kernel and the
+    bias reduction on a SIDE stream (after an event on the stream that produced its inputs), returns ``None`` for them,
+    and one callback queued on the autograd engine -- it runs when the whole backward pass is over -- makes the main
+    stream wait for the side stream and assigns every ``.grad`` from the per-step gradient buffer with ONE index gather
+    (instead of one permute-copy per convolution).  The deep levels of the U-Net are a chain of 5-50 us kernels that leave
+    most of the chip idle; the weight-gradient kernels fill it.  Only ``loss.backward()`` sees the gradients (they are
+    accumulated into ``.grad``); ``torch.autograd.grad(..., unet.parameters())`` does not -- hence opt-in."""
+
+    def __init__(self, convs, dwall, sizes, device):
+        self.convs, self.dwall, self.device = convs, dwall, device
+        self.side = _side_stream(device)
+        nb = [c.weight.shape[0] if c.bias is not None else 0 for c in convs]
+        self.dball = torch.zeros(max(1, sum(nb)), device=device)
+        self.boff = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+        self.used = set()
+        self.queued = False
+
+    def bias_slice(self, i):
+        return self.dball[int(self.boff[i]):int(self.boff[i + 1])]
+
+    def enqueue(self, i):
+        self.used.add(i)
+        if not self.queued:
+            self.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finalize)
+
+    @staticmethod
+    def unpack_index(convs, sizes, device):
+        """position in the flat per-step buffer (tap-major [ntap][co][ci padded] per convolution) of every weight element,
+        in the order of the concatenated parameters"""
+        chunks, off = [], 0
+        for c, n in zip(convs, sizes):
+            co, ci, k = c.weight.shape[0], c.weight.shape[1], c.weight.shape[2]
+            cip = (ci + 15) // 16 * 16
+            o = np.arange(co)[:, None, None]
+            i = np.arange(ci)[None, :, None]
+            t = np.arange(k ** 3)[None, None, :]
+            chunks.append((off + (t * co + o) * cip + i).reshape(-1))
+            off += n
+        return torch.from_numpy(np.concatenate(chunks)).to(device)
+
+    def finalize(self):
+        self.queued = False
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().wait_stream(self.side)
+            gflat = self.dwall[self.uidx]            # one gather: every weight gradient in parameter layout
+            o = 0
+            for i, c in enumerate(self.convs):
+                n = c.weight.numel()
+                if i in self.used:
+                    if c.weight.requires_grad:
+                        g = gflat[o:o + n].view_as(c.weight)
+                        c.weight.grad = g if c.weight.grad is None else c.weight.grad + g
+                    if c.bias is not None and c.bias.requires_grad:
+                        gb = self.bias_slice(i)
+                        c.bias.grad = gb if c.bias.grad is None else c.bias.grad + gb
+                o += n
+        self.used = set()
+
+
 class _Conv3dHip(torch.autograd.Function):
     """y = conv3d(x, weight, bias), stride 1, padding (k-1)/2, on channels-last x [B,T,Z,X,Ci].
 
@@ -78,13 +153,15 @@ class _Conv3dHip(torch.autograd.Function):
         cip, cop = (ci + 15) // 16 * 16, (co + 15) // 16 * 16
         if cop != co:
             raise NotImplementedError("HIP conv3d needs out_channels to be a multiple of 16 (got %d)" % co)
-        ctx.dwbuf = None
+        ctx.dwbuf = ctx.defer = None
         if packs is None:
             fidx, bidx, _, _ = _pack_indices(co, ci, k, x.device)
             wflat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
             fpack, bpack = wflat[fidx], None
         else:
-            fpack, bpack, ctx.dwbuf = packs
+            fpack, bpack, ctx.dwbuf = packs[:3]
+            if len(packs) > 3:
+                ctx.defer = packs[3:5]              # (_DeferredGrads, index of this convolution in it)
             wflat = bidx = None
         xin = x.detach()
         if cip != ci:
@@ -108,6 +185,7 @@ class _Conv3dHip(torch.autograd.Function):
         co, ci, k, cip, bidx, has_bias = ctx.meta
         gy = gy.contiguous()
         dx = dw = db = None
+        ready = torch.cuda.current_stream().record_event() if ctx.defer is not None else None   # gy is complete here
         if ctx.needs_input_grad[0]:
             dxp = torch.empty(xin.shape, device=gy.device, dtype=torch.float32)
             d = _desc(gy, co, cip, k)
@@ -115,6 +193,22 @@ class _Conv3dHip(torch.autograd.Function):
             _lib.check(L.stpde_conv3d_fwd(C.byref(d), _lib.ptr(gy), _lib.ptr(bpack), None, _lib.ptr(dxp),
                                           _lib.stream_ptr()))
             dx = dxp[..., :ci] if cip != ci else dxp
+        if ctx.defer is not None and ctx.dwbuf is not None:
+            # weight gradient + bias reduction on the side stream; .grad is assigned when the backward pass is over
+            defer, idx = ctx.defer
+            gy.record_stream(defer.side)
+            xin.record_stream(defer.side)
+            defer.side.wait_event(ready)          # not the input-gradient kernel just queued: the two run side by side
+            with torch.cuda.stream(defer.side):
+                if ctx.needs_input_grad[1]:
+                    dwt, ctx.dwbuf = ctx.dwbuf, None
+                    d = _desc(xin, cip, co, k)
+                    _lib.check(L.stpde_conv3d_wgrad(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt),
+                                                    _lib.stream_ptr()))
+                if has_bias and ctx.needs_input_grad[2]:
+                    torch.sum(gy.reshape(-1, co), 0, out=defer.bias_slice(idx))
+            defer.enqueue(idx)
+            return dx, None, None, None
         if ctx.needs_input_grad[1]:
             ntap = k ** 3
             dwt, ctx.dwbuf = ctx.dwbuf, None     # zero-filled slice of the per-step buffer (used once), else a fresh one
@@ -182,14 +276,17 @@ class _BnActHip(torch.autograd.Function):
 
     @staticmethod
     @_lib.guarded
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, scratch=None):
         L = _lib.lib()
         x = x.contiguous()
         residual = residual.contiguous() if residual is not None else None
         c = x.shape[-1]
         d = _lib.BnDesc()
         d.N, d.C, d.training, d.relu, d.eps, d.momentum = x.numel() // c, c, int(training), int(relu), eps, momentum
-        sums = torch.empty(3 * c, device=x.device) if training else None
+        # scratch = zero-filled [5][C] slice of the U-Net's per-step buffer (3C forward sums, 2C backward sums): no memsets
+        ctx.scratch = scratch
+        d.scratch_zeroed = int(scratch is not None)
+        sums = (scratch[:3 * c] if scratch is not None else torch.empty(3 * c, device=x.device)) if training else None
         stat = torch.empty(2 * c, device=x.device)
         y = torch.empty_like(x)
         _lib.check(L.stpde_bn_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(residual),
@@ -217,12 +314,14 @@ class _BnActHip(torch.autograd.Function):
         dr = torch.empty_like(x) if (ctx.has_res and need_r) else None
         dw = torch.empty(c, device=x.device) if (weight is not None and need_w) else None
         db = torch.empty(c, device=x.device) if need_b else None
-        bsum = torch.empty(2 * c, device=x.device)
+        scratch, ctx.scratch = ctx.scratch, None          # used once (a second backward gets a fresh buffer + memset)
+        d.scratch_zeroed = int(scratch is not None)
+        bsum = scratch[3 * c:] if scratch is not None else torch.empty(2 * c, device=x.device)
         _lib.check(L.stpde_bn_bwd(C.byref(d), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gy),
                                   _lib.ptr(weight.detach() if weight is not None else None), _lib.ptr(stat),
                                   _lib.ptr(bsum), _lib.ptr(dx), _lib.ptr(dr), _lib.ptr(dw), _lib.ptr(db),
                                   _lib.stream_ptr()))
-        return dx, dr, dw, db, None, None, None, None, None, None
+        return dx, dr, dw, db, None, None, None, None, None, None, None
 
 
 def _bn_act(x, bn, relu, residual=None):
@@ -245,8 +344,11 @@ def _bn_act(x, bn, relu, residual=None):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
+    scratch = getattr(bn, "_stpde_scratch", None)
+    if scratch is not None:
+        bn._stpde_scratch = None              # one use per step
     return _BnActHip.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps),
-                           bool(relu))
+                           bool(relu), scratch)
 
 
 class _ResampleHip(torch.autograd.Function):
@@ -367,6 +469,9 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
                              "Instead igres: {}, ogres: {}".format(igres, ogres))
         self.exp_fac = fac.astype(np.int32)
         self.expand = bool(np.any(self.exp_fac != 0))
+        # weight / bias gradients of the convolutions on a side stream, .grad assigned when loss.backward() is over (see
+        # _DeferredGrads); off by default: only .backward() sees these gradients, torch.autograd.grad(...) does not
+        self.deferred_weight_grads = False
         self.li = int(round(math.log2(max(self.igres))))   # number of input levels
         self.lo = int(round(math.log2(max(self.ogres))))   # number of output levels
         self._create_layers()
@@ -456,11 +561,18 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
         need_dw = torch.is_grad_enabled() and any(c.weight.requires_grad for c in convs)
         sizes = [c.weight.shape[2] ** 3 * c.weight.shape[0] * ((c.weight.shape[1] + 15) // 16 * 16) for c in convs]
         dwall = torch.zeros(sum(sizes), device=device) if need_dw else None
+        defer = None
+        if need_dw and self.deferred_weight_grads and self.training:
+            defer = _DeferredGrads(convs, dwall, sizes, device)
+            if len(plan) < 4:
+                plan = plan + (_DeferredGrads.unpack_index(convs, sizes, device),)
+                self._pack_plan = plan
+            defer.uidx = plan[3]
         o = 0
-        for c, (a, b, e), n in zip(convs, plan[2], sizes):
+        for i, (c, (a, b, e), n) in enumerate(zip(convs, plan[2], sizes)):
             co, ci, k = c.weight.shape[0], c.weight.shape[1], c.weight.shape[2]
             dw = dwall[o:o + n].view(k ** 3, co, (ci + 15) // 16 * 16) if need_dw else None
-            c._stpde_packs = (packs[a:b], packs[b:e], dw)
+            c._stpde_packs = (packs[a:b], packs[b:e], dw) + ((defer, i) if defer is not None else ())
             o += n
         bns = []
         if self.training:
@@ -470,6 +582,14 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
                 torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
                 for m in bns:
                     m._stpde_counted = True
+            # one zero-filled buffer for the statistics scratch of every BatchNorm of the step (forward + backward sums):
+            # one memset instead of two per BatchNorm call
+            allbn = [m for m in self.modules() if isinstance(m, nn.BatchNorm3d)]
+            zero = torch.zeros(5 * sum(m.num_features for m in allbn), device=device)
+            o = 0
+            for m in allbn:
+                m._stpde_scratch = zero[o:o + 5 * m.num_features]
+                o += 5 * m.num_features
         return convs, bns
 
     def forward(self, x):
@@ -484,6 +604,9 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
                 c._stpde_packs = None
             for m in bns:
                 m._stpde_counted = False
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm3d):
+                    m._stpde_scratch = None
 
     def _forward_impl(self, x):
         h = self.conv_in.forward_cl(x.permute(0, 2, 3, 4, 1).contiguous())

@@ -23,6 +23,14 @@ run(net, 2)
 t_eager, y_e = run(net, 10)
 g_e = [p.grad.clone() for p in net.parameters()]
 print("eager ms/iter", t_eager)
+net.deferred_weight_grads = True          # weight / bias gradients on a side stream, .grad assigned after the backward pass
+run(net, 2)
+t_def, y_d = run(net, 10)
+g_d = [p.grad for p in net.parameters()]
+print("eager, deferred weight gradients ms/iter", t_def)
+print("  out rel diff", ((y_d - y_e).abs().max() / y_e.abs().max()).item(),
+      " max grad-norm rel diff", max(((a - b).norm() / (b.norm() + 1e-20)).item() for a, b in zip(g_d, g_e)))
+net.deferred_weight_grads = False
 try:
     gnet = torch.cuda.make_graphed_callables(net2, (x,))
     m_params[id(gnet)] = list(net2.parameters())
