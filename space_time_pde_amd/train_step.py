@@ -93,7 +93,7 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
         raise KeyError(loss_type)
     if hasattr(unet, "deferred_weight_grads"):
         # this step calls loss.backward(): the U-Net's weight gradients may run beside its input-gradient chain
-        unet.deferred_weight_grads = unet.training
+        unet.deferred_weight_grads = True
     latent_grid = unet(input_grid).permute(0, 2, 3, 4, 1)            # train.py:58-60
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)

@@ -562,7 +562,7 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
         sizes = [c.weight.shape[2] ** 3 * c.weight.shape[0] * ((c.weight.shape[1] + 15) // 16 * 16) for c in convs]
         dwall = torch.zeros(sum(sizes), device=device) if need_dw else None
         defer = None
-        if need_dw and self.deferred_weight_grads and self.training:
+        if need_dw and self.deferred_weight_grads:
             defer = _DeferredGrads(convs, dwall, sizes, device)
             if len(plan) < 4:
                 plan = plan + (_DeferredGrads.unpack_index(convs, sizes, device),)
