@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 bash $R/tools/profile_r2.sh > $O/profile_r2.log 2>&1
 cd $R
-python tools/make_traffic_json.py $O/prof_r2/r2_pmc_FETCH_SIZE.txt $O/prof_r2/r2_pmc_WRITE_SIZE.txt 262144 softplus $O/prof_r2/pmc_traffic.json
+python tools/make_traffic_json.py $O/prof_r2/r2_pmc_FETCH_SIZE.txt $O/prof_r2/r2_pmc_WRITE_SIZE.txt 1048576 softplus $O/prof_r2/pmc_traffic.json
 python bench.py --traffic-json $O/prof_r2/pmc_traffic.json > $O/r2_bench.json 2> $O/r2_bench.err
 python bench.py --act leakyrelu --no-cpu-baseline > $O/r2_bench_leakyrelu.json 2> $O/r2_bench_leakyrelu.err
 python bench.py --mlp-precision fp32x3 --no-cpu-baseline > $O/r2_bench_fp32x3.json 2> $O/r2_bench_fp32x3.err
