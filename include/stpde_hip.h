@@ -126,7 +126,7 @@ int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pre, const fl
  * {1, 2}: equivalent to three stpde_jet_layer_fwd calls, but the inter-layer data stays in registers (the accumulator
  * tiles of one layer are the B operand of the next); the pre-activations of all three layers are written for the backward.
  * Wh_pack / Ws_pack / tanc / out_pre: HOST arrays of 3 device pointers (layers 3, 4, 5).  Stream sets (0,0) (3,0)
- * (3,1 combined) (3,2). */
+ * (3,1 combined) (3,2), and the forward-only value-tile set (0,3): ntiles = row tiles / 4, tanc may be NULL. */
 int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                        const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
                        float* const* out_pre, const float* cw, void* stream);

@@ -70,7 +70,6 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
   constexpr bool VT = S1 == 0 && S2 > 0;     // value-tile mode: every stream is the value stream of its own row tile
   const int lo = lane * 4;
   f32x4 (&acc)[1][S] = *reinterpret_cast<f32x4 (*)[1][S]>(accm);
-  const f32x4* xb = xbv[0];
   constexpr int mi = 0;
     if (EPI == EPI_FWD) {
 #pragma unroll

@@ -27,10 +27,14 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
   if (tile >= a.ntiles) return;
   const int lo = lane * 4;
   float cq[6];
-  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
-  f32x4 xb[XT];
+  constexpr bool VT = S1 == 0 && S2 > 0;     // value-tile mode (forward-only queries): the S "streams" are the value
+  constexpr int NX = VT ? S : 1;             // streams of S consecutive row tiles, each with its own raw-input tile
+  if (!VT) load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  f32x4 xb[NX][XT];
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+  for (int sv = 0; sv < NX; ++sv)
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
 
   // epilogue of one layer: skip GEMM with the raw input (bias through its ones column), tangent constants, store
   auto finish = [&](int l, int MT, int mt, f32x4* acc) {
@@ -38,7 +42,9 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
     for (int xt = 0; xt < XT; ++xt) {
       const f32x4 w = ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
 #pragma unroll
-      for (int r = 0; r < x_live(xt); ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
+      for (int sv = 0; sv < NX; ++sv)
+#pragma unroll
+        for (int r = 0; r < x_live(xt); ++r) acc[sv] = mfma4(w[r], xb[sv][xt][r], acc[sv]);
     }
     if (S1 == 3) {
 #pragma unroll
@@ -164,7 +170,7 @@ extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16
     }
     a.Wh[l] = Wh_pack[l];
     a.Ws[l] = Ws_pack[l];
-    a.tanc[l] = tanc[l];
+    a.tanc[l] = tanc ? tanc[l] : nullptr;
     a.out[l] = out_pre[l];
   }
   a.cw = cw;
@@ -175,6 +181,7 @@ extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16
   if (S1 == 3 && S2 == 0) return launch_tail_act<3, 0>(a, nf16, (hipStream_t)stream);
   if (S1 == 3 && S2 == 1 && cfg->combo && cw) return launch_tail_act<3, 1>(a, nf16, (hipStream_t)stream);
   if (S1 == 3 && S2 == 2) return launch_tail_act<3, 2>(a, nf16, (hipStream_t)stream);
+  if (S1 == 0 && S2 == 3) return launch_tail_act<0, 3>(a, nf16, (hipStream_t)stream);   // value tiles: ntiles = row tiles / 4
   stpde_set_error("jet_tail_fwd: stream configuration S1=%d S2=%d not compiled", S1, S2);
   return STPDE_E_UNSUPPORTED;
 }

@@ -196,14 +196,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   constexpr int SH = (S + 1) / 2, SXH = (SX + 1) / 2;
   bf16x8 pa8[BF ? SPL : 1][BF ? SH : 1][MCW];
   const bf16x4 zero4 = to_bf4(f32x4{0.f, 0.f, 0.f, 0.f});
-  // the SPL bf16 terms of an fp32 fragment (SPL = 1: plain rounding)
-  auto split = [&](f32x4 v, bf16x4* t) {
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) {
-      t[k] = to_bf4(v);
-      if (k + 1 < SPL) v -= bf4_to_f32(t[k]);
-    }
-  };
   // bf16-pipe modes: the column-major abar blocks `raw_` of the tile -> split into bf16 terms, transposed through this
   // wave's private patch (one ds_write_b64 + one transpose read per term), packed two streams per MFMA operand
   auto pack_p = [&](f32x4 (*raw_)[MCW]) {

@@ -367,15 +367,15 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         lcfg.S1, lcfg.S2, lcfg.act, lcfg.act_param = 0, 3, cfg.act, cfg.act_param
         lnt = nt // 4
     # fc3 -> fc4 -> fc5 in one kernel (inter-layer data in registers) for the reference widths and the training stream sets
-    tail = (fused_tail and not vt and plan.nf in (16, 32) and (cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
-            and (cfg.S2 != 1 or cw is not None))
+    tail = (fused_tail and plan.nf in (16, 32) and (vt or ((cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
+                                                           and (cfg.S2 != 1 or cw is not None))))
     for l in range(1, 6):
         lay = plan.layers[l]
         if tail and l == 3:
             outs = [torch.empty(nt * S * plan.layers[k]["MT"] * _FRAG, device=dev) for k in (3, 4, 5)]
             arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
             with _timed("tail_fwd"):
-                check(L.stpde_jet_tail_fwd(C.byref(cfg), nt, plan.nf // 16, ptr(prev), ptr(X),
+                check(L.stpde_jet_tail_fwd(C.byref(lcfg), lnt, plan.nf // 16, ptr(prev), ptr(X),
                                            arr([pv(packs, k, "Wh") for k in (3, 4, 5)]),
                                            arr([pv(packs, k, "Ws") for k in (3, 4, 5)]),
                                            arr([pv(packs, k, "tanc") for k in (3, 4, 5)]), arr(outs), ptr(cw), st))
