@@ -355,6 +355,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_hip_event_median": round(step_ms_median, 3),
+            "ms_per_step_hip_event_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
