@@ -40,25 +40,27 @@ struct WgradArgs {
 #ifndef STPDE_ABLATE_W
 #define STPDE_ABLATE_W 0
 #endif
-constexpr int TPAD = 20;             // padded row length of a transposed (feature-major) LDS block
-constexpr int TBLK = 16 * TPAD;      // floats per transposed block
-
-// column-major image in registers -> feature-major padded LDS block
-__device__ __forceinline__ void lds_put_T(float* blk, int lane, f32x4 v) {
+// Padded row length TP (floats) of a transposed (feature-major) LDS block.  Under the per-instruction banking of gfx950
+// (MI355X_MICROARCH.md, LDS): TP = 24 makes the ds_read_b128 of a block conflict-free and its four ds_write_b32 2-way
+// conflicted, which a ds_write_b32 hides (its cost is the VGPR transfer); TP = 20 is the other way round (writes free, reads 2-way:
+// SQ_LDS_BANK_CONFLICT was 38 % of the LDS-array cycles of the first-layer kernel) and is kept where 24 would not fit two ring
+// buffers in LDS.
+template <int TP>
+__device__ __forceinline__ void lds_put_T(float* blk, int lane, f32x4 v) {   // column-major image -> feature-major block
   const int g = lane >> 4, j = lane & 15;
-  float* w = blk + (4 * g) * TPAD + j;
+  float* w = blk + (4 * g) * TP + j;
   w[0] = v[0];
-  w[TPAD] = v[1];
-  w[2 * TPAD] = v[2];
-  w[3 * TPAD] = v[3];
+  w[TP] = v[1];
+  w[2 * TP] = v[2];
+  w[3 * TP] = v[3];
 }
-// row-major image in registers -> the same LDS block format
-__device__ __forceinline__ void lds_put_R(float* blk, int lane, f32x4 v) {
-  *reinterpret_cast<f32x4*>(blk + (lane & 15) * TPAD + 4 * (lane >> 4)) = v;
+template <int TP>
+__device__ __forceinline__ void lds_put_R(float* blk, int lane, f32x4 v) {   // row-major image -> the same block format
+  *reinterpret_cast<f32x4*>(blk + (lane & 15) * TP + 4 * (lane >> 4)) = v;
 }
-// row-major image out of a transposed LDS block: lane 16g+c gets rows 4g..4g+3 of feature c
-__device__ __forceinline__ f32x4 lds_get_R(const float* blk, int lane) {
-  return *reinterpret_cast<const f32x4*>(blk + (lane & 15) * TPAD + 4 * (lane >> 4));
+template <int TP>
+__device__ __forceinline__ f32x4 lds_get_R(const float* blk, int lane) {     // lane 16g+c: rows 4g..4g+3 of feature c
+  return *reinterpret_cast<const f32x4*>(blk + (lane & 15) * TP + 4 * (lane >> 4));
 }
 
 // BF: one v_mfma_f32_16x16x32_bf16 contracts over the 16 rows of the tile for TWO derivative streams (k-slot e of a
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // row-major operand fragment with the hardware transpose read ds_read_b64_tr_b16 (column-major sources) or a plain
   // ds_read_b64 (row-major sources).  (First half of round 2: fp32 blocks transposed with four ds_write_b32 per lane and
   // converted / split by every consumer; in plain bf16 mode those transposes were 44 % of the kernel.)
+  constexpr int TP = (2 * RS * S * 16 * 24 * 4 + NW * 2 * 16 * 24 * 4 <= 150 * 1024) ? 24 : 20;
+  constexpr int TBLK = 16 * TP;
   constexpr int BLK = BF ? 128 * SPL : TBLK;
   constexpr int NBUF = (2 * RS * S * BLK * 4 + NW * 2 * BLK * 4 <= 150 * 1024) ? 2 : 1;
   constexpr int SX = S1 == 3 ? 4 : 1;       // raw-input tiles only feed the value and tangent streams
@@ -116,12 +120,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         if (t + 1 < SPL) v -= bf4_to_f32(h);   // exact: the residual of a round-to-nearest bf16 fits in fp32
       }
     } else if (row_major) {
-      lds_put_R(blk, lane, v);
+      lds_put_R<TP>(blk, lane, v);
     } else {
-      lds_put_T(blk, lane, v);
+      lds_put_T<TP>(blk, lane, v);
     }
   };
-  auto get = [&](const float* blk) -> f32x4 { return lds_get_R(blk, lane); };
+  auto get = [&](const float* blk) -> f32x4 { return lds_get_R<TP>(blk, lane); };
   // bf16-pipe modes: term t of this lane's row-major operand fragment (rows 4g..4g+3 of feature c) out of a block written
   // by put(); cm = the block came from a column-major source ([row][feature] image -> transpose read)
   auto get16 = [&](const float* blk, int t, bool cm = true) -> bf16x4 {
@@ -186,9 +190,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         float* patch = pp[wv][(st * MCW + mi) & 1];
-        lds_put_T(patch, lane, raw[st][mi]);
+        lds_put_T<TP>(patch, lane, raw[st][mi]);
         __builtin_amdgcn_wave_barrier();
-        pa[st][mi] = lds_get_R(patch, lane);
+        pa[st][mi] = lds_get_R<TP>(patch, lane);
         __builtin_amdgcn_wave_barrier();
       }
   };
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 template <int S1, int S2, int ACT, int MCW, int KTT>
 __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
   constexpr int S = 1 + S1 + S2, NK = KTT + XT;
+  constexpr int TP = 24, TBLK = 16 * TP;
   __shared__ __attribute__((aligned(16))) float pp[4][2][TBLK];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -404,9 +409,9 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
   auto transpose = [&](f32x4 v) -> f32x4 {   // column-major image -> row-major image (alternating patches)
     float* patch = pp[wv][flip];
     flip ^= 1;
-    lds_put_T(patch, lane, v);
+    lds_put_T<TP>(patch, lane, v);
     __builtin_amdgcn_wave_barrier();
-    const f32x4 r = lds_get_R(patch, lane);
+    const f32x4 r = lds_get_R<TP>(patch, lane);
     __builtin_amdgcn_wave_barrier();
     return r;
   };
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
   }
 
   // block reduction (4 waves) through the patches, then one set of atomics per block
-  float* red = &pp[0][0][0];        // 4 x 256 floats needed, 8 x 320 available
+  float* red = &pp[0][0][0];        // 4 x 256 floats needed, 8 x 384 available
   const int ldw = 16 * (KTT + XT);
 #pragma unroll
   for (int mi = 0; mi < MCW; ++mi)
