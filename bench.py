@@ -219,7 +219,8 @@ def main():
         sev[k][1].record()
     sync()
     dt = time.perf_counter() - t0
-    step_ms = sorted(a.elapsed_time(b) for a, b in sev)
+    step_ms_seq = [a.elapsed_time(b) for a, b in sev]
+    step_ms = sorted(step_ms_seq)
     step_ms_median = step_ms[len(step_ms) // 2]
     # per-kernel HIP-event timings: a SECOND pass outside the timed region (the event pairs around ~70 launches per
     # step would otherwise sit inside it)
@@ -356,6 +357,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_hip_event_median": round(step_ms_median, 3),
             "ms_per_step_hip_event_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+            "ms_per_step_hip_event_sequence": [round(v, 2) for v in step_ms_seq],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

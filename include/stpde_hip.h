@@ -241,10 +241,13 @@ int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* 
  * Channels-last x [N][C], N = B*T*Z*X, C a power of two in [16, 512].
  * forward:  y = act(bn(x) [+ residual]);  training != 0: batch statistics (biased variance for the normalisation,
  *           running_mean / running_var updated in place with torch's momentum rule and the unbiased variance);
- *           training == 0: running statistics.  sums: [3][C] scratch (training), stat: [2][C] receives mean, rstd.
+ *           training == 0: running statistics.  sums: [STPDE_BN_REP][3][C] scratch (training), stat: [2][C] receives mean, rstd.
  * backward: dz = dy * [y > 0] (relu) ; dresidual = dz ; dx, dgamma, dbeta as torch's batch_norm backward
- *           (training: with the batch-statistics terms, evaluation: without).  bsum: [2][C] scratch.
+ *           (training: with the batch-statistics terms, evaluation: without).  bsum: [STPDE_BN_REP][2][C] scratch.
+ * The reduction kernels spread their per-block atomics over STPDE_BN_REP replicas of the sums (one copy made ~1000 blocks
+ * queue on 2 C addresses); the elementwise kernels add the replicas up in a fixed order.
  * Any of residual, gamma, beta, dx, dresidual, dgamma, dbeta may be NULL. */
+#define STPDE_BN_REP 16
 typedef struct {
   long N;
   int C, training, relu;

@@ -51,6 +51,9 @@ class ResampleDesc(C.Structure):
                 ("fz", C.c_int), ("fx", C.c_int)]
 
 
+BN_REP = 16        # STPDE_BN_REP: replicas of the BatchNorm reduction scratch (include/stpde_hip.h)
+
+
 class BnDesc(C.Structure):
     _fields_ = [("N", C.c_long), ("C", C.c_int), ("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float),
                 ("momentum", C.c_float), ("scratch_zeroed", C.c_int)]

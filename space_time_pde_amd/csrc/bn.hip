@@ -17,75 +17,96 @@ struct BnArgs {
   const float* beta;
   float* running_mean;   // updated in training mode (may be null)
   float* running_var;
-  float* sums;           // [3][C]: shift, sum(x - shift), sum((x - shift)^2)      (training forward)
+  float* sums;           // [STPDE_BN_REP][3][C]: shift (replica 0), sum(x - shift), sum((x - shift)^2)   (training forward)
   float* stat;           // [2][C]: mean, rstd (written by apply, read by backward)
   float* y;
   const float* dy;
-  float* bsum;           // [2][C]: sum(dz), sum(dz * xhat)
+  float* bsum;           // [STPDE_BN_REP][2][C]: sum(dz), sum(dz * xhat)
   float* dx;
   float* dr;             // gradient of the residual input or null
   float* dgamma;
   float* dbeta;
 };
 
-// thread -> (channel slot, row offset): C <= 256: one channel per thread, 256 / C rows in flight per block;
-// C == 512: two channels per thread (c and c + 256), one row in flight
+// thread -> (channel quad q = 4 consecutive channels, row offset): C / 4 quads, 256 / (C / 4) rows in flight per block; every
+// access is one 16-byte load / store per thread and a block iteration covers 4 KiB of contiguous memory.  (First version: one
+// channel and 4 bytes per thread -- 1.15 TB/s on the 524,288-voxel level; the four kernels were 4.0 ms of the step.)
 struct BnMap {
-  int c, nc, row0, rstep;
+  int q, row0, rstep, nq;
 };
 __device__ __forceinline__ BnMap bn_map(int C) {
   BnMap m;
-  if (C <= 256) {
-    m.c = threadIdx.x % C;
-    m.nc = 1;
-    m.row0 = threadIdx.x / C;
-    m.rstep = 256 / C;
-  } else {
-    m.c = threadIdx.x;
-    m.nc = C / 256;
-    m.row0 = 0;
-    m.rstep = 1;
-  }
+  m.nq = C >> 2;                 // 4 .. 128
+  m.q = threadIdx.x % m.nq;
+  m.row0 = threadIdx.x / m.nq;
+  m.rstep = 256 / m.nq;
   return m;
 }
 
-// sums over the threads of a block that share a channel slot; result valid for threads with row0 == 0
-__device__ __forceinline__ float bn_block_sum(float v, float* sh, const BnMap& m, int C) {
+// sums over the threads of a block that share a channel quad; result valid for threads with row0 == 0.
+// Lanes of a wave that share a quad are nq apart: butterfly over the lane bits above log2(nq), then the four waves through LDS.
+__device__ __forceinline__ f32x4 bn_block_sum(f32x4 v, f32x4* sh, const BnMap& m) {
+  for (int off = 32; off >= m.nq; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, 64);
+  }
   __syncthreads();
   sh[threadIdx.x] = v;
   __syncthreads();
-  float s = 0.f;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   if (m.row0 == 0) {
-    const int stride = C <= 256 ? C : 256;
-    for (int t = threadIdx.x; t < 256; t += stride) s += sh[t];
+    if (m.nq <= 64) {
+      for (int w = 0; w < 4; ++w) s += sh[64 * w + m.q];       // lane q of every wave holds that wave's sum
+    } else {
+      s = sh[m.q] + sh[128 + m.q];                             // nq == 128: two rows in flight, no lanes to fold
+    }
   }
   return s;
 }
 
+__device__ __forceinline__ void atomic_add4(float* p, f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) atomicAdd(p + i, v[i]);
+}
+
 __global__ __launch_bounds__(256) void k_bn_stats(BnArgs a) {
-  __shared__ float sh[256];
+  __shared__ f32x4 sh[256];
   const int C = a.d.C;
   const long N = a.d.N;
   const BnMap m = bn_map(C);
   const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * rows_per_block;
   const long hi = lo + rows_per_block < N ? lo + rows_per_block : N;
-  for (int k = 0; k < m.nc; ++k) {
-    const int c = m.c + 256 * k;
-    const float shift = a.x[c];                    // voxel 0 of this channel
-    float s1 = 0.f, s2 = 0.f;
-    for (long row = lo + m.row0; row < hi; row += m.rstep) {
-      const float v = a.x[row * C + c] - shift;
-      s1 += v;
-      s2 += v * v;
+  const int c = 4 * m.q;
+  const f32x4 shift = ld4(a.x + c);                    // voxel 0 of these channels
+  f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  long row = lo + m.row0;
+  const long st = m.rstep;
+  for (; row + 3 * st < hi; row += 4 * st) {          // four independent 16-byte loads in flight per thread
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ld4(a.x + (row + u * st) * C + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 d = v[u] - shift;
+      s1 += d;
+      s2 += d * d;
     }
-    s1 = bn_block_sum(s1, sh, m, C);
-    s2 = bn_block_sum(s2, sh, m, C);
-    if (m.row0 == 0) {
-      atomicAdd(a.sums + C + c, s1);
-      atomicAdd(a.sums + 2 * C + c, s2);
-      if (blockIdx.x == 0) a.sums[c] = shift;
-    }
+  }
+  for (; row < hi; row += st) {
+    const f32x4 v = ld4(a.x + row * C + c) - shift;
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = bn_block_sum(s1, sh, m);
+  s2 = bn_block_sum(s2, sh, m);
+  if (m.row0 == 0) {
+    // the partial sums of a block go to replica blockIdx % STPDE_BN_REP: with one copy, ~1000 blocks queue up on the same 2 C
+    // addresses in the L2 atomic units (that, not HBM, bounded this kernel: 62 us for 67 MB)
+    float* rep = a.sums + (size_t)(blockIdx.x % STPDE_BN_REP) * 3 * C;
+    atomic_add4(rep + C + c, s1);
+    atomic_add4(rep + 2 * C + c, s2);
+    if (blockIdx.x == 0) st4(a.sums + c, shift);
   }
 }
 
@@ -96,64 +117,96 @@ __global__ __launch_bounds__(256) void k_bn_apply(BnArgs a) {
   const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * rows_per_block;
   const long hi = lo + rows_per_block < N ? lo + rows_per_block : N;
-  for (int k = 0; k < m.nc; ++k) {
-    const int c = m.c + 256 * k;
-    float mean, var;
-    if (a.d.training) {
-      const float shift = a.sums[c], e1 = a.sums[C + c] / (float)N, e2 = a.sums[2 * C + c] / (float)N;
-      mean = shift + e1;
-      var = fmaxf(e2 - e1 * e1, 0.f);               // biased variance of the batch
-    } else {
-      mean = a.running_mean[c];
-      var = a.running_var[c];
+  const int c = 4 * m.q;
+  f32x4 mean, var;
+  if (a.d.training) {
+    f32x4 t1 = f32x4{0.f, 0.f, 0.f, 0.f}, t2 = t1;
+    for (int r = 0; r < STPDE_BN_REP; ++r) {          // fixed order: every block gets the same sums
+      t1 += ld4(a.sums + ((size_t)r * 3 + 1) * C + c);
+      t2 += ld4(a.sums + ((size_t)r * 3 + 2) * C + c);
     }
-    const float rstd = 1.f / sqrtf(var + a.d.eps);
-    if (blockIdx.x == 0 && m.row0 == 0) {
-      a.stat[c] = mean;
-      a.stat[C + c] = rstd;
-      if (a.d.training && a.running_mean) {         // torch: running = (1 - momentum) * running + momentum * batch
-        const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-        a.running_mean[c] = (1.f - a.d.momentum) * a.running_mean[c] + a.d.momentum * mean;
-        a.running_var[c] = (1.f - a.d.momentum) * a.running_var[c] + a.d.momentum * unb;
-      }
+    const f32x4 shift = ld4(a.sums + c), e1 = t1 / (float)N, e2 = t2 / (float)N;
+    mean = shift + e1;
+    var = e2 - e1 * e1;                               // biased variance of the batch
+#pragma unroll
+    for (int i = 0; i < 4; ++i) var[i] = fmaxf(var[i], 0.f);
+  } else {
+    mean = ld4(a.running_mean + c);
+    var = ld4(a.running_var + c);
+  }
+  f32x4 rstd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rstd[i] = 1.f / sqrtf(var[i] + a.d.eps);
+  if (blockIdx.x == 0 && m.row0 == 0) {
+    st4(a.stat + c, mean);
+    st4(a.stat + C + c, rstd);
+    if (a.d.training && a.running_mean) {           // torch: running = (1 - momentum) * running + momentum * batch
+      const f32x4 unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+      st4(a.running_mean + c, (1.f - a.d.momentum) * ld4(a.running_mean + c) + a.d.momentum * mean);
+      st4(a.running_var + c, (1.f - a.d.momentum) * ld4(a.running_var + c) + a.d.momentum * unb);
     }
-    const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
-    const float scale = rstd * g;
-    for (long row = lo + m.row0; row < hi; row += m.rstep) {
-      const long i = row * C + c;
-      float v = (a.x[i] - mean) * scale + b;
-      if (a.r) v += a.r[i];
-      if (a.d.relu) v = v > 0.f ? v : 0.f;
-      a.y[i] = v;
+  }
+  const f32x4 one = f32x4{1.f, 1.f, 1.f, 1.f}, zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 g = a.gamma ? ld4(a.gamma + c) : one, b = a.beta ? ld4(a.beta + c) : zero;
+  const f32x4 scale = rstd * g;
+  for (long row = lo + m.row0; row < hi; row += m.rstep) {
+    const long i = row * C + c;
+    f32x4 v = (ld4(a.x + i) - mean) * scale + b;
+    if (a.r) v += ld4(a.r + i);
+    if (a.d.relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
     }
+    st4(a.y + i, v);
   }
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(BnArgs a) {
-  __shared__ float sh[256];
+  __shared__ f32x4 sh[256];
   const int C = a.d.C;
   const long N = a.d.N;
   const BnMap m = bn_map(C);
   const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * rows_per_block;
   const long hi = lo + rows_per_block < N ? lo + rows_per_block : N;
-  for (int k = 0; k < m.nc; ++k) {
-    const int c = m.c + 256 * k;
-    const float mean = a.stat[c], rstd = a.stat[C + c];
-    float s1 = 0.f, s2 = 0.f;
-    for (long row = lo + m.row0; row < hi; row += m.rstep) {
-      const long i = row * C + c;
-      float dz = a.dy[i];
-      if (a.d.relu && !(a.y[i] > 0.f)) dz = 0.f;
-      s1 += dz;
-      s2 += dz * (a.x[i] - mean) * rstd;
+  const int c = 4 * m.q;
+  const f32x4 mean = ld4(a.stat + c), rstd = ld4(a.stat + C + c);
+  f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  const bool relu = a.d.relu != 0;
+  auto term = [&](f32x4 dz, f32x4 y, f32x4 x) {
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!(y[k] > 0.f)) dz[k] = 0.f;
     }
-    s1 = bn_block_sum(s1, sh, m, C);
-    s2 = bn_block_sum(s2, sh, m, C);
-    if (m.row0 == 0) {
-      atomicAdd(a.bsum + c, s1);
-      atomicAdd(a.bsum + C + c, s2);
+    s1 += dz;
+    s2 += dz * (x - mean) * rstd;
+  };
+  long row = lo + m.row0;
+  const long st = m.rstep;
+  for (; row + 3 * st < hi; row += 4 * st) {          // 8-12 independent 16-byte loads in flight per thread
+    f32x4 dz[4], y[4], x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = (row + u * st) * C + c;
+      dz[u] = ld4(a.dy + i);
+      x[u] = ld4(a.x + i);
+      y[u] = relu ? ld4(a.y + i) : dz[u];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) term(dz[u], y[u], x[u]);
+  }
+  for (; row < hi; row += st) {
+    const long i = row * C + c;
+    const f32x4 dz = ld4(a.dy + i);
+    term(dz, relu ? ld4(a.y + i) : dz, ld4(a.x + i));
+  }
+  s1 = bn_block_sum(s1, sh, m);
+  s2 = bn_block_sum(s2, sh, m);
+  if (m.row0 == 0) {
+    float* rep = a.bsum + (size_t)(blockIdx.x % STPDE_BN_REP) * 2 * C;
+    atomic_add4(rep + c, s1);
+    atomic_add4(rep + C + c, s2);
   }
 }
 
@@ -164,23 +217,31 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnArgs a) {
   const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * rows_per_block;
   const long hi = lo + rows_per_block < N ? lo + rows_per_block : N;
-  for (int k = 0; k < m.nc; ++k) {
-    const int c = m.c + 256 * k;
-    const float mean = a.stat[c], rstd = a.stat[C + c];
-    const float sdz = a.bsum[c], sdzx = a.bsum[C + c];
-    if (blockIdx.x == 0 && m.row0 == 0) {
-      if (a.dbeta) a.dbeta[c] = sdz;
-      if (a.dgamma) a.dgamma[c] = sdzx;
+  const int c = 4 * m.q;
+  const f32x4 mean = ld4(a.stat + c), rstd = ld4(a.stat + C + c);
+  f32x4 sdz = f32x4{0.f, 0.f, 0.f, 0.f}, sdzx = sdz;
+  for (int r = 0; r < STPDE_BN_REP; ++r) {
+    sdz += ld4(a.bsum + ((size_t)r * 2) * C + c);
+    sdzx += ld4(a.bsum + ((size_t)r * 2 + 1) * C + c);
+  }
+  if (blockIdx.x == 0 && m.row0 == 0) {
+    if (a.dbeta) st4(a.dbeta + c, sdz);
+    if (a.dgamma) st4(a.dgamma + c, sdzx);
+  }
+  const f32x4 one = f32x4{1.f, 1.f, 1.f, 1.f}, zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 g = a.gamma ? ld4(a.gamma + c) : one;
+  const f32x4 k1 = a.d.training ? sdz / (float)N : zero, k2 = a.d.training ? sdzx / (float)N : zero;
+  for (long row = lo + m.row0; row < hi; row += m.rstep) {
+    const long i = row * C + c;
+    f32x4 dz = ld4(a.dy + i);
+    if (a.d.relu) {
+      const f32x4 y = ld4(a.y + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!(y[k] > 0.f)) dz[k] = 0.f;
     }
-    const float g = a.gamma ? a.gamma[c] : 1.f;
-    const float k1 = a.d.training ? sdz / (float)N : 0.f, k2 = a.d.training ? sdzx / (float)N : 0.f;
-    for (long row = lo + m.row0; row < hi; row += m.rstep) {
-      const long i = row * C + c;
-      float dz = a.dy[i];
-      if (a.d.relu && !(a.y[i] > 0.f)) dz = 0.f;
-      if (a.dr) a.dr[i] = dz;
-      if (a.dx) a.dx[i] = g * rstd * (dz - k1 - (a.x[i] - mean) * rstd * k2);
-    }
+    if (a.dr) st4(a.dr + i, dz);
+    if (a.dx) st4(a.dx + i, g * rstd * (dz - k1 - (ld4(a.x + i) - mean) * rstd * k2));
   }
 }
 
@@ -193,7 +254,7 @@ static int bn_check(const stpde_bn_desc* d) {
 }
 
 static unsigned bn_grid(const stpde_bn_desc* d) {
-  const long rows_per_pass = d->C <= 256 ? 256 / d->C : 1;
+  const long rows_per_pass = 256 / (d->C / 4);
   long blocks = (d->N + rows_per_pass * 8 - 1) / (rows_per_pass * 8);   // >= 8 row passes per block
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
@@ -221,9 +282,11 @@ extern "C" int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float*
   a.stat = stat;
   a.y = y;
   const unsigned grid = bn_grid(d);
+  // the reduction kernels end in 8 atomics per channel quad and block: a quarter of the blocks (>= 4 waves per SIMD still)
+  const unsigned rgrid = grid > 1024 ? 1024 : grid;
   if (d->training) {
-    if (!d->scratch_zeroed) (void)hipMemsetAsync(sums, 0, 3 * d->C * sizeof(float), (hipStream_t)stream);
-    STPDE_LAUNCH(k_bn_stats, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (!d->scratch_zeroed) (void)hipMemsetAsync(sums, 0, (size_t)STPDE_BN_REP * 3 * d->C * sizeof(float), (hipStream_t)stream);
+    STPDE_LAUNCH(k_bn_stats, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, a);
     rc = stpde_check_launch("k_bn_stats");
     if (rc) return rc;
   }
@@ -253,8 +316,8 @@ extern "C" int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float*
   a.dgamma = dgamma;
   a.dbeta = dbeta;
   const unsigned grid = bn_grid(d);
-  if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, 2 * d->C * sizeof(float), (hipStream_t)stream);
-  STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, (size_t)STPDE_BN_REP * 2 * d->C * sizeof(float), (hipStream_t)stream);
+  STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, (hipStream_t)stream, a);
   rc = stpde_check_launch("k_bn_bwd_reduce");
   if (rc) return rc;
   STPDE_LAUNCH(k_bn_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

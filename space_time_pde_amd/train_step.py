@@ -10,6 +10,8 @@ of the points, and
   * the IM-NET gradients (0.84 MB) are all-reduced after backward.
 Losses are normalised by the GLOBAL element counts, so the sharded sum equals the single-process mean.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -93,7 +95,7 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
         raise KeyError(loss_type)
     if hasattr(unet, "deferred_weight_grads"):
         # this step calls loss.backward(): the U-Net's weight gradients may run beside its input-gradient chain
-        unet.deferred_weight_grads = True
+        unet.deferred_weight_grads = os.environ.get("STPDE_UNET_DEFERRED", "1") != "0"
     latent_grid = unet(input_grid).permute(0, 2, 3, 4, 1)            # train.py:58-60
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)

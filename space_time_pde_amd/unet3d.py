@@ -94,6 +94,7 @@ class _DeferredGrads:
         self.dball = torch.zeros(max(1, sum(nb)), device=device)
         self.boff = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
         self.used = set()
+        self.keep = []
         self.queued = False
 
     def bias_slice(self, i):
@@ -124,6 +125,7 @@ class _DeferredGrads:
         self.queued = False
         with torch.cuda.device(self.device):
             torch.cuda.current_stream().wait_stream(self.side)
+            self.keep = []                           # operands of the side-stream kernels: free for reuse on this stream now
             gflat = self.dwall[self.uidx]            # one gather: every weight gradient in parameter layout
             o = 0
             for i, c in enumerate(self.convs):
@@ -196,8 +198,9 @@ class _Conv3dHip(torch.autograd.Function):
         if ctx.defer is not None and ctx.dwbuf is not None:
             # weight gradient + bias reduction on the side stream; .grad is assigned when the backward pass is over
             defer, idx = ctx.defer
-            gy.record_stream(defer.side)
-            xin.record_stream(defer.side)
+            # the operands stay referenced until the callback has made the main stream wait for the side stream: no
+            # record_stream(), whose event-polled block reuse makes the caching allocator's behaviour timing-dependent
+            defer.keep.append((gy, xin))
             defer.side.wait_event(ready)          # not the input-gradient kernel just queued: the two run side by side
             with torch.cuda.stream(defer.side):
                 if ctx.needs_input_grad[1]:
@@ -283,10 +286,11 @@ class _BnActHip(torch.autograd.Function):
         c = x.shape[-1]
         d = _lib.BnDesc()
         d.N, d.C, d.training, d.relu, d.eps, d.momentum = x.numel() // c, c, int(training), int(relu), eps, momentum
-        # scratch = zero-filled [5][C] slice of the U-Net's per-step buffer (3C forward sums, 2C backward sums): no memsets
+        # scratch = zero-filled [BN_REP][5][C] slice of the U-Net's per-step buffer (forward + backward sums): no memsets
         ctx.scratch = scratch
         d.scratch_zeroed = int(scratch is not None)
-        sums = (scratch[:3 * c] if scratch is not None else torch.empty(3 * c, device=x.device)) if training else None
+        R = _lib.BN_REP
+        sums = (scratch[:3 * R * c] if scratch is not None else torch.empty(3 * R * c, device=x.device)) if training else None
         stat = torch.empty(2 * c, device=x.device)
         y = torch.empty_like(x)
         _lib.check(L.stpde_bn_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(residual),
@@ -316,7 +320,8 @@ class _BnActHip(torch.autograd.Function):
         db = torch.empty(c, device=x.device) if need_b else None
         scratch, ctx.scratch = ctx.scratch, None          # used once (a second backward gets a fresh buffer + memset)
         d.scratch_zeroed = int(scratch is not None)
-        bsum = scratch[3 * c:] if scratch is not None else torch.empty(2 * c, device=x.device)
+        R = _lib.BN_REP
+        bsum = scratch[3 * R * c:] if scratch is not None else torch.empty(2 * R * c, device=x.device)
         _lib.check(L.stpde_bn_bwd(C.byref(d), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gy),
                                   _lib.ptr(weight.detach() if weight is not None else None), _lib.ptr(stat),
                                   _lib.ptr(bsum), _lib.ptr(dx), _lib.ptr(dr), _lib.ptr(dw), _lib.ptr(db),
@@ -585,11 +590,12 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
             # one zero-filled buffer for the statistics scratch of every BatchNorm of the step (forward + backward sums):
             # one memset instead of two per BatchNorm call
             allbn = [m for m in self.modules() if isinstance(m, nn.BatchNorm3d)]
-            zero = torch.zeros(5 * sum(m.num_features for m in allbn), device=device)
+            per = 5 * _lib.BN_REP
+            zero = torch.zeros(per * sum(m.num_features for m in allbn), device=device)
             o = 0
             for m in allbn:
-                m._stpde_scratch = zero[o:o + 5 * m.num_features]
-                o += 5 * m.num_features
+                m._stpde_scratch = zero[o:o + per * m.num_features]
+                o += per * m.num_features
         return convs, bns
 
     def forward(self, x):
