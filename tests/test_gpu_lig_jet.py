@@ -379,3 +379,37 @@ def test_retain_graph_second_backward_rebuilds_the_stash(hiplib):
     loss.backward()
     assert torch.equal(latd.grad, g1)
     assert torch.allclose(net.fc[1].weight.grad, 2 * w1, rtol=1e-5, atol=1e-7 * float(w1.abs().max()))
+
+
+@pytest.mark.parametrize("cin,nf", [(8, 16), (16, 32), (24, 16)])
+def test_fewer_latent_channels(hiplib, cin, nf):
+    """Latent widths below the reference's 32: the augmented input then leaves the sparse third tile (and for 8 channels
+    the second tile) empty and the latent-gradient GEMM runs with one 16-channel tile (k_xbar<1>) or a partly filled
+    second one; forward jets and all gradients vs the fp64 oracle."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, nonlinearities
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31 + cin)
+    torch.manual_seed(5)
+    net = implicit_net.ImNet(dim=3, in_features=cin, out_features=4, nf=nf,
+                             activation=nonlinearities.NONLINEARITIES["softplus"]).to(dev)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, cin, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(2, 75, 3, generator=g)
+    pairs = ((1, 1), (2, 2))
+    latd = lat.to(dev).requires_grad_(True)
+    with _lib.dispatch_trace() as tr:
+        jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, pairs, chunk_points=64)
+        cot = torch.randn(jets.shape, generator=g)
+        (jets * cot.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+    assert tr.has("k_xbar<1>" if cin <= 16 else "k_xbar<2>"), "\n".join(tr.kernels)
+    p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
+    lat64 = lat.double().requires_grad_(True)
+    ref = J.lig_jets(p64, "softplus", lat64, pts.double(), 0., 1., second=tuple(pp))
+    ref = ref.permute(0, 3, 1, 2).reshape(ref.shape[0], 4, -1)
+    (ref * cot.double()).sum().backward()
+    for s in range(ref.shape[0]):
+        assert _relerr(jets[s], ref[s].detach()) < 2e-5, "stream %d" % s
+    assert _relerr(latd.grad, lat64.grad) < 2e-4
+    for k in range(6):
+        assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
+        assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
