@@ -97,7 +97,7 @@ int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* 
  * [b*p*2^d, d+c] matrix of src/local_implicit_grid.py:53, together with the torch.autograd.grad sweeps of
  * src/pde.py:8-9 (forward-mode streams instead of reverse sweeps).
  * out_pre[tile][S][MT] = W_h * act_jet(in_pre[tile][S][KT]) + W_s * X + tangent consts   (pre-activations)
- * first_hidden != 0: the input is layer 0's output, regenerated on the fly from X (in_pre ignored). */
+ * first_hidden != 0: the input is layer 0's output, computed on the fly from X (in_pre ignored). */
 typedef struct {
   int ntiles, KT, MT, first_hidden;
   stpde_jet_cfg cfg;

@@ -62,7 +62,8 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 }
 
 // Epilogue of one output tile `mt` held in acc[S] (D image): forward = skip GEMM + tangent constants + store of the
-// pre-activations; dgrad = activation-jet adjoint against the stored / regenerated pre-activations + R-image copies.
+// pre-activations; dgrad = activation-jet adjoint against the stored pre-activations (first hidden layer: the z0 stash of
+// the forward kernel + the constant tangent columns; its tangent-stream adjoints leave as per-tile row sums).
 template <int S1, int S2, int EPI, int ACT>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
                                                const f32x4 (*xbv)[XT], const float* cq, float& pacc) {

@@ -10,8 +10,8 @@
 //     (2*KC) m-tiles of dW: wave w = (m-slot w % KC, k-slot w / KC) accumulates a 2 x KC block of 16x16 tiles;
 //   * produce stage: wave w builds ring slot w of the NEXT row tile -- loads the S pre-activation blocks of its
 //     k-tile, applies the activation jet ONCE for the whole workgroup, and writes them transposed (padded
-//     feature-major LDS blocks, conflict-free b32 writes / b128 reads); for the first hidden layer the activated
-//     input is instead regenerated from the raw input directly in the row-major image (operands swapped);
+//     feature-major LDS blocks); for the first hidden layer the value stream of the pre-activations comes from the z0
+//     stash the forward kernel wrote and the tangent streams are the constant columns W0[:, d];
 //   * consume stage: every wave reads the ring slots of its k-slot and runs 2*KC*4*S MFMAs against its own abar
 //     blocks (transposed once per tile through a private patch);
 //   * double-buffered ring, one barrier per row tile; partial sums are merged with fp32 atomics at the end.
