@@ -17,6 +17,8 @@
 //   * double-buffered ring, one barrier per row tile; partial sums are merged with fp32 atomics at the end.
 // Block order is XCD-aware (all k-groups of a tile range share one XCD's L2).
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 struct WgradArgs {
@@ -31,6 +33,11 @@ struct WgradArgs {
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
   int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
+  int xfold;           // fp32 hidden-group launches: the (k-group, k-slot) pairs 0 .. XT-1 also contract their abar blocks with
+                       // raw-input tile 0 .. XT-1 (one extra 16x16 tile per wave, the XR fragment straight from memory), and all
+                       // of them keep the row sums of the tangent-stream adjoints (the tangent "input" of a skip connection is the
+                       // unit vector e_d): no separate launch for the three raw-input k-tiles, which re-read and re-transposed every
+                       // abar block of the layer for 3 / 35 of the MFMA work (9.3 + 5.9 ms per step for layers 1 and 2)
   stpde_jet_cfg cfg;
 };
 
@@ -240,12 +247,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   const int stride = a.gx;
   int tile = bx;
   f32x4 pa[S][MCW];
+  // folded raw-input tile (xfold): slot index of this wave, its accumulators, the XR fragment of the current tile
+  constexpr bool XF = !HASX && !BF;
+  const int xslot = (kz - a.kz0) * (NW / NM) + ks;
+  const int xsel = xslot < XT ? xslot : XT - 1;
+  f32x4 accx[XF ? MCW : 1];
+  float acct[XF && S1 == 3 ? 3 : 1][XF ? MCW : 1];
+  f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (XF) {
+#pragma unroll
+    for (int mi = 0; mi < MCW; ++mi) accx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (S1 == 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) acct[d][mi] = 0.f;
+    }
+  }
   if (tile < a.ntiles) {
     f32x4 raw[S][MCW];
     produce(tile, 0);
     load_p_raw(tile, raw);
     transpose_p(raw, pa);
     pack_p(raw);
+    if constexpr (XF) {
+      if (a.xfold) xr = ld4(a.XR + ((size_t)tile * XT + xsel) * 256 + lo);
+    }
   }
   __syncthreads();
   int buf = 0;
@@ -254,6 +281,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     const int nx = next < a.ntiles ? next : tile;   // branch-free tail: the last iteration re-produces its own tile
     f32x4 raw[S][MCW];
     load_p_raw(nx, raw);                           // lands while the MFMAs below run
+    f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (XF) {
+      // branch-free: without xfold the pointer is this launch's own XR anyway and the results are simply not written
+      xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accx[mi] = mfma4(pa[0][mi][r], xr[r], accx[mi]);
+      if constexpr (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi)
+            acct[d][mi] += (pa[1 + d][mi][0] + pa[1 + d][mi][1]) + (pa[1 + d][mi][2] + pa[1 + d][mi][3]);
+      }
+    }
     if constexpr (SPLP && !HASX && KC % 2 == 0) {
       // split mode, hidden k-tiles: two k-tiles at a time and the six partial products outermost, so that consecutive
       // MFMAs go to 2 x MCW different accumulators (six back-to-back MFMAs into ONE accumulator stall on each other)
@@ -346,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       }
     }
     }
+    if constexpr (XF) xr = xrn;
     if (NBUF == 2) {
       if (STPDE_ABLATE_W != 3) produce(nx, buf ^ 1);
       if (STPDE_ABLATE_W != 2) {
@@ -375,6 +419,31 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * kq + c, acc[mi][ki][r]);
+    }
+  }
+  if constexpr (XF) {
+    if (a.xfold && xslot < XT) {
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) {
+        const int mt = mt0 + mi;
+        if (mt >= MT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r]);
+        if constexpr (S1 == 3) {
+          if (xslot == 0) {
+            // column d of the raw-input block: sum over all rows of the tangent-stream adjoint d (lane (g, c) holds the rows
+            // 4g..4g+3 of output feature c: fold the four lane groups, lanes of group 0 add)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              float v = acct[d][mi];
+              v += __shfl_xor(v, 16, 64);
+              v += __shfl_xor(v, 32, 64);
+              if (g == 0) atomicAdd(a.dW + (size_t)(16 * mt + c) * ldw + 16 * KT + d, v);
+            }
+          }
+        }
+      }
     }
   }
 }
@@ -524,10 +593,16 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   a.gy = (a.MT + 2 * KC - 1) / (2 * KC);    // groups of 2*KC output tiles
   const int ngr = (a.KT + XT + 7) / 8;      // k-groups (ring = 8 k-tiles)
   const int nhid = a.KT / 8;                // groups made of hidden tiles only
+  // fp32, every hidden k-tile in a full group and enough (k-group, k-slot) pairs for the XT raw-input tiles: those are folded
+  // into the hidden-group launch and the second launch is dropped (STPDE_WGRAD_XFOLD=0: two launches)
+  static const int xfold_env = getenv("STPDE_WGRAD_XFOLD") ? atoi(getenv("STPDE_WGRAD_XFOLD")) : 1;
+  const int kslots = 8 / KC;                 // k-slots per workgroup (NW / NM)
+  const bool xfold = xfold_env && !a.bf16 && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
   for (int part = 0; part < 2; ++part) {
     a.kz0 = part == 0 ? 0 : nhid;
     a.gz = part == 0 ? nhid : ngr - nhid;
-    if (a.gz <= 0) continue;
+    a.xfold = (xfold && part == 0) ? 1 : 0;
+    if (a.gz <= 0 || (xfold && part == 1)) continue;
     int gx = 512 / (a.gy * a.gz);           // ~2 rounds of one 8-wave workgroup per CU
     if (gx > a.ntiles) gx = a.ntiles;
     gx = (gx + 7) / 8 * 8;

@@ -46,9 +46,11 @@ def _assert_benchmarked_kernels(tr, act):
     assert tr.has("k_layer_coop", "1, true>)", cfg, "MCg = 4", "PRO = 0", "EPI = 1"), dump
     # layer-2 forward (activation-jet prologue)
     assert tr.has("k_layer_coop", cfg, "PRO = 1", "EPI = 0"), dump
-    # weight gradients: first hidden layer (MODE = 1, KC = 8: hidden-only and raw-input launches), layer 2 (MODE 0, KC 4)
+    # weight gradients: first hidden layer (MODE = 1, KC = 8) and layer 2 (MODE 0, KC 4): ONE launch each -- the raw-input
+    # k-tiles are folded into the hidden k-groups (no HASX = true launch for this stream set any more; the value-stream
+    # launch of layer 0, S1 = S2 = 0, is the only raw-input-only one left)
     assert tr.has("k_wgrad_coop", "false>)", cfg, "MODE = 1", "KC = 8"), dump
-    assert tr.has("k_wgrad_coop", "true>)", cfg, "MODE = 1", "KC = 8"), dump
+    assert not tr.has("k_wgrad_coop", "true>)", cfg), dump
     assert tr.has("k_wgrad_coop", cfg, "MODE = 0", "KC = 4"), dump
     assert tr.has("k_wgrad_wave", cfg), dump
     assert tr.has("k_gather") and tr.has("k_xbar") and tr.has("k_reduce_bwd"), dump
