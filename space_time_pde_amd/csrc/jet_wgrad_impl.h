@@ -474,6 +474,11 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
 #pragma unroll
     for (int ki = 0; ki < NK; ++ki) acc[mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float acct[S1 == 3 ? 3 : 1][MCW];
+#pragma unroll
+  for (int d = 0; d < (S1 == 3 ? 3 : 1); ++d)
+#pragma unroll
+    for (int mi = 0; mi < MCW; ++mi) acct[d][mi] = 0.f;
   int flip = 0;
   auto transpose = [&](f32x4 v) -> f32x4 {   // column-major image -> row-major image (alternating patches)
     float* patch = pp[wv][flip];
@@ -528,16 +533,16 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
       for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mi][KTT + xt] = mfma4(pa[0][mi][r], xr[r], acc[mi][KTT + xt]);
-      if (S1 == 3 && xt == 0) {
+    }
+    if (S1 == 3) {
+      // tangent stream d of a skip connection sees the unit vector e_d: its contribution to column d of the raw-input block
+      // is the sum over rows of the adjoint -- per-lane partial sums here, folded once at the end (12 VALU instead of the 24
+      // MFMAs against unit vectors of the first version)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const float u = c == d ? 1.f : 0.f;     // tangent stream d sees the unit vector e_d
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-          for (int mi = 0; mi < MCW; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mi][KTT] = mfma4(pa[1 + d][mi][r], u, acc[mi][KTT]);
-        }
-      }
+        for (int mi = 0; mi < MCW; ++mi)
+          acct[d][mi] += (pa[1 + d][mi][0] + pa[1 + d][mi][1]) + (pa[1 + d][mi][2] + pa[1 + d][mi][3]);
     }
   }
 
@@ -556,6 +561,22 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
       const float sum = (red[lo + wv] + red[256 + lo + wv]) + (red[512 + lo + wv] + red[768 + lo + wv]);
       atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + wv) * ldw + 16 * ki + c, sum);
     }
+  if constexpr (S1 == 3) {
+    // tangent columns: lane (g, c) holds the partial row sums (rows 4g..4g+3 of every tile this wave walked) of output
+    // feature c; fold the four lane groups, then one atomic per wave, feature and d
+#pragma unroll
+    for (int mi = 0; mi < MCW; ++mi) {
+      const int mt = mt0 + mi;
+      if (mt >= MT) continue;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float v = acct[d][mi];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) atomicAdd(a.dW + (size_t)(16 * mt + c) * ldw + 16 * KTT + d, v);
+      }
+    }
+  }
 }
 
 template <int S1, int S2, int ACT, int MCW, int KTT>
