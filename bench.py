@@ -121,8 +121,8 @@ def cpu_baseline(act, chunk=4096, nchunks=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1 << 20)
     ap.add_argument("--act", default="softplus", help="softplus = reference run_experiment.sh:16; leakyrelu = module default")
     ap.add_argument("--chunk", type=int, default=1 << 20, help="points per launch chunk")
