@@ -249,28 +249,50 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   f32x4 pa[S][MCW];
   // folded raw-input tile (xfold): slot index of this wave, its accumulators, the XR fragment of the current tile
   constexpr bool XF = !HASX && !BF;
+  // the plain bf16 mode folds the same way (XB): the value product as ONE bf16 MFMA per output tile (raw-input fragment rounded
+  // to bf16 like every operand of the mode, the second stream slot of the MFMA zero), the tangent columns as fp32 sums of the
+  // column-major abar blocks (per lane and feature over all tiles; folded over the 16 rows at the end).  Not the split mode:
+  // its kernel has no registers left (248 VGPRs).
+  constexpr bool XB = !HASX && BF && SPL == 1;
   const int xslot = (kz - a.kz0) * (NW / NM) + ks;
   const int xsel = xslot < XT ? xslot : XT - 1;
-  f32x4 accx[XF ? MCW : 1];
+  f32x4 accx[(XF || XB) ? MCW : 1];
   float acct[XF && S1 == 3 ? 3 : 1][XF ? MCW : 1];
+  f32x4 acctb[XB && S1 == 3 ? 3 : 1][XB ? MCW : 1];
   f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (XF) {
+  if constexpr (XF || XB) {
 #pragma unroll
     for (int mi = 0; mi < MCW; ++mi) accx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (S1 == 3) {
+  }
+  if constexpr (XF && S1 == 3) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) acct[d][mi] = 0.f;
+  }
+  if constexpr (XB && S1 == 3) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // XB: every tile's column-major abar blocks are added exactly once (the last iteration re-loads its own tile: weight 0)
+  auto tangent_sums_b = [&](f32x4 (*raw_)[MCW], float wgt) {
+    if constexpr (XB && S1 == 3) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi) acct[d][mi] = 0.f;
+        for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] += wgt * raw_[1 + d][mi];
     }
-  }
+  };
   if (tile < a.ntiles) {
     f32x4 raw[S][MCW];
     produce(tile, 0);
     load_p_raw(tile, raw);
     transpose_p(raw, pa);
     pack_p(raw);
-    if constexpr (XF) {
+    tangent_sums_b(raw, 1.f);
+    if constexpr (XF || XB) {
       if (a.xfold) xr = ld4(a.XR + ((size_t)tile * XT + xsel) * 256 + lo);
     }
   }
@@ -282,6 +304,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     f32x4 raw[S][MCW];
     load_p_raw(nx, raw);                           // lands while the MFMAs below run
     f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (XB) {
+      xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
+      const bf16x8 x8 = cat8(to_bf4(xr), zero4);
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[0][0][mi], x8, accx[mi]);
+    }
     if constexpr (XF) {
       // branch-free: without xfold the pointer is this launch's own XR anyway and the results are simply not written
       xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
@@ -389,7 +417,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       }
     }
     }
-    if constexpr (XF) xr = xrn;
+    if constexpr (XF || XB) xr = xrn;
+    tangent_sums_b(raw, next < a.ntiles ? 1.f : 0.f);
     if (NBUF == 2) {
       if (STPDE_ABLATE_W != 3) produce(nx, buf ^ 1);
       if (STPDE_ABLATE_W != 2) {
@@ -419,6 +448,30 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * kq + c, acc[mi][ki][r]);
+    }
+  }
+  if constexpr (XB) {
+    if (a.xfold && xslot < XT) {
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) {
+        const int mt = mt0 + mi;
+        if (mt >= MT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r]);
+        if constexpr (S1 == 3) {
+          if (xslot == 0) {
+            // column-major partial sums: lane (g, j) holds features 4g..4g+3 summed over the tiles' row j; fold the 16 rows
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = row_sum16(acctb[d][mi][r]);
+                if (c == 15) atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * KT + d, v);
+              }
+          }
+        }
+      }
     }
   }
   if constexpr (XF) {
@@ -618,7 +671,7 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   // into the hidden-group launch and the second launch is dropped (STPDE_WGRAD_XFOLD=0: two launches)
   static const int xfold_env = getenv("STPDE_WGRAD_XFOLD") ? atoi(getenv("STPDE_WGRAD_XFOLD")) : 1;
   const int kslots = 8 / KC;                 // k-slots per workgroup (NW / NM)
-  const bool xfold = xfold_env && !a.bf16 && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
+  const bool xfold = xfold_env && (!a.bf16 || (a.bf16 == 1 && KC >= 4)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
   for (int part = 0; part < 2; ++part) {
     a.kz0 = part == 0 ? 0 : nhid;
     a.gz = part == 0 ? nhid : ngr - nhid;
