@@ -212,6 +212,9 @@ def main():
     # timed region: exactly `steps` steps between two barrier + synchronize brackets; nothing but one pair of HIP events
     # per step (on torch's current stream = the stream every kernel of the step is launched on) is recorded inside it
     sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()          # no cyclic-garbage pause of the host interpreter inside the timed region (re-enabled right after it)
     t0 = time.perf_counter()
     for k in range(args.steps):
         sev[k][0].record()
@@ -219,6 +222,7 @@ def main():
         sev[k][1].record()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     step_ms_seq = [a.elapsed_time(b) for a, b in sev]
     step_ms = sorted(step_ms_seq)
     step_ms_median = step_ms[len(step_ms) // 2]
