@@ -366,7 +366,10 @@ struct XbarArgs {
 };
 
 constexpr int XPAD = 49;   // padded row length (floats) of the 16 x 48 transpose patch: odd -> conflict-free columns
-constexpr int XR = 4;      // row tiles per wave: every weight fragment fetched from L2 feeds XR * XL * 4 MFMAs
+#ifndef STPDE_XBAR_R
+#define STPDE_XBAR_R 4
+#endif
+constexpr int XR = STPDE_XBAR_R;      // row tiles per wave: every weight fragment fetched from L2 feeds XR * XL * 4 MFMAs
 
 // XL = number of 16-channel output tiles (C <= 16 XL).  The coordinate / bias columns of the augmented input get no
 // adjoint (query points carry no gradient), so only the latent channels are contracted.  Round 2: one row tile per wave
