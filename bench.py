@@ -1,6 +1,10 @@
 """Hot-path benchmark: query-points/sec of one MeshfreeFlowNet training step (fwd + PDE residuals + bwd).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under ``python -m torch.distributed.run`` (RANK / WORLD_SIZE in the environment) every
+process is one rank; a plain ``python bench.py --gpus N`` spawns its N ranks itself (torch.multiprocessing.spawn on
+127.0.0.1, as the reference's experiments/rb2d/train_ddp.py:483-494 does) -- both routes run the same ``main``.
 
 A "step" is one pass of the hot path over one batch of synthetic input (experiments/rb2d/train.py:58-77 of the
 reference): UNet3d encoder -> latent grid -> local-implicit-grid gather -> IM-NET on every query point with the RB2
@@ -74,13 +78,14 @@ def make_inputs(n_pts, dev, seed=0, igres=(32, 128, 128)):
     return crop, pts, tgt
 
 
-def cpu_baseline(act, chunk=4096, nchunks=3):
-    """Time the CPU oracle (restatement of the reference's 25-reverse-sweep path) on a bounded sample (~30 s).
+def cpu_baseline(act, chunk=1024, nchunks=16):
+    """Time the CPU oracle (restatement of the reference's 25-reverse-sweep path) on a bounded sample (~40 s).
 
+    Sample: 16 chunks of 1024 points = the reference's own unit of work (train.py:230 n_samp_pts_per_crop and
+    :245 pseudo_batch_size default to 1024), plus ONE chunk of 4096 points for continuity with the rounds-1/2 figure.
     The host may have far more cores than the op-level parallelism of this graph can use (128 threads ran 7x slower
-    than 16 on the GPU box), so the thread count is calibrated on a small chunk first and reported as ``cores``; one
-    more chunk is timed with 8 threads for comparability with the build-container figures (BASELINE.md section 2, and
-    profiles/r2_cpu_ref_vs_port.json: the restatement takes the same time as the imported reference there).
+    than 16 on the GPU box), so the thread count is calibrated on a chunk first and reported as ``cores``
+    (profiles/r2_cpu_ref_vs_port.json: the restatement takes 1.12-1.30x the time of the imported reference).
     """
     from oracle import cpu_ref
     g = torch.Generator().manual_seed(0)
@@ -100,25 +105,43 @@ def cpu_baseline(act, chunk=4096, nchunks=3):
     run(256)                                   # warm-up (sympy lambdify, allocator)
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32)}):
         torch.set_num_threads(nt)
-        t = run(1024)
+        t = run(chunk)
         if t < best_t:
             best, best_t = nt, t
     torch.set_num_threads(best)
     times = sorted(run(chunk) for _ in range(nchunks))
-    med = times[len(times) // 2]
-    t8 = med
-    if best != 8:
-        torch.set_num_threads(min(8, ncpu))
-        t8 = run(chunk)
-    return dict(value=chunk / med, unit="query-points/s", cores=best, kind="port", value_8_threads=chunk / t8,
-                sample="%d chunks of %d points over the same [1,32,128,128,32] latent grid (UNet excluded: <1%% of the "
-                       "work), %s, %d threads (best of 8/16/32 on this host, %d logical CPUs), median chunk %.2f s "
-                       "(+1 chunk at 8 threads: %.2f s); the reference path cannot hold 2^20 points at once and "
-                       "pseudo-batches (evaluation.py:54-60)"
-                       % (nchunks, chunk, act, best, ncpu, med, t8))
+    total = sum(times)
+    t4k = run(4096)
+    return dict(value=nchunks * chunk / total, unit="query-points/s", cores=best, kind="port",
+                value_chunk4096=4096 / t4k,
+                sample="%d chunks of %d points (the reference's default points per crop, train.py:230) over the same "
+                       "[1,32,128,128,32] latent grid (UNet excluded: <1%% of the work), %s, %d threads (best of 8/16/32 on "
+                       "this host, %d logical CPUs), %.1f s in total, chunk min / median / max %.2f / %.2f / %.2f s; one "
+                       "4096-point chunk: %.2f s; the reference path cannot hold 2^20 points at once and pseudo-batches "
+                       "(evaluation.py:54-60)"
+                       % (nchunks, chunk, act, best, ncpu, total, times[0], times[len(times) // 2], times[-1], t4k))
 
 
-def main():
+def _spawn_rank(rank, world, port, argv):
+    """One self-spawned rank: the environment torch.distributed.run would have set, then the ordinary main()."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    main(argv)
+
+
+def self_spawn(world, argv):
+    """``python bench.py --gpus N`` without a launcher: spawn the N ranks (reference: train_ddp.py:491-494, mp.spawn)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_spawn_rank, args=(world, port, argv), nprocs=world, join=True)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -134,7 +157,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(args.gpus, list(sys.argv[1:] if argv is None else argv))
 
     # stdout carries exactly ONE line (the JSON record): libraries that print to file descriptor 1 (RCCL announces its
     # path there when the process group comes up) are sent to stderr until the record is written
@@ -145,9 +170,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                         % (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
     # test hooks for the 1-GPU box (never set by the driver): all ranks on device 0 / another backend than RCCL, so that
     # `--gpus 2` can be dry-run through gloo where RCCL would refuse two ranks on one device
     if os.environ.get("STPDE_BENCH_ONE_DEVICE") == "1":
@@ -356,6 +380,8 @@ def main():
             "value": args.points * args.steps / dt,
             "unit": "query-points/s",
             "n_gpus": world,
+            "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
+            "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,

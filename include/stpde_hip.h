@@ -40,7 +40,7 @@ extern "C" {
 #define STPDE_ACT_SWISH 4
 #define STPDE_ACT_LEAKYRELU 5
 
-#define STPDE_XT 3 /* the augmented raw input [r(3) ; latent(c) ; 1 ; 0-pad] occupies 3 feature tiles: c <= 44 */
+#define STPDE_XT 3 /* the augmented raw input [r(3) ; latent(c) ; 1 ; 0-pad] occupies 3 feature tiles, the third one sparse (4 live slots): 3 + c + 1 <= 36, i.e. c <= 32 */
 #define STPDE_PBAR_SLOTS 64 /* accumulation slots of the swish-beta adjoint (stpde_jet_layer_bwd), summed by the caller */
 
 /* Derivative-stream configuration shared by the jet kernels. */

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
 _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
+ABI_VERSION = 300   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
 XT = 3
@@ -212,6 +214,10 @@ def lib():
                     fn = getattr(h, name)          # AttributeError if the symbol is missing
                     fn.argtypes = argtypes
                     fn.restype = restype
+                if h.stpde_version() != ABI_VERSION:
+                    raise RuntimeError("libstpde_hip.so at %s has ABI version %d, this package needs %d: rebuild it "
+                                       "(python -c 'import __graft_entry__ as g; g.build()')"
+                                       % (LIB_PATH, h.stpde_version(), ABI_VERSION))
                 _lib = h
     return _lib
 

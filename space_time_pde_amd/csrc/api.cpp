@@ -28,7 +28,8 @@ int stpde_check_launch(const char* what) {
   return STPDE_OK;
 }
 
-extern "C" int stpde_version(void) { return 100; }
+// ABI version: bumped whenever a descriptor or a signature of include/stpde_hip.h changes (_lib.ABI_VERSION must match)
+extern "C" int stpde_version(void) { return 300; }
 
 extern "C" int stpde_last_error(char* buf, unsigned long n) {
   if (!buf || n == 0) return STPDE_E_BADARG;

@@ -220,7 +220,13 @@ class RB2DataLoader(torch.utils.data.Dataset):
     (the HIP interpolation kernel) and returned as float32 tensors there, so the feeder never touches scipy.
 
     ``numpy_rng=True`` draws the sample points with ``np.random.rand`` exactly like the reference (:153), so a seeded
-    numpy stream reproduces the reference's samples; the default draws them on the device."""
+    numpy stream reproduces the reference's samples; the default draws them on the device.
+
+    ``device=None`` (default) keeps the Dataset on the HOST like the reference's: it then works unchanged under the
+    reference's ``DataLoader(..., num_workers=1, pin_memory=True)`` (experiments/rb2d/train.py:318-321; forked workers
+    must not touch the GPU and pin_memory rejects device tensors).  ``device="cuda"`` opts into the on-device pipeline:
+    use it with ``num_workers=0, pin_memory=False`` (``__getitem__`` raises inside a worker process), or call
+    ``RB2DeviceLoader.get`` directly for whole batches."""
 
     def __init__(self, data_dir="./", data_filename="./data/rb2d_ra1e6_s42.npz", nx=128, nz=128, nt=16,
                  n_samp_pts_per_crop=1024, downsamp_xz=4, downsamp_t=4, normalize_output=False, normalize_hres=False,
@@ -228,7 +234,8 @@ class RB2DataLoader(torch.utils.data.Dataset):
         self.data_dir, self.data_filename = data_dir, data_filename
         self.normalize_hres, self.return_hres, self.numpy_rng = normalize_hres, return_hres, numpy_rng
         if device is None:
-            device = "cuda" if torch.cuda.is_available() else "cpu"
+            device = "cpu"
+        self._on_device = torch.device(device).type != "cpu"
         self._impl = RB2DeviceLoader(os.path.join(data_dir, data_filename), nx=nx, nz=nz, nt=nt,
                                      n_samp_pts_per_crop=n_samp_pts_per_crop, downsamp_xz=downsamp_xz,
                                      downsamp_t=downsamp_t, normalize_output=normalize_output, device=device,
@@ -242,6 +249,10 @@ class RB2DataLoader(torch.utils.data.Dataset):
         return len(self._impl)
 
     def __getitem__(self, idx):
+        if self._on_device and torch.utils.data.get_worker_info() is not None:
+            raise RuntimeError("RB2DataLoader(device=%r) cannot be used from DataLoader worker processes: pass "
+                               "num_workers=0, pin_memory=False, or keep the dataset on the host (device=None)"
+                               % (str(self._impl.data.device),))
         pc = None
         if self.numpy_rng:
             pc = torch.from_numpy(np.random.rand(self.n_samp_pts_per_crop, 3).astype(np.float32))[None]

@@ -16,7 +16,10 @@ from . import regular_nd_grid_interpolation as rgi
 from .implicit_net import ImNet
 
 _tls = threading.local()
-stats = {"hip_jet_calls": 0, "hip_value_calls": 0, "generic_calls": 0}
+stats = {"hip_jet_calls": 0, "hip_value_calls": 0, "generic_calls": 0,
+         # slower-strategy counters of pde.py (each also warns once): sympy analysis failures and residuals evaluated with
+         # the lambdified torch functions instead of the HIP residual program
+         "combo_plan_errors": 0, "jet_compile_errors": 0, "residual_torch_fallbacks": 0}
 
 
 class JetRequest:
@@ -48,7 +51,7 @@ def _fast_eligible(model, latent_grid, query_pts):
     return (isinstance(model, ImNet) and model.dim == 3 and latent_grid.dim() == 5 and query_pts.dim() == 3
             and query_pts.shape[-1] == 3 and latent_grid.is_cuda and query_pts.is_cuda
             and latent_grid.dtype == torch.float32 and query_pts.dtype == torch.float32
-            and model.nf % 16 == 0 and model.out_features <= 16 and model.in_features <= 44
+            and model.nf % 16 == 0 and model.out_features <= 16 and model.in_features <= lig_jet.MAX_LATENT_CHANNELS
             and latent_grid.shape[-1] == model.in_features
             and lig_jet.activation_name(model.activ) is not None)
 

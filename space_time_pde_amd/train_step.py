@@ -93,9 +93,21 @@ def sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if loss_type not in _LOSS_SUMS:
         raise KeyError(loss_type)
-    if hasattr(unet, "deferred_weight_grads"):
-        # this step calls loss.backward(): the U-Net's weight gradients may run beside its input-gradient chain
+    # this step calls loss.backward() itself, so the U-Net's weight gradients may run beside its input-gradient chain
+    # (unet3d._DeferredGrads, opt-in); the caller's setting of the flag is restored when the step is over
+    prev_deferred = getattr(unet, "deferred_weight_grads", None)
+    if prev_deferred is not None:
         unet.deferred_weight_grads = os.environ.get("STPDE_UNET_DEFERRED", "1") != "0"
+    try:
+        return _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n_points_global, alpha_reg,
+                             alpha_pde, loss_type, xmin, xmax, distributed, sync_unet_grads)
+    finally:
+        if prev_deferred is not None:
+            unet.deferred_weight_grads = prev_deferred
+
+
+def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, n_points_global, alpha_reg, alpha_pde,
+                  loss_type, xmin, xmax, distributed, sync_unet_grads):
     latent_grid = unet(input_grid).permute(0, 2, 3, 4, 1)            # train.py:58-60
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)

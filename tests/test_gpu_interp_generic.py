@@ -145,12 +145,15 @@ def test_large_size_properties(hiplib):
     assert torch.isfinite(a).all()
 
 
-def test_full_size_step_subset_vs_oracle_and_additivity(hiplib):
-    """BASELINE configs[1] size (latent [1,32,128,128,32], 2^20 points, RB2 + continuity, softplus):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "bf16"])
+def test_full_size_step_subset_vs_oracle_and_additivity(hiplib, prec, monkeypatch):
+    """(parametrised over the three MFMA operand modes, VERDICT r2 #3b: fp32x3 with the fp32 tolerances, bf16 with the
+    mode's 3e-2 Frobenius bound.)  BASELINE configs[1] size (latent [1,32,128,128,32], 2^20 points, RB2 + continuity, softplus):
     (a) points are independent, so pred / residuals of a random subset must equal the CPU oracle run on just that subset;
     (b) gradients are additive over points: grads(all points) == grads(first half) + grads(second half)."""
     from oracle import cpu_ref
-    from space_time_pde_amd import implicit_net, local_implicit_grid as lig, physics
+    from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, physics
+    monkeypatch.setattr(lig_jet, "mlp_precision", prec)
     g = torch.Generator().manual_seed(0)
     N = 1 << 20
     lat0 = (0.5 * torch.randn(1, 32, 128, 128, 32, generator=g))
@@ -178,11 +181,20 @@ def test_full_size_step_subset_vs_oracle_and_additivity(hiplib):
     params = [(net.fc[k].weight.detach().cpu(), net.fc[k].bias.detach().cpu()) for k in range(6)]
     ref = cpu_ref.lig_pde_step(params, "softplus", lat0, pts[:, sel], torch.zeros(1, 1024, 4), cpu_ref.rb2_oracle(**kw),
                                backward=False)
-    assert (pred[:, sel].cpu() - ref["pred"]).abs().max().item() < 2e-5 * ref["pred"].abs().max().item()
+    if prec == "bf16":
+        def nrm(a, b):
+            return (a.double() - b.double()).norm().item() / b.double().norm().item()
+        assert nrm(pred[:, sel].cpu(), ref["pred"]) < 3e-2
+        for k, v in ref["residues"].items():
+            assert nrm(res[k][:, sel].cpu(), v) < 3e-2, k
+    else:
+        assert (pred[:, sel].cpu() - ref["pred"]).abs().max().item() < 2e-5 * ref["pred"].abs().max().item()
     # second derivatives carry 1/cubesize^2 = 127^2: the fp32 reference path itself is only good to ~2e-4 of the
     # residual scale per point here (SURVEY a-Q8: fp32 vs fp64 of the reference, max-rel 1.7e-4), so: tight in the
     # bulk, bounded in the tail
     for k, v in ref["residues"].items():
+        if prec == "bf16":
+            break
         err = (res[k][:, sel].cpu() - v).abs() / v.abs().max()
         assert err.median().item() < 1e-5 and err.max().item() < 1e-3, (k, err.max().item())
     # (b) additivity of the gradients over the two halves

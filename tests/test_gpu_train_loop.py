@@ -126,3 +126,32 @@ def test_two_ranks_on_one_gpu_gloo_step_equals_single_rank(hiplib, tmp_path):
     out = str(tmp_path / "rank0_gloo.pt")
     mp.spawn(_rccl_worker, args=(2, port, out, "gloo", True), nprocs=2, join=True)
     _compare_with_single_device(torch.load(out))
+
+
+@pytest.mark.gpu
+def test_bench_self_spawns_two_ranks(hiplib):
+    """``python bench.py --gpus 2`` with NO launcher around it spawns its two ranks itself (as the reference's
+    train_ddp.py:491-494 does) and rank 0 prints the one JSON line.  On a box with >= 2 devices this is RCCL with two
+    ranks; on the 1-GPU test box the documented hook puts both ranks on cuda:0 over gloo (RCCL refuses two ranks per
+    device) -- same spawn code, same sharded step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    multi = torch.cuda.device_count() >= 2
+    if not multi:
+        env.update(STPDE_BENCH_ONE_DEVICE="1", STPDE_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--points", "32768", "--igres", "8", "32", "32", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_world"] == 2 and rec["steps"] == 2
+    assert rec["dist_backend"] == ("nccl" if multi else "gloo")
+    assert rec["value"] > 0 and rec["config"]["parallelism"] == "points sharded x2"

@@ -168,6 +168,22 @@ def test_dataloader_matches_reference_on_cpu(golden_dir, tmp_path):
     run_dataloader_fixture(golden_dir, tmp_path, "cpu")
 
 
+def test_dataset_works_under_the_reference_dataloader_settings(tmp_path):
+    """the drop-in Dataset must survive the reference's own DataLoader settings
+    (experiments/rb2d/train.py:318-321: worker processes, pin_memory on CUDA hosts): default device = host tensors."""
+    from space_time_pde_amd import dataloader_spacetime as dl
+    rng = np.random.default_rng(3)
+    np.savez(os.path.join(tmp_path, "synth.npz"),
+             **{k: rng.standard_normal((12, 24, 24)).astype(np.float32) for k in ("p", "b", "u", "w")})
+    ds = dl.RB2DataLoader(str(tmp_path), "synth.npz", nx=16, nz=16, nt=8, n_samp_pts_per_crop=32, downsamp_xz=4,
+                          downsamp_t=2)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, drop_last=True, num_workers=1,
+                                         pin_memory=torch.cuda.is_available())
+    lres, pc, pv = next(iter(loader))
+    assert lres.shape == (2, 4, 4, 4, 4) and pc.shape == (2, 32, 3) and pv.shape == (2, 32, 4)
+    assert lres.device.type == "cpu" and torch.isfinite(pv).all()
+
+
 def run_dataloader_fixture(golden_dir, tmp_path, device):
     from space_time_pde_amd import dataloader_spacetime as dl
     d = np.load(os.path.join(golden_dir, "n3_dataloader.npz"))
