@@ -209,6 +209,74 @@ int stpde_lig_xbar_rows(const stpde_xbar_desc* d, const float* const* abar, cons
 int stpde_lig_dlatent_reduce(int B, int n0, int n1, int n2, int C, const float* xrows, const int* perm,
                              const int* start, float* dlatent, void* stream);
 
+/* ---- a4/a5/a7 in ONE call per direction (lig_imnet_jet_fwd / lig_imnet_jet_bwd) ---------------------
+ * The whole query path of src/local_implicit_grid.py:47-59 (gather -> IM-NET on all derivative streams -> corner-weighted
+ * sum) for one chunk of query points, and its backward (what loss.backward(), experiments/rb2d/train.py:77, does through
+ * it: weight gradients of fc0..fc5, latent-grid gradient).  Launch sequencing only: the kernels are the ones behind the
+ * per-layer entry points above, issued in the same order; the per-layer entry points stay exported (profiling, tests).
+ * All buffers are the caller's (stpde_lig_workspace); sizes in floats for a chunk of P points, nt = P / 2 row tiles,
+ * S = 1 + S1 + S2 streams of cfg_mlp, block = 256 floats:
+ *   X, XR [nt][3][block]   coef [P][16]   cw [P][8] (combined stream only, else NULL)   cell [P] int
+ *   pre[0] = z0 stash [nt][MT_0][block] (training only)      pre[l], l >= 1: [nt][S][MT_l][block]
+ *   backward scratch: abar2x / abar3x = sizes of pre[2] / pre[3] (fresh adjoint buffers of the fused tail), tan0
+ *   [nt][MT_0][48], abar0 [nt][1 + S1][MT_0][block] (only when tan0 is NULL and S1 == 3), xrows [16 nt][CP], perm [P],
+ *   start [n_nodes + 1], sort_tmp (stpde_lig_sort_tmp_bytes). */
+typedef struct {
+  int nlayers;                 /* 6: fc0 .. fc5 of src/implicit_net.py:31-36 */
+  int cin, cout, nf16;         /* latent channels, outputs, nf / 16 */
+  int KT[8], MT[8];            /* hidden k-tiles / output tiles of each layer */
+  const float* Wh[8];          /* A-operand packs (see stpde_jet_layer_fwd); Wh[0] / WhT[0] unused */
+  const float* WhT[8];
+  const float* Ws[8];
+  const float* WsL[8];
+  const float* tanc[8];
+  const void* Wh16[8];         /* bf16 packs of the wide layers or NULL */
+  const void* WhT16[8];
+  int mfma_bf16;               /* 0 / 1 / 3 as stpde_layer_desc.mfma_bf16 */
+  long dw_off[8];              /* offset (floats) of layer l's dW_aug block [16 MT][16 (KT + 3)] in dW_flat */
+} stpde_imnet_plan;
+typedef struct {
+  float* X;
+  float* XR;
+  float* coef;
+  float* cw;
+  int* cell;
+  float* pre[8];
+  float* abar2x;
+  float* abar3x;
+  float* tan0;
+  float* abar0;
+  float* xrows;
+  int* perm;
+  int* start;
+  void* sort_tmp;
+  unsigned long sort_tmp_bytes;
+} stpde_lig_workspace;
+#define STPDE_F_STASH 1          /* forward: keep what the backward needs (XR, z0) */
+#define STPDE_F_VALUE_TILES 2    /* forward-only value queries: four row tiles per pass over the weights */
+#define STPDE_F_FUSED_TAIL 4     /* fc3 -> fc4 -> fc5 in one kernel each way (nf = 16 / 32) */
+#define STPDE_F_TAN0_ROWSUM 8    /* backward: layer-0 tangent adjoints as per-tile row sums (needs workspace.tan0) */
+#define STPDE_F_DETERMINISTIC 16 /* backward: d latent by per-node sums in a fixed order instead of fp32 atomics */
+#define STPDE_F_WGRAD 32         /* backward: compute the weight gradients */
+#define STPDE_F_WGRAD_FP32 64    /* fp32x3 mode: keep the wide layers' weight gradients on the exact-fp32 MFMA */
+/* cfg_mlp = streams the layer kernels carry, cfg_out = streams of `jets` (they differ for piecewise-linear activations,
+ * see stpde_lig_reduce_fwd); jets points at the first point of the chunk inside [S_out][n_out][ldp]. */
+int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* plan, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,
+                            const stpde_gather_desc* gd, const float* pts, const float* latent,
+                            const stpde_lig_workspace* ws, float* jets, long ldp, int flags, void* stream);
+/* cfg_val = cfg_mlp with S1 = S2 = 0 (layer-0 weight gradient of the value stream).  dW_flat (zero-filled by the caller,
+ * accumulated into; may be NULL), dlatent (accumulated into; may be NULL), act_param_bar as stpde_jet_layer_bwd. */
+int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* plan, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,
+                            const stpde_jet_cfg* cfg_val, const stpde_gather_desc* gd, const stpde_lig_workspace* ws,
+                            const float* jets_bar, long ldp, float* dW_flat, float* dlatent, float* act_param_bar,
+                            int flags, void* stream);
+/* Cell sort of the deterministic d latent (replaces the torch.sort + index_add_ + cumsum of the round-2 host): perm [P] =
+ * point indices in stable cell order, start [n_nodes + 1] = number of points in cells < c; tmp = device scratch of at
+ * least stpde_lig_sort_tmp_bytes(P, n_nodes) bytes. */
+unsigned long stpde_lig_sort_tmp_bytes(int P, long n_nodes);
+int stpde_lig_cell_sort(int P, long n_nodes, const int* cell, int* perm, int* start, void* tmp, unsigned long tmp_bytes,
+                        void* stream);
+
 /* ---- a2/a3 for any dim 1..4: plain multilinear interpolation ---------------------------------------
  * Replaces regular_nd_grid_interpolation (src/regular_nd_grid_interpolation.py:81-104) and the three outputs
  * of ..._coefficients (:14-78).  grid [B][n_0..n_{dim-1}][C], pts [B*N][dim].  Any output pointer may be NULL. */

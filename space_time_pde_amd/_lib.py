@@ -12,10 +12,10 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
-ABI_VERSION = 300   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 301   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
@@ -41,6 +41,23 @@ class LayerDesc(C.Structure):
 class XbarDesc(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("nlayers", C.c_int), ("C", C.c_int), ("n1", C.c_int), ("n2", C.c_int),
                 ("MT", C.c_int * 8), ("SP", C.c_int * 8)]
+
+
+class ImNetPlanDesc(C.Structure):       # stpde_imnet_plan
+    _fields_ = [("nlayers", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("nf16", C.c_int), ("KT", C.c_int * 8),
+                ("MT", C.c_int * 8), ("Wh", C.c_void_p * 8), ("WhT", C.c_void_p * 8), ("Ws", C.c_void_p * 8),
+                ("WsL", C.c_void_p * 8), ("tanc", C.c_void_p * 8), ("Wh16", C.c_void_p * 8), ("WhT16", C.c_void_p * 8),
+                ("mfma_bf16", C.c_int), ("dw_off", C.c_long * 8)]
+
+
+class LigWorkspace(C.Structure):        # stpde_lig_workspace
+    _fields_ = [("X", C.c_void_p), ("XR", C.c_void_p), ("coef", C.c_void_p), ("cw", C.c_void_p), ("cell", C.c_void_p),
+                ("pre", C.c_void_p * 8), ("abar2x", C.c_void_p), ("abar3x", C.c_void_p), ("tan0", C.c_void_p),
+                ("abar0", C.c_void_p), ("xrows", C.c_void_p), ("perm", C.c_void_p), ("start", C.c_void_p),
+                ("sort_tmp", C.c_void_p), ("sort_tmp_bytes", C.c_ulong)]
+
+
+F_STASH, F_VALUE_TILES, F_FUSED_TAIL, F_TAN0_ROWSUM, F_DETERMINISTIC, F_WGRAD, F_WGRAD_FP32 = 1, 2, 4, 8, 16, 32, 64
 
 
 class Conv3dDesc(C.Structure):
@@ -170,6 +187,13 @@ _SIGNATURES = {
     "stpde_lig_xbar_scatter": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP], C.c_int),
     "stpde_lig_xbar_rows": ([C.POINTER(XbarDesc), C.POINTER(_VP), C.POINTER(_VP), _VP, _VP], C.c_int),
     "stpde_lig_dlatent_reduce": ([C.c_int] * 5 + [_VP] * 5, C.c_int),
+    "stpde_lig_imnet_jet_fwd": ([C.POINTER(ImNetPlanDesc), C.POINTER(JetCfg), C.POINTER(JetCfg), C.POINTER(GatherDesc), _VP,
+                                 _VP, C.POINTER(LigWorkspace), _VP, C.c_long, C.c_int, _VP], C.c_int),
+    "stpde_lig_imnet_jet_bwd": ([C.POINTER(ImNetPlanDesc), C.POINTER(JetCfg), C.POINTER(JetCfg), C.POINTER(JetCfg),
+                                 C.POINTER(GatherDesc), C.POINTER(LigWorkspace), _VP, C.c_long, _VP, _VP, _VP, C.c_int, _VP],
+                                C.c_int),
+    "stpde_lig_sort_tmp_bytes": ([C.c_int, C.c_long], C.c_ulong),
+    "stpde_lig_cell_sort": ([C.c_int, C.c_long, _VP, _VP, _VP, _VP, C.c_ulong, _VP], C.c_int),
     "stpde_interp_fwd": ([C.POINTER(InterpDesc)] + [_VP] * 7, C.c_int),
     "stpde_interp_bwd_grid": ([C.POINTER(InterpDesc)] + [_VP] * 5, C.c_int),
     "stpde_conv3d_fwd": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),

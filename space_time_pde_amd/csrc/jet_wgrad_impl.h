@@ -655,6 +655,11 @@ static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
     } else {
       if (a.KT == 2) return launch_wgrad_wave<S1, S2, ACT, 2, 2>(a, stream);
       if (a.KT == 4) return launch_wgrad_wave<S1, S2, ACT, 2, 4>(a, stream);
+      // fc3 of the reference net (4 output tiles, 8 hidden k-tiles): all four output tiles in ONE pass halves the stash reads
+      // of this HBM-bound kernel (the two-pass grid reads abar3 / pre2 twice: 11.4 -> 9.6 ms per step, 368 registers = one wave
+      // per SIMD); STPDE_WGRAD_MCW4=0: two passes
+      static const int mcw4 = getenv("STPDE_WGRAD_MCW4") ? atoi(getenv("STPDE_WGRAD_MCW4")) : 1;
+      if (a.KT == 8 && a.MT == 4 && mcw4) return launch_wgrad_wave<S1, S2, ACT, 4, 8>(a, stream);
       if (a.KT == 8) return launch_wgrad_wave<S1, S2, ACT, 2, 8>(a, stream);
     }
     return -1;

@@ -1,0 +1,238 @@
+// One call per direction for the whole query path (lig_imnet_jet_fwd / lig_imnet_jet_bwd):
+//   forward   gather -> fc1 (fc0 on the fly) -> fc2 -> fc3..fc5 (fused tail or per layer) -> corner reduction
+//   backward  corner-reduction adjoint -> weight gradients / input gradients fc5..fc1 -> fc0 weight gradient ->
+//             latent-gradient GEMM -> deterministic per-node sums (cell sort on the device) or fp32-atomic scatter
+// i.e. what src/local_implicit_grid.py:47-59 + src/implicit_net.py:48-54 + the reverse sweeps of src/pde.py:8-9 and
+// loss.backward() (experiments/rb2d/train.py:77) do for one chunk of query points.  Pure launch sequencing: every kernel is
+// the one behind the per-layer entry points of include/stpde_hip.h (same order as the Python host used to issue them), the
+// caller owns every buffer (stpde_lig_workspace), nothing is allocated or synchronised here.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace {
+
+struct Seq {                       // first error wins, later launches are skipped
+  int rc = STPDE_OK;
+  template <class F>
+  void operator()(F&& f) {
+    if (rc == STPDE_OK) rc = f();
+  }
+};
+
+stpde_layer_desc layer_desc(int ntiles, const stpde_imnet_plan* p, int l, const stpde_jet_cfg& cfg, int bf16) {
+  stpde_layer_desc d{};
+  d.ntiles = ntiles;
+  d.KT = p->KT[l];
+  d.MT = p->MT[l];
+  d.first_hidden = l == 1;
+  d.cfg = cfg;
+  d.mfma_bf16 = bf16;
+  return d;
+}
+
+bool tail_ok(const stpde_imnet_plan* p, const stpde_jet_cfg& c, const float* cw, bool value_tiles) {
+  if (p->nlayers != 6 || (p->nf16 != 1 && p->nf16 != 2)) return false;
+  if (value_tiles) return true;
+  const bool set = (c.S1 == 0 && c.S2 == 0) || (c.S1 == 3 && (c.S2 == 0 || c.S2 == 1 || c.S2 == 2));
+  return set && (c.S2 != 1 || cw);
+}
+
+__global__ __launch_bounds__(256) void k_cell_count(const int* cell, int P, int* counts) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < P) atomicAdd(counts + cell[p] + 1, 1);
+}
+__global__ __launch_bounds__(256) void k_iota(int* v, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+int key_bits(long n_nodes) {
+  int b = 1;
+  while ((1L << b) < n_nodes + 1) ++b;
+  return b;
+}
+
+}  // namespace
+
+// Scratch of stpde_lig_cell_sort for P points on a grid of n_nodes nodes: the radix sort's / scan's temporary storage plus
+// two key arrays, one value array and the histogram.
+extern "C" unsigned long stpde_lig_sort_tmp_bytes(int P, long n_nodes) {
+  if (P <= 0 || n_nodes <= 0) return 0;
+  size_t a = 0, b = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr, P, 0,
+                                     key_bits(n_nodes));
+  hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int*)nullptr, (int*)nullptr, (int)(n_nodes + 1));
+  const size_t t = (a > b ? a : b);
+  return (unsigned long)((t + 255) / 256 * 256 + 2 * (((size_t)P * 4 + 255) / 256 * 256));
+}
+
+// perm [P] = point indices in STABLE cell order (ties keep ascending point index: LSD radix sort), start [n_nodes + 1] =
+// number of points in cells < c.  Replaces torch.sort + index_add_ + cumsum of the round-2 host (rocprim / ATen kernels).
+extern "C" int stpde_lig_cell_sort(int P, long n_nodes, const int* cell, int* perm, int* start, void* tmp,
+                                   unsigned long tmp_bytes, void* stream) {
+  if (P <= 0 || n_nodes <= 0 || !cell || !perm || !start || !tmp || tmp_bytes < stpde_lig_sort_tmp_bytes(P, n_nodes)) {
+    stpde_set_error("lig_cell_sort: bad argument / scratch too small");
+    return STPDE_E_BADARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t arr = ((size_t)P * 4 + 255) / 256 * 256;
+  char* base = (char*)tmp;
+  int* keys_out = (int*)base;
+  int* iota = (int*)(base + arr);
+  void* cub = base + 2 * arr;
+  size_t cub_bytes = tmp_bytes - 2 * arr;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_iota, dim3((P + 255) / 256), dim3(256), 0, st, iota, P);
+  if (hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, cell, keys_out, (const int*)iota, perm, P, 0, key_bits(n_nodes), st) !=
+      hipSuccess) {
+    stpde_set_error("lig_cell_sort: radix sort failed");
+    return STPDE_E_LAUNCH;
+  }
+  if (hipMemsetAsync(start, 0, (size_t)(n_nodes + 1) * sizeof(int), st) != hipSuccess) return STPDE_E_LAUNCH;
+  hipLaunchKernelGGL(k_cell_count, dim3((P + 255) / 256), dim3(256), 0, st, cell, P, start);
+  cub_bytes = tmp_bytes - 2 * arr;
+  if (hipcub::DeviceScan::InclusiveSum(cub, cub_bytes, (const int*)start, start, (int)(n_nodes + 1), st) != hipSuccess) {
+    stpde_set_error("lig_cell_sort: scan failed");
+    return STPDE_E_LAUNCH;
+  }
+  return stpde_check_launch("lig_cell_sort");
+}
+
+extern "C" int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* p, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,
+                                       const stpde_gather_desc* gd, const float* pts, const float* latent,
+                                       const stpde_lig_workspace* ws, float* jets, long ldp, int flags, void* stream) {
+  if (!p || !cfg_mlp || !cfg_out || !gd || !pts || !latent || !ws || !jets || p->nlayers < 2 || p->nlayers > 8 || (gd->P & 1)) {
+    stpde_set_error("lig_imnet_jet_fwd: bad argument");
+    return STPDE_E_BADARG;
+  }
+  const int nt = gd->P / 2, NL = p->nlayers;
+  const bool stash = flags & STPDE_F_STASH;
+  const int S = 1 + cfg_mlp->S1 + cfg_mlp->S2;
+  Seq seq;
+  seq([&] { return stpde_lig_gather(gd, pts, latent, ws->X, stash ? ws->XR : nullptr, ws->coef, ws->cell, ws->cw, stream); });
+  // forward-only value queries: VALUE-TILE kernels (four consecutive row tiles share one pass over the weights)
+  const bool vt = S == 1 && !stash && (flags & STPDE_F_VALUE_TILES) && nt % 4 == 0 && (!p->mfma_bf16 || p->mfma_bf16 == 3);
+  stpde_jet_cfg lcfg = *cfg_mlp;
+  int lnt = nt;
+  if (vt) {
+    lcfg.S1 = 0;
+    lcfg.S2 = 3;
+    lnt = nt / 4;
+  }
+  const bool tail = (flags & STPDE_F_FUSED_TAIL) && tail_ok(p, *cfg_mlp, ws->cw, vt);
+  const float* prev = nullptr;
+  for (int l = 1; l < NL; ++l) {
+    if (tail && l == 3) {
+      const float* Wh[3] = {p->Wh[3], p->Wh[4], p->Wh[5]};
+      const float* Wsk[3] = {p->Ws[3], p->Ws[4], p->Ws[5]};
+      const float* tc[3] = {p->tanc[3], p->tanc[4], p->tanc[5]};
+      float* outs[3] = {ws->pre[3], ws->pre[4], ws->pre[5]};
+      seq([&] { return stpde_jet_tail_fwd(&lcfg, lnt, p->nf16, prev, ws->X, Wh, Wsk, tc, outs, ws->cw, stream); });
+      break;
+    }
+    const void* w16 = p->mfma_bf16 ? p->Wh16[l] : nullptr;
+    stpde_layer_desc d = layer_desc(lnt, p, l, lcfg, w16 ? p->mfma_bf16 : 0);
+    seq([&] {
+      return stpde_jet_layer_fwd(&d, prev, ws->X, p->Wh[l], p->Ws[l], p->tanc[l], p->Ws[0], p->tanc[0], ws->pre[l], ws->cw, w16,
+                                 (l == 1 && stash) ? ws->pre[0] : nullptr, stream);
+    });
+    prev = ws->pre[l];
+  }
+  seq([&] { return stpde_lig_reduce_fwd(cfg_out, S, gd->P, p->cout, ws->pre[NL - 1], ws->coef, jets, ldp, stream); });
+  return seq.rc;
+}
+
+extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,
+                                       const stpde_jet_cfg* cfg_val, const stpde_gather_desc* gd, const stpde_lig_workspace* ws,
+                                       const float* jets_bar, long ldp, float* dW_flat, float* dlatent, float* act_param_bar,
+                                       int flags, void* stream) {
+  if (!p || !cfg_mlp || !cfg_out || !cfg_val || !gd || !ws || !jets_bar || p->nlayers != 6 || (gd->P & 1) || !ws->pre[0]) {
+    stpde_set_error("lig_imnet_jet_bwd: bad argument (needs the stash of a forward call with STPDE_F_STASH)");
+    return STPDE_E_BADARG;
+  }
+  const int nt = gd->P / 2, NL = p->nlayers;
+  const stpde_jet_cfg& cfg = *cfg_mlp;
+  const int S = 1 + cfg.S1 + cfg.S2, SP0 = 1 + cfg.S1;
+  const bool wgrad = (flags & STPDE_F_WGRAD) && dW_flat;
+  Seq seq;
+  // adjoint of the fc5 output rows (overwrites the forward's output buffer)
+  seq([&] { return stpde_lig_reduce_bwd(cfg_out, S, gd->P, p->cout, jets_bar, ldp, ws->coef, ws->pre[NL - 1], stream); });
+  const int MT0 = p->MT[0];
+  const bool split0 = SP0 == 4 && (flags & STPDE_F_TAN0_ROWSUM) && ws->tan0;
+  if (!split0 && SP0 != 1 && !ws->abar0) {
+    stpde_set_error("lig_imnet_jet_bwd: workspace.abar0 needed without the tangent row sums");
+    return STPDE_E_BADARG;
+  }
+  float* z0 = ws->pre[0];
+  float* abar0 = (split0 || SP0 == 1) ? z0 : ws->abar0;   // value-stream-only layer-0 adjoint goes over the z0 stash
+  const bool tail = (flags & STPDE_F_FUSED_TAIL) && tail_ok(p, cfg, ws->cw, false) && ws->abar2x && ws->abar3x;
+  float* abar[8];
+  for (int l = 1; l < NL; ++l) abar[l] = ws->pre[l];      // where the adjoint of layer l's output rows lives once it exists
+  for (int l = NL - 1; l >= 1; --l) {
+    const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
+    stpde_layer_desc d = layer_desc(nt, p, l, cfg, w16 ? p->mfma_bf16 : 0);
+    // weight gradient: same operand mode as the layer kernels; only the wide layers (MT >= 8) have bf16-pipe kernels
+    stpde_layer_desc dwg = layer_desc(nt, p, l, cfg, (w16 && p->MT[l] >= 8 && (p->mfma_bf16 == 1 || !(flags & STPDE_F_WGRAD_FP32))) ? p->mfma_bf16 : 0);
+    if (wgrad)
+      seq([&] {
+        return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->XR, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
+                               stream);
+      });
+    if (tail && l >= 3) {
+      if (l == 5) {
+        abar[3] = ws->abar3x;
+        abar[2] = ws->abar2x;
+        const float* WhT[3] = {p->WhT[3], p->WhT[4], p->WhT[5]};
+        const float* pre[3] = {ws->pre[2], ws->pre[3], ws->pre[4]};
+        float* outs[3] = {abar[2], abar[3], ws->pre[4]};
+        seq([&] { return stpde_jet_tail_bwd(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, stream); });
+      }
+      continue;
+    }
+    seq([&] {
+      return stpde_jet_layer_bwd(&d, abar[l], p->WhT[l], l > 1 ? ws->pre[l - 1] : nullptr, ws->X, p->Ws[0], p->tanc[0], abar0,
+                                 ws->cw, act_param_bar, w16, (l == 1 && split0) ? ws->tan0 : nullptr, l == 1 ? z0 : nullptr,
+                                 stream);
+    });
+  }
+  if (wgrad) {
+    stpde_layer_desc d = layer_desc(nt, p, 0, cfg, 0);
+    d.first_hidden = 0;
+    float* dw0 = dW_flat + p->dw_off[0];
+    if (split0) {
+      d.cfg = *cfg_val;       // value stream x raw input (the S = 1 weight-gradient kernels)
+      seq([&] { return stpde_jet_wgrad(&d, 1, abar0, nullptr, ws->XR, nullptr, dw0, nullptr, stream); });
+      seq([&] { return stpde_jet_tan0_reduce(nt, MT0, ws->tan0, dw0, 16 * STPDE_XT, stream); });
+    } else {
+      seq([&] { return stpde_jet_wgrad(&d, SP0, abar0, nullptr, ws->XR, nullptr, dw0, ws->cw, stream); });
+    }
+  }
+  if (dlatent) {
+    stpde_xbar_desc xd{};
+    xd.ntiles = nt;
+    xd.nlayers = 5;
+    xd.C = p->cin;
+    xd.n1 = gd->n1;
+    xd.n2 = gd->n2;
+    const float* ab[5];
+    const float* wt[5];
+    for (int l = 0; l < 5; ++l) {
+      xd.MT[l] = p->MT[l];
+      xd.SP[l] = l == 0 ? (split0 ? 1 : SP0) : S;
+      ab[l] = l == 0 ? abar0 : abar[l];
+      wt[l] = p->WsL[l];
+    }
+    if (!(flags & STPDE_F_DETERMINISTIC)) {
+      seq([&] { return stpde_lig_xbar_scatter(&xd, ab, wt, ws->cell, dlatent, stream); });
+    } else {
+      const long n_nodes = (long)gd->B * gd->n0 * gd->n1 * gd->n2;
+      seq([&] { return stpde_lig_xbar_rows(&xd, ab, wt, ws->xrows, stream); });
+      seq([&] { return stpde_lig_cell_sort(gd->P, n_nodes, ws->cell, ws->perm, ws->start, ws->sort_tmp, ws->sort_tmp_bytes, stream); });
+      seq([&] {
+        return stpde_lig_dlatent_reduce(gd->B, gd->n0, gd->n1, gd->n2, p->cin, ws->xrows, ws->perm, ws->start, dlatent, stream);
+      });
+    }
+  }
+  return seq.rc;
+}

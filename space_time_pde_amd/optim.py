@@ -20,10 +20,26 @@ _CHUNK_DT = np.dtype([("tensor", "<i4"), ("pad", "<i4"), ("offset", "<i8")])   #
 
 
 class FusedClipAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0):
+    """clip_grad_value_ + Adam over FLAT buffers (round 3).
+
+    ``flat=True`` (default): on the first step the parameters of a group are moved into ONE contiguous fp32 buffer (every
+    ``p.data`` becomes a view of it, values preserved), and ``exp_avg`` / ``exp_avg_sq`` are views of two more buffers
+    allocated once.  A step is then: gradients gathered into the flat gradient buffer (``torch._foreach_copy_``: a
+    handful of multi-tensor launches; skipped for gradients that already live there, see ``gather_grads``) and ONE
+    ``stpde_clip_adam`` launch over the whole buffer -- no per-step table build, no host-to-device upload.
+    ``gather_grads()`` returns that flat gradient buffer with every ``p.grad`` re-pointed into it, so a data-parallel
+    step all-reduces exactly the buffer the optimizer reads (reference: DDP's bucket, train_ddp.py:401-406).
+    The per-parameter state keeps torch.optim.Adam's names and shapes; ``state_dict()`` returns plain (cloned) tensors,
+    so checkpoints interoperate with the reference's Adam both ways.
+    A group falls back to the multi-tensor pointer-table kernel for a step in which some parameter has no gradient or the
+    step counts differ (torch's Adam skips such parameters; a flat pass could not)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0, flat=True):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_grad=clip_grad))
+        self._use_flat = bool(flat)
+        self._flat = {}          # id(group) -> dict(P, G, M, V, offs, views...)
 
     def __setstate__(self, state):
         # Optimizer.load_state_dict replaces param_groups with the SAVED groups: a checkpoint written by the
@@ -35,6 +51,102 @@ class FusedClipAdam(torch.optim.Optimizer):
             group.setdefault("clip_grad", self.defaults["clip_grad"])
             if group.get("amsgrad") or group.get("maximize"):
                 raise ValueError("FusedClipAdam does not implement amsgrad / maximize")
+        self._flat = {}          # loaded state tensors are fresh allocations: rebuild the flat views on the next step
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat = {}
+
+    def add_param_group(self, group):
+        super().add_param_group(group)
+        if hasattr(self, "_flat"):
+            self._flat = {}
+
+    def state_dict(self):
+        sd = super().state_dict()
+        # plain tensors in NEW dicts (the base class hands out the live per-parameter dicts): no views of the flat buffers,
+        # no shared step tensor -- what torch.optim.Adam writes
+        sd["state"] = {k: {n: (v.clone() if torch.is_tensor(v) and (v._base is not None or n == "step") else v)
+                           for n, v in st.items()} for k, st in sd["state"].items()}
+        return sd
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _flat_group(self, gi, group):
+        """Flat buffers of a group (built once): parameters re-pointed into P, moments into M / V."""
+        ent = self._flat.get(gi)
+        params = group["params"]
+        if ent is not None and len(ent["params"]) == len(params) and all(a is b for a, b in zip(ent["params"], params)):
+            return ent
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and
+                                 p.device == params[0].device for p in params):
+            return None
+        dev = params[0].device
+        offs, tot = [], 0
+        for p in params:
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4            # every tensor starts 16-byte aligned
+        P, G, M, V = (torch.zeros(tot, device=dev) for _ in range(4))
+        pv, gv = [], []
+        for p, o in zip(params, offs):
+            n = p.numel()
+            view = P[o:o + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            pv.append(view)
+            gv.append(G[o:o + n].view_as(p))
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.tensor(0.0)
+            for name, buf in (("exp_avg", M), ("exp_avg_sq", V)):
+                mv = buf[o:o + n].view_as(p)
+                if name in st:
+                    mv.copy_(st[name])
+                st[name] = mv
+        ent = dict(params=list(params), P=P, G=G, M=M, V=V, offs=offs, n=tot, gviews=gv, step=None)
+        self._share_step(ent)
+        self._flat[gi] = ent
+        return ent
+
+    def _share_step(self, ent):
+        """All parameters at the same step count: ONE shared ``step`` tensor (one host increment per step instead of one
+        per parameter); un-shared again (``_unshare_step``) before a pointer-table step could advance them unequally."""
+        steps = {float(self.state[p]["step"]) for p in ent["params"]}
+        if len(steps) == 1:
+            ent["step"] = torch.tensor(steps.pop())
+            for p in ent["params"]:
+                self.state[p]["step"] = ent["step"]
+
+    def _unshare_step(self, ent):
+        if ent.get("step") is not None:
+            for p in ent["params"]:
+                self.state[p]["step"] = self.state[p]["step"].clone()
+            ent["step"] = None
+
+    def gather_grads(self, group_index=0):
+        """Flat gradient buffer of a parameter group with every existing ``p.grad`` copied in and re-pointed to its view
+        (so the following ``step()`` finds them in place).  Parameters without a gradient contribute zeros."""
+        group = self.param_groups[group_index]
+        ent = self._flat_group(group_index, group)
+        if ent is None:
+            raise RuntimeError("gather_grads needs contiguous fp32 CUDA parameters on one device")
+        self._gather(ent)
+        return ent["G"]
+
+    @staticmethod
+    def _gather(ent):
+        src, dst = [], []
+        for p, gvw in zip(ent["params"], ent["gviews"]):
+            g = p.grad
+            if g is None:
+                gvw.zero_()
+            elif g.data_ptr() != gvw.data_ptr():
+                src.append(g)
+                dst.append(gvw)
+        if src:
+            torch._foreach_copy_(dst, src)
+            for p, gvw in zip(ent["params"], ent["gviews"]):
+                if p.grad is not None:
+                    p.grad = gvw
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,8 +155,34 @@ class FusedClipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            ent = self._flat_group(gi, group) if self._use_flat else None
+            if ent is not None and all(p.grad is not None for p in ent["params"]):
+                if ent["step"] is None:
+                    self._share_step(ent)
+                if ent["step"] is not None:
+                    ent["step"] += 1
+                    t = float(ent["step"])
+                    self._gather(ent)
+                    d = _lib.AdamDesc()
+                    d.n = ent["n"]
+                    d.clip, d.beta1, d.beta2, d.eps = float(group["clip_grad"] or 0.0), b1, b2, group["eps"]
+                    d.weight_decay = group["weight_decay"]
+                    d.step_size, d.bias2_sqrt = group["lr"] / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)
+                    with _lib.device_of(ent["P"]):
+                        _lib.check(L.stpde_clip_adam(C.byref(d), _lib.ptr(ent["P"]), _lib.ptr(ent["G"]),
+                                                     _lib.ptr(ent["M"]), _lib.ptr(ent["V"]), _lib.stream_ptr()))
+                    continue
+            if ent is not None:
+                self._unshare_step(ent)
+            self._step_table(L, group)
+        return loss
+
+    def _step_table(self, L, group):
+        """Multi-tensor pointer-table launch: parameters with a gradient only, per-tensor step counts."""
+        b1, b2 = group["betas"]
+        if True:
             rows, chunks, keep = [], [], []
             for p in group["params"]:
                 if p.grad is None:
@@ -68,7 +206,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                     chunks.append((len(rows), 0, off))
                 rows.append(ptrs + (n, group["lr"] / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)))
             if not rows:
-                continue
+                return
             dev = keep[0].device
             # ONE launch for the whole group: tensor table + chunk table (a few KB) are uploaded per step
             tab = torch.from_numpy(np.array(rows, dtype=_TENSOR_DT).view(np.uint8)).to(dev)
@@ -82,4 +220,3 @@ class FusedClipAdam(torch.optim.Optimizer):
                                                    _lib.stream_ptr()))
                 tab.record_stream(torch.cuda.current_stream())
                 chk.record_stream(torch.cuda.current_stream())
-        return loss

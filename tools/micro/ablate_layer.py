@@ -3,6 +3,7 @@ the layer library with -DSTPDE_ABLATE=n (see jet_layer_impl.h) and times stpde_j
 
     python tools/micro/ablate_layer.py build      # here (no GPU): compiles tools/micro/_abl/libabl_<n>.so
     python tools/micro/ablate_layer.py run        # on the GPU box
+    python tools/micro/ablate_layer.py run bf16   # the same kernels with bf16 MFMA operands (BASELINE configs[3] mode)
 """
 import ctypes as C
 import os
@@ -35,7 +36,7 @@ def build():
         print("variant", n, "rc", p.returncode, out.decode()[-300:] if p.returncode else "")
 
 
-def run():
+def run(bf16=False):
     import torch
     from space_time_pde_amd import _lib
     from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
@@ -52,6 +53,7 @@ def run():
     abar0 = torch.empty(nt * 4 * plan.layers[0]["MT"] * 256, device=dev)
     tan0 = torch.empty(nt * plan.layers[0]["MT"] * 48, device=dev)
     pv = plan.pack_view
+    p16 = plan.pack_bf16(packs, 1) if bf16 else {}
     res = {}
     for n in VARIANTS:
         so = os.path.join(OUT, "libabl_%d.so" % n)
@@ -61,18 +63,18 @@ def run():
         L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
         L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 13
         d = _lib.LayerDesc()
-        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, 0
+        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, int(bf16)
         st = _lib.stream_ptr()
         p = _lib.ptr
 
         def fwd():
             return L.stpde_jet_layer_fwd(C.byref(d), None, p(X), p(pv(packs, 1, "Wh")), p(pv(packs, 1, "Ws")),
                                          p(pv(packs, 1, "tanc")), p(pv(packs, 0, "Ws")), p(pv(packs, 0, "tanc")), p(out1),
-                                         p(cw), None, p(abar0), st)
+                                         p(cw), p(p16.get((1, "Wh"))), p(abar0), st)
 
         def bwd():
             return L.stpde_jet_layer_bwd(C.byref(d), p(out1), p(pv(packs, 1, "WhT")), None, p(X), p(pv(packs, 0, "Ws")),
-                                         p(pv(packs, 0, "tanc")), p(abar0), p(cw), None, None, p(tan0), p(abar0), st)
+                                         p(pv(packs, 0, "tanc")), p(abar0), p(cw), None, p(p16.get((1, "WhT"))), p(tan0), p(abar0), st)
 
         for name, fn in (("fwd", fwd), ("dgrad", bwd)):
             assert fn() == 0
@@ -92,4 +94,7 @@ def run():
 
 
 if __name__ == "__main__":
-    (build if sys.argv[1:] == ["build"] else run)()
+    if sys.argv[1:] == ["build"]:
+        build()
+    else:
+        run(bf16="bf16" in sys.argv[2:])
