@@ -64,6 +64,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t opt_store_rsrc(float* base, un
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
                                            __builtin_amdgcn_readfirstlane(base ? bytes : 0u), 0x00020000);
 }
+// 16-byte loads through a buffer descriptor: wave-uniform base in SGPRs, ONE per-lane offset register, the block offset as
+// the instruction's scalar offset -- kernels that keep many weight fragments in flight would otherwise hold a 64-bit
+// per-lane address pair for every one of them.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t load_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long u = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, lane_byte_off, uniform_byte_off, 0);
+}
+__device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_byte_off, uniform_byte_off, 0);
+}
 __device__ __forceinline__ void opt_st4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
 }

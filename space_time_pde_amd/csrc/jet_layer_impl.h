@@ -24,6 +24,23 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #define STPDE_ABLATE 0
 #endif
 
+// Phase timing (tools/micro/ablate_layer.py stamp, private builds with -DSTPDE_STAMP=1): s_memtime stamps of every wave of
+// 256 mid-launch workgroups at the phase boundaries of k_layer_coop, read back with stpde_stamp_read (jet_layer_s31.hip).
+#ifndef STPDE_STAMP
+#define STPDE_STAMP 0
+#endif
+#if STPDE_STAMP
+#define STPDE_STAMP_B0 8192
+static __device__ unsigned long long g_stamp[256 * 8 * 16];
+#define STAMP(i)                                                                                          \
+  do {                                                                                                    \
+    if (blockIdx.x >= STPDE_STAMP_B0 && blockIdx.x < STPDE_STAMP_B0 + 256 && (threadIdx.x & 63) == 0)     \
+      g_stamp[((blockIdx.x - STPDE_STAMP_B0) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 struct LayerArgs {
   const float* Bin;    // [tile][S][KT][256] B-operand source (pre-activations or adjoints)
   const float* Wp;     // [KT][MT][256] packed A operand
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   // Pass splitting (dgrad of wide layers): the output passes of one row tile are run by different workgroups that
   // sit in consecutive slots of the SAME XCD (block b runs on XCD b % 8), i.e. at the same time on the same L2, so
   // the tile's B operand is fetched from HBM once instead of once per pass.
+  STAMP(0);
   int tile = blockIdx.x, pass0 = 0, pstep = 1;
   if (a.split > 0) {
     const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
@@ -357,8 +375,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
         for (int mi = 0; mi < MCg; ++mi) wr[q][mi] = ld4(wp + ((size_t)q * MT + mi) * 256);
     }
     __syncthreads();              // ring free (previous pass fully consumed)
+    STAMP(1);
     produce_group(0, 0);
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     for (int gi = 0; gi < ngroups; ++gi) {
       const int buf = gi & 1;
       if constexpr (BF) {
@@ -434,8 +455,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
       if (STPDE_ABLATE != 5) produce_group(gi + 1 < ngroups ? gi + 1 : gi, buf ^ 1);
+      if (gi < 8) STAMP(4 + gi);
       if (STPDE_ABLATE != 2) __syncthreads();
     }
+    STAMP(12);
     if (STPDE_ABLATE == 4) {     // keep the accumulators alive without the epilogue
       f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -448,13 +471,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
       layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc);
+    STAMP(13);
   }
   flush_pbar<EPI, ACT>(a, pacc, lane);
 }
 
+#include "jet_spec_bf16.h"
+
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
 static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   LayerArgs a = a0;
+  // bf16 operands, first hidden layer of the reference width: the wave-specialised persistent kernel (jet_spec_bf16.h);
+  // STPDE_BF_SPEC=0 keeps the cooperative kernel
+  if constexpr (PRO == PRO_L0 && EPI == EPI_FWD && NW == 4 && MCg == 4 && S1 == 3 && S2 <= 2) {
+    static const int spec_env = getenv("STPDE_BF_SPEC") ? atoi(getenv("STPDE_BF_SPEC")) : 1;
+    if (a.Wp16 && a.nsplit == 1 && spec_env && a.MT == 16 && (a.KT == 32 || a.KT == 16))
+      return launch_fc1_fwd_spec<S1, S2, ACT>(a, stream);
+  }
   const int npass = a.MT / (NW * MCg);
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
   a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;

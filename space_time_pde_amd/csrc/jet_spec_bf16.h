@@ -1,0 +1,243 @@
+// Wave-specialised, persistent bf16 variants of the first-hidden-layer kernels (BASELINE configs[3], round 3).
+//
+// Why: with bf16 operands the MFMAs of a row tile take 1/16 of their fp32 time and what is left of k_layer_coop is a chain
+// of latencies -- s_memtime stamps (tools/micro/ablate_layer.py stamp bf16, profiles/r3_stamp_bf16.txt) show a workgroup
+// living 49 k cycles per row tile for 5 k cycles of MFMAs: 8 k before the first MFMA (raw-input loads from HBM, first
+// produce stage), 7-9 k per group of 8 k-tiles (produce stage and MFMAs of one wave run back to back, every group waits
+// for an L2 round trip of its weight fragments) and 8 k of epilogue.  The activation jets (VALU) and the bf16 MFMAs use
+// different pipes of a SIMD, but one wave issues them one after the other.
+//
+// Here a workgroup has 8 waves with FIXED ROLES and stays resident (one per CU, walking row tiles with a grid stride):
+//   waves 0-3  producers: layer 0 on the fly (fp32 MFMA) + activation jet + bf16 rounding of 2 k-tiles each per step into
+//              an LDS ring, the z0 stash store; they run ONE STEP AHEAD of the consumers, across row-tile boundaries
+//   waves 4-7  consumers: the bf16 MFMAs of 4 output tiles x S streams each, weight fragments through a register ring
+//              4 k-tile pairs deep that runs across steps and row tiles (the weights do not depend on the tile), then the
+//              skip GEMM / tangent constants / stores of the finished tile
+// Every SIMD hosts one producer and one consumer wave, so its VALU and MFMA pipes work at the same time; one barrier per
+// step.  Arithmetic (operand rounding, accumulation order over the k-tile pairs) is exactly that of
+// k_layer_coop<..., BF = true>: results are bit-identical.
+#pragma once
+#include <type_traits>
+
+// NST = steps (groups of 8 k-tiles) per row tile = KT / 8, compile-time so that every ring / register-array index is static.
+// Nothing in the producers' loop reads global memory except the prefetch of the next tile's raw input: their layer-0 weight
+// fragments (always the same 2 * NST k-tiles) live in registers, the tangent constants W0[:, d] in LDS.
+#if STPDE_STAMP
+#define SPEC_STAMP(it, i)                                                                                         \
+  do {                                                                                                            \
+    if ((it) == 64 && blockIdx.x < 256 && (threadIdx.x & 63) == 0)                                                \
+      g_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter();                   \
+  } while (0)
+#else
+#define SPEC_STAMP(it, i)
+#endif
+template <int S1, int S2, int ACT, int NST>
+__global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
+  constexpr int S = 1 + S1 + S2, MCg = 4, GK = 8, KT = GK * NST, KP = KT / 2, ST = S1 == 3 ? 3 : 1;
+  __shared__ __attribute__((aligned(16))) float hb[2][GK][S][128];     // bf16 fragment blocks (512 B each)
+  __shared__ __attribute__((aligned(16))) float tcl[ST][KT][256];      // tangent constants of layer 0 (S1 == 3)
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const bool consumer = wv >= 4;
+  const int w = wv & 3;
+  const int MT = a.MT;
+  const int lo = lane * 4;
+  const int G = gridDim.x;
+  const int ntl = a.ntiles > (int)blockIdx.x ? (a.ntiles - (int)blockIdx.x + G - 1) / G : 0;   // row tiles of this workgroup
+
+  if (S1 == 3) {
+    for (int i = threadIdx.x; i < 3 * KT * 64; i += 512)
+      st4(&tcl[0][0][0] + 4 * i, ld4(a.tanc0 + 4 * (size_t)i));
+  }
+  // wave-uniform by construction; told to the compiler (scalar offsets of the buffer loads / stores below)
+  const int mt0 = __builtin_amdgcn_readfirstlane(w * MCg);
+  __syncthreads();
+
+  // The two roles are separate code paths with their own loops (and the same sequence of barriers: one after step 0 of
+  // every iteration, one after each of the steps 1 .. NST-1), so that the register allocator does not keep the producers'
+  // weight fragments and the consumers' accumulators / weight ring alive at the same time.
+  if (!consumer) {
+    // =========================================== producers ===========================================
+    f32x4 w0r[NST][2][XT];
+    f32x4 xb[XT], xn[XT];
+    float cq[6], cqn[6];
+#pragma unroll
+    for (int g = 0; g < NST; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) w0r[g][k][xt] = ld4(a.W0s + ((size_t)xt * KT + GK * g + 4 * k + w) * 256 + lo);
+    if (ntl > 0) {
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)blockIdx.x * XT + xt) * 256 + lo);
+      load_cq<S2>(a.cw, blockIdx.x * 2 + ((lane & 15) >> 3), cqn);
+    }
+    auto produce = [&](auto gc, int tile) {
+      constexpr int g = decltype(gc)::value;
+      const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int slot = 4 * k + w, kt = GK * g + slot;
+        f32x4 raw[S], B[S], part[XT];
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+          f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < x_live(xt); ++r) c = mfma4(w0r[g][k][xt][r], xb[xt][r], c);
+          part[xt] = c;
+        }
+        raw[0] = (part[0] + part[1]) + part[2];
+        opt_st4(z0r, kt * 1024 + lane * 16, raw[0]);
+        if (S1 == 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) raw[1 + d] = ld4(&tcl[d][kt][lo]);
+#pragma unroll
+          for (int p = 0; p < S2; ++p) raw[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
+#pragma unroll
+        for (int st = 0; st < S; ++st) *reinterpret_cast<bf16x4*>(&hb[g & 1][slot][st][lane * 2]) = to_bf4(B[st]);
+      }
+    };
+    for (int it = 0; it <= ntl; ++it) {
+      const int tile = (int)blockIdx.x + it * G;
+      if (it < ntl) {
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) xb[xt] = xn[xt];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cq[i] = cqn[i];
+        SPEC_STAMP(it, 0);
+        produce(std::integral_constant<int, 0>{}, tile);
+      }
+      SPEC_STAMP(it, 1);
+      __syncthreads();
+      SPEC_STAMP(it, 2);
+      if (it == ntl) break;
+      auto step = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if (g == NST - 1 && it + 1 < ntl) {           // prefetch the next tile's raw input (HBM latency behind this step)
+#pragma unroll
+          for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)(tile + G) * XT + xt) * 256 + lo);
+          load_cq<S2>(a.cw, (tile + G) * 2 + ((lane & 15) >> 3), cqn);
+        }
+        produce(gc, tile);
+        SPEC_STAMP(it, 1 + 2 * g);
+        __syncthreads();
+        SPEC_STAMP(it, 2 + 2 * g);
+      };
+      if constexpr (NST > 1) step(std::integral_constant<int, 1>{});
+      if constexpr (NST > 2) step(std::integral_constant<int, 2>{});
+      if constexpr (NST > 3) step(std::integral_constant<int, 3>{});
+    }
+  } else {
+    // =========================================== consumers ===========================================
+    f32x4 acc[MCg][S];
+    bf16x8 wr[4][MCg];
+    f32x4 xb[1][XT];
+    // weight fragments through a buffer descriptor (block offsets are instruction immediates / SGPRs, one lane-offset VGPR)
+    const auto wrs = load_rsrc(a.Wp16, (unsigned)KP * MT * 1024u);
+    const auto srs = load_rsrc(a.Wsp, (unsigned)XT * MT * 1024u);
+    const auto trs = load_rsrc(a.tanc, (unsigned)3 * MT * 1024u);
+    const int wlane = lane * 16;
+    auto wload = [&](int kp, int mi) -> bf16x8 {
+      return __builtin_bit_cast(bf16x8, buf_ld16(wrs, wlane, ((kp * MT + mt0 + mi) * 64) * 16));
+    };
+    // The skip GEMM with the raw input (bias through its ones column) and the tangent constants are ADDED to the accumulators
+    // during the steps of the tile (output tiles 2(g-1), 2(g-1)+1 in step g: the consumers' steps stay as long as the
+    // producers'), so that the only work left when the last group is done is the store of the pre-activations.  Every address
+    // is descriptor + scalar offset + the lane offset (no per-block address registers).
+    auto skip_part = [&](int mi) {
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+        const f32x4 wv4 = __builtin_bit_cast(f32x4, buf_ld16(srs, wlane, (xt * MT + mt0 + mi) * 1024));
+#pragma unroll
+        for (int r = 0; r < x_live(xt); ++r) acc[mi][0] = mfma4(wv4[r], xb[0][xt][r], acc[mi][0]);
+      }
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          acc[mi][1 + d] += __builtin_bit_cast(f32x4, buf_ld16(trs, wlane, (d * MT + mt0 + mi) * 1024));
+      }
+    };
+    auto epilogue = [&](int tile) {
+      const auto ors = load_rsrc(a.Out + (size_t)tile * S * MT * 256, (unsigned)S * MT * 1024u);
+#pragma unroll
+      for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+        for (int st = 0; st < S; ++st) buf_st16(ors, wlane, (st * MT + mt0 + mi) * 1024, acc[mi][st]);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int mi = 0; mi < MCg; ++mi) wr[q][mi] = wload(q, mi);
+    // the 4 k-tile pairs of group gg (compile-time) out of ring buffer (gg & 1)
+    auto consume = [&](auto ggc) {
+      constexpr int gg = decltype(ggc)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x8 B8[S];
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+          B8[st] = cat8(*reinterpret_cast<const bf16x4*>(&hb[gg & 1][2 * q][st][lane * 2]),
+                        *reinterpret_cast<const bf16x4*>(&hb[gg & 1][2 * q + 1][st][lane * 2]));
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+          for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(wr[q][mi], B8[st], acc[mi][st]);
+        // ring: this slot now fetches the pair four ahead (wraps into the next row tile: the weights are the same)
+        const int kpn = (4 * gg + q + 4) % KP;          // compile-time after unrolling
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi) wr[q][mi] = wload(kpn, mi);
+      }
+    };
+    for (int it = 0; it <= ntl; ++it) {
+      const int tile = (int)blockIdx.x + it * G;        // the producers' tile; step 0 finishes tile - G here
+      SPEC_STAMP(it, 0);
+      if (it >= 1) {
+        consume(std::integral_constant<int, NST - 1>{});
+        SPEC_STAMP(it, 9);
+        epilogue(tile - G);
+      }
+      SPEC_STAMP(it, 1);
+      __syncthreads();
+      SPEC_STAMP(it, 2);
+      if (it == ntl) break;
+      auto step = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if (g == 1) {
+#pragma unroll
+          for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+            for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int xt = 0; xt < XT; ++xt) xb[0][xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);   // for the epilogue
+        }
+        consume(std::integral_constant<int, g - 1>{});
+        // this step's share of the skip GEMM (NST = 4: tiles 0,1 / 2,3 / none; NST = 2: all four in step 1)
+        constexpr int per = NST == 2 ? MCg : 2;
+#pragma unroll
+        for (int mi = per * (g - 1); mi < per * g && mi < MCg; ++mi) skip_part(mi);
+        SPEC_STAMP(it, 1 + 2 * g);
+        __syncthreads();
+        SPEC_STAMP(it, 2 + 2 * g);
+      };
+      if constexpr (NST > 1) step(std::integral_constant<int, 1>{});
+      if constexpr (NST > 2) step(std::integral_constant<int, 2>{});
+      if constexpr (NST > 3) step(std::integral_constant<int, 3>{});
+    }
+  }
+  static_assert(NST <= 4 && NST >= 2 && NST % 2 == 0, "ring parity needs an even number of steps per tile");
+}
+
+template <int S1, int S2, int ACT>
+static int launch_fc1_fwd_spec(const LayerArgs& a, hipStream_t stream) {
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  int grid = ncu < a.ntiles ? ncu : a.ntiles;
+  if (a.KT == 32)
+    STPDE_LAUNCH((k_fc1_fwd_spec<S1, S2, ACT, 4>), dim3(grid), dim3(512), 0, stream, a);
+  else
+    STPDE_LAUNCH((k_fc1_fwd_spec<S1, S2, ACT, 2>), dim3(grid), dim3(512), 0, stream, a);
+  return stpde_check_launch("k_fc1_fwd_spec");
+}

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import XT, GatherDesc, JetCfg, LayerDesc, XbarDesc, check, ptr, stream_ptr
+from ._lib import XT, GatherDesc, ImNetPlanDesc, JetCfg, LayerDesc, LigWorkspace, XbarDesc, check, ptr, stream_ptr
 
 _FRAG = 256  # floats per 16x16 fragment block
 # widest latent the HIP jet path takes: the augmented input [r(3); latent(c); 1] must fit XT = 3 fragment tiles whose third
@@ -333,8 +333,129 @@ def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=0):
     return d
 
 
+# ------------------------------------------------------------------------------------------------------------
+# one C call per direction (include/stpde_hip.h: stpde_lig_imnet_jet_fwd / _bwd); the per-kernel functions below stay as
+# the profiling path (bench.py's per-kernel event timings) and are what ``STPDE_PIPELINE=0`` selects
+# ------------------------------------------------------------------------------------------------------------
+use_pipeline = os.environ.get("STPDE_PIPELINE", "1") != "0"
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def _plan_desc(meta, packs):
+    plan = meta.plan
+    d = ImNetPlanDesc()
+    d.nlayers, d.cin, d.cout, d.nf16 = 6, plan.cin, plan.cout, plan.nf // 16
+    pv = plan.pack_view
+    for l, lay in enumerate(plan.layers):
+        d.KT[l], d.MT[l] = lay["KT"], lay["MT"]
+        if lay["KT"]:
+            d.Wh[l], d.WhT[l] = pv(packs, l, "Wh").data_ptr(), pv(packs, l, "WhT").data_ptr()
+        d.Ws[l], d.WsL[l], d.tanc[l] = (pv(packs, l, n).data_ptr() for n in ("Ws", "WsL", "tanc"))
+        if meta.packs16:
+            d.Wh16[l], d.WhT16[l] = _dp(meta.packs16.get((l, "Wh"))), _dp(meta.packs16.get((l, "WhT")))
+        d.dw_off[l] = plan.dw_off[l][0]
+    d.mfma_bf16 = meta.nsplit if meta.packs16 else 0
+    return d
+
+
+def _gather_desc(meta, latent, Pc, p0):
+    gd = GatherDesc()
+    gd.P, gd.N, gd.B = Pc, meta.N, meta.B
+    gd.n0, gd.n1, gd.n2, gd.C = latent.shape[1], latent.shape[2], latent.shape[3], latent.shape[4]
+    for k in range(3):
+        gd.lo_c[k], gd.hi_c[k], gd.cube[k] = meta.lo_c[k], meta.hi_c[k], meta.cube[k]
+    gd.p_base = p0
+    for k in range(6):
+        gd.alpha[k] = meta.cfg_out.alpha[k]
+    return gd
+
+
+def _flags(meta, need_grad):
+    f = 0
+    if need_grad:
+        f |= _lib.F_STASH
+    if value_tiles:
+        f |= _lib.F_VALUE_TILES
+    if fused_tail:
+        f |= _lib.F_FUSED_TAIL
+    if tan0_rowsum:
+        f |= _lib.F_TAN0_ROWSUM
+    if deterministic_dlatent:
+        f |= _lib.F_DETERMINISTIC
+    if meta.need_wgrad:
+        f |= _lib.F_WGRAD
+    if not wgrad_split:
+        f |= _lib.F_WGRAD_FP32
+    return f
+
+
+def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
+    """_forward_chunk through ONE library call: this function only allocates the chunk's buffers."""
+    plan, S = meta.plan, meta.S
+    Pc = pts_c.shape[0]
+    nt = Pc // 2
+    dev = pts_c.device
+    ws = LigWorkspace()
+    s = dict(p0=p0, Pc=Pc, ws=ws)
+    s["X"] = torch.empty(nt * XT * _FRAG, device=dev)
+    s["XR"] = torch.empty(nt * XT * _FRAG, device=dev) if need_grad else None
+    s["cw"] = torch.empty(Pc * 8, device=dev) if meta.cfg_out.combo else None
+    s["coef"] = torch.empty(Pc * 16, device=dev)
+    s["cell"] = torch.empty(Pc, device=dev, dtype=torch.int32)
+    s["bufs"] = [None] + [torch.empty(nt * S * plan.layers[l]["MT"] * _FRAG, device=dev) for l in range(1, 6)]
+    s["z0"] = torch.empty(nt * plan.layers[0]["MT"] * _FRAG, device=dev) if need_grad else None
+    ws.X, ws.XR, ws.coef, ws.cw, ws.cell = (_dp(s[k]) for k in ("X", "XR", "coef", "cw", "cell"))
+    ws.pre[0] = _dp(s["z0"])
+    for l in range(1, 6):
+        ws.pre[l] = s["bufs"][l].data_ptr()
+    pd = _plan_desc(meta, packs)
+    gd = _gather_desc(meta, latent, Pc, p0)
+    check(_lib.lib().stpde_lig_imnet_jet_fwd(C.byref(pd), C.byref(meta.cfg), C.byref(meta.cfg_out), C.byref(gd), ptr(pts_c),
+                                             ptr(latent), C.byref(ws), C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2],
+                                             _flags(meta, need_grad), stream_ptr()))
+    s["gd"] = gd
+    return s
+
+
+def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
+    """_backward_chunk through ONE library call (+ allocation of its scratch)."""
+    plan, S = meta.plan, meta.S
+    Pc, ws, gd = saved["Pc"], saved["ws"], saved["gd"]
+    nt = Pc // 2
+    dev = saved["X"].device
+    keep = []
+
+    def buf(n, dtype=torch.float32):
+        t = torch.empty(n, device=dev, dtype=dtype)
+        keep.append(t)
+        return t.data_ptr()
+
+    MT0 = plan.layers[0]["MT"]
+    SP0 = 1 + meta.cfg.S1
+    ws.abar2x, ws.abar3x = buf(saved["bufs"][2].numel()), buf(saved["bufs"][3].numel())
+    ws.tan0 = buf(nt * MT0 * 48) if (SP0 == 4 and tan0_rowsum) else None
+    ws.abar0 = buf(nt * SP0 * MT0 * _FRAG) if (SP0 == 4 and not tan0_rowsum) else None
+    if dlatent is not None and deterministic_dlatent:
+        cp = (plan.cin + 3) // 4 * 4
+        n_nodes = meta.B * meta.grid_shape[0] * meta.grid_shape[1] * meta.grid_shape[2]
+        ws.xrows = buf(Pc * 8 * cp)
+        ws.perm, ws.start = buf(Pc, torch.int32), buf(n_nodes + 1, torch.int32)
+        nb = int(_lib.lib().stpde_lig_sort_tmp_bytes(Pc, n_nodes))
+        ws.sort_tmp, ws.sort_tmp_bytes = buf(nb, torch.uint8), nb
+    pd = _plan_desc(meta, packs)
+    check(_lib.lib().stpde_lig_imnet_jet_bwd(C.byref(pd), C.byref(meta.cfg), C.byref(meta.cfg_out), C.byref(meta.cfg_val),
+                                             C.byref(gd), C.byref(ws), C.c_void_p(jets_bar.data_ptr() + 4 * saved["p0"]),
+                                             jets_bar.shape[2], ptr(dw_flat), ptr(dlatent), ptr(pbar), _flags(meta, True),
+                                             stream_ptr()))
+
+
 def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     """Run gather + layers 1..5 + reduce for points [p0, p0+Pc) ; returns the buffers backward needs."""
+    if use_pipeline and profile is None:
+        return _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad)
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()
@@ -407,6 +528,8 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
 def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
     """reduce_bwd -> for l = 5..1: wgrad_l (reads abar_l and the still intact pre-activations of layer l-1), then
     dgrad_l (overwrites them with abar_{l-1}) -> wgrad_0 -> xbar/scatter."""
+    if "ws" in saved:
+        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar)
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()

@@ -120,7 +120,9 @@ def _assert_mode_kernels(tr, prec):
 
 
 def _assert_bf16_kernels(tr, cfg, dump):
-    for pro, epi in ((2, 0), (0, 2), (1, 0), (0, 1)):
+    # first hidden layer forward: the wave-specialised persistent kernel (csrc/jet_spec_bf16.h)
+    assert tr.has("k_fc1_fwd_spec", cfg), dump
+    for pro, epi in ((0, 2), (1, 0), (0, 1)):
         assert tr.has("k_layer_coop", "true", cfg, "PRO = %d" % pro, "EPI = %d" % epi), dump
     # bf16 weight gradients with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
     assert tr.has("k_wgrad_coop", "false, true>)", cfg, "MODE = 1", "KC = 8"), dump
@@ -207,6 +209,59 @@ def test_recompute_mode_gives_bit_identical_gradients(hiplib, monkeypatch):
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2], out[1][2]):
         assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+
+
+@pytest.mark.parametrize("act", ["softplus", "leakyrelu"])
+def test_one_call_per_direction_equals_the_per_kernel_path(hiplib, act, monkeypatch):
+    """stpde_lig_imnet_jet_fwd / _bwd (one C call per direction, cell sort on the device) against the per-layer entry points
+    sequenced from Python: the same kernels in the same order -> identical jets and d latent bit for bit, weight gradients
+    to fp32-atomic rounding.  Several chunks, an odd point count, many points per cell."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, nonlinearities
+    g = torch.Generator().manual_seed(51)
+    lat = 0.5 * torch.randn(2, 3, 4, 5, 32, generator=g)
+    pts = torch.rand(2, 1501, 3, generator=g)
+    torch.manual_seed(7)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES[act]).to(DEV)
+    combo = {(1, 1): 1.0, (2, 2): 0.25}
+    out, cot = [], None
+    for pipe in (False, True):
+        monkeypatch.setattr(lig_jet, "use_pipeline", pipe)
+        for p in net.parameters():
+            p.grad = None
+        latd = lat.to(DEV).requires_grad_(True)
+        with _lib.dispatch_trace() as tr:
+            jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=1024, combo=combo)
+            if cot is None:
+                cot = torch.randn(jets.shape, generator=g).to(DEV)
+            (jets * cot).sum().backward()
+            torch.cuda.synchronize()
+        assert tr.has("k_dlat_reduce") and tr.has("k_gather") and tr.has("k_tail_bwd"), "\n".join(tr.kernels)
+        out.append((jets.detach().clone(), latd.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+
+
+def test_cell_sort_on_device_matches_torch(hiplib):
+    """stpde_lig_cell_sort: stable order of the points by cell + exclusive cell offsets == torch.sort(stable) + bincount."""
+    import ctypes as C
+    from space_time_pde_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    for P, n_nodes in ((4096, 300), (100000, 2 * 32 * 128 * 128), (2, 9)):
+        cell = torch.randint(0, n_nodes - 1, (P,), generator=g, dtype=torch.int32).to(DEV)
+        perm = torch.empty(P, device=DEV, dtype=torch.int32)
+        start = torch.empty(n_nodes + 1, device=DEV, dtype=torch.int32)
+        nb = int(hiplib.stpde_lig_sort_tmp_bytes(P, n_nodes))
+        tmp = torch.empty(nb, device=DEV, dtype=torch.uint8)
+        _lib.check(hiplib.stpde_lig_cell_sort(P, n_nodes, _lib.ptr(cell), _lib.ptr(perm), _lib.ptr(start), _lib.ptr(tmp), nb,
+                                              _lib.stream_ptr()))
+        want = torch.sort(cell, stable=True)[1].int()
+        assert torch.equal(perm, want)
+        cnt = torch.bincount(cell.long(), minlength=n_nodes)
+        want_start = torch.cat([torch.zeros(1, device=DEV, dtype=torch.long), torch.cumsum(cnt, 0)]).int()
+        assert torch.equal(start, want_start)
 
 
 def test_wider_latent_takes_the_generic_path(hiplib):

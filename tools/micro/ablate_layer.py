@@ -36,6 +36,127 @@ def build():
         print("variant", n, "rc", p.returncode, out.decode()[-300:] if p.returncode else "")
 
 
+def build_stamp():
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, "libabl_stamp.so")
+    srcs = [os.path.join(CSRC, f) for f in ("jet_layer.hip", "jet_layer_s31.hip", "api.cpp")]
+    stub = os.path.join(OUT, "stub.cpp")
+    open(stub, "w").write('#include <hip/hip_runtime.h>\nstruct LayerArgs;\n' + "".join(
+        "int stpde_layer_launch_%s(const LayerArgs&, int, hipStream_t) { return 2; }\n" % k
+        for k in ("0_0", "0_3", "3_0", "3_2", "3_6")))
+    r = subprocess.run(["hipcc"] + FLAGS + ["-DSTPDE_STAMP=1", "-shared", "-o", so] + srcs + [stub], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    print("stamp build rc", r.returncode, r.stdout.decode()[-300:] if r.returncode else "")
+
+
+def stamp(bf16=False):
+    """Phase timeline of k_layer_coop (first hidden layer, forward and dgrad): mean cycles between the s_memtime stamps of
+    256 mid-launch workgroups (all waves)."""
+    import numpy as np
+    import torch
+    from space_time_pde_amd import _lib
+    from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
+    dev = torch.device("cuda:0")
+    plan = ImNetPlan.get(3, 32, 4, 32)
+    nt = 1 << 17
+    cfg, S, _ = make_cfg("softplus", 0.0, True, [], {(1, 1): 1.0, (2, 2): 0.25})
+    torch.manual_seed(0)
+    packs = 0.05 * torch.randn(plan.n_pack, device=dev)
+    X = torch.randn(nt * 3 * 256, device=dev)
+    cw = torch.rand(nt * 2 * 8, device=dev)
+    lay = plan.layers[1]
+    out1 = torch.empty(nt * S * lay["MT"] * 256, device=dev)
+    abar0 = torch.empty(nt * 4 * plan.layers[0]["MT"] * 256, device=dev)
+    tan0 = torch.empty(nt * plan.layers[0]["MT"] * 48, device=dev)
+    pv = plan.pack_view
+    p16 = plan.pack_bf16(packs, 1) if bf16 else {}
+    L = C.CDLL(os.path.join(OUT, "libabl_stamp.so"))
+    L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
+    L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 13
+    d = _lib.LayerDesc()
+    d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, int(bf16)
+    st = _lib.stream_ptr()
+    p = _lib.ptr
+
+    def fwd():
+        return L.stpde_jet_layer_fwd(C.byref(d), None, p(X), p(pv(packs, 1, "Wh")), p(pv(packs, 1, "Ws")),
+                                     p(pv(packs, 1, "tanc")), p(pv(packs, 0, "Ws")), p(pv(packs, 0, "tanc")), p(out1),
+                                     p(cw), p(p16.get((1, "Wh"))), p(abar0), st)
+
+    def bwd():
+        return L.stpde_jet_layer_bwd(C.byref(d), p(out1), p(pv(packs, 1, "WhT")), None, p(X), p(pv(packs, 0, "Ws")),
+                                     p(pv(packs, 0, "tanc")), p(abar0), p(cw), None, p(p16.get((1, "WhT"))), p(tan0), p(abar0), st)
+
+    names = ["start->ring free", "first produce", "barrier", "g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "loop end",
+             "epilogue"]
+    for name, fn in (("fwd", fwd), ("dgrad", bwd)):
+        for _ in range(2):
+            assert fn() == 0
+        torch.cuda.synchronize()
+        host = (C.c_ulonglong * (256 * 8 * 16))()
+        assert L.stpde_stamp_read(host) == 0
+        a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, 16).astype(np.int64)
+        print("== %s (%s): mean cycles per phase over the waves that recorded it; 100 MHz s_memtime ticks x 24 = shader cycles at 2.4 GHz"
+              % (name, "bf16" if bf16 else "fp32"))
+        idx = [0, 1, 2, 3] + list(range(4, 12)) + [12, 13]
+        prev = 0
+        for k, i in enumerate(idx[1:]):
+            cur, pre = a[:, :, i], a[:, :, idx[k]]
+            ok = (cur > 0) & (pre > 0) & (cur >= pre)
+            if ok.any():
+                print("  %-18s n=%5d  mean %9.1f ticks  (min %d, max %d)" % (names[k], ok.sum(), (cur - pre)[ok].mean(),
+                                                                            (cur - pre)[ok].min(), (cur - pre)[ok].max()))
+        tot = a[:, :, 13] - a[:, :, 0]
+        ok = (a[:, :, 13] > 0) & (a[:, :, 0] > 0)
+        print("  %-18s n=%5d  mean %9.1f ticks" % ("TOTAL wave life", ok.sum(), tot[ok].mean()))
+
+
+def stamp_spec():
+    """Step timeline of the wave-specialised bf16 forward (k_fc1_fwd_spec): iteration 64 of every workgroup; per role the mean
+    cycles from the start of the iteration to the arrival at each step barrier and to its release."""
+    import numpy as np
+    import torch
+    from space_time_pde_amd import _lib
+    from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
+    dev = torch.device("cuda:0")
+    plan = ImNetPlan.get(3, 32, 4, 32)
+    nt = 1 << 17
+    cfg, S, _ = make_cfg("softplus", 0.0, True, [], {(1, 1): 1.0, (2, 2): 0.25})
+    torch.manual_seed(0)
+    packs = 0.05 * torch.randn(plan.n_pack, device=dev)
+    X = torch.randn(nt * 3 * 256, device=dev)
+    cw = torch.rand(nt * 2 * 8, device=dev)
+    lay = plan.layers[1]
+    out1 = torch.empty(nt * S * lay["MT"] * 256, device=dev)
+    z0 = torch.empty(nt * plan.layers[0]["MT"] * 256, device=dev)
+    pv = plan.pack_view
+    p16 = plan.pack_bf16(packs, 1)
+    L = C.CDLL(os.path.join(OUT, "libabl_stamp.so"))
+    L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
+    d = _lib.LayerDesc()
+    d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, 1
+    p = _lib.ptr
+    for _ in range(2):
+        assert L.stpde_jet_layer_fwd(C.byref(d), None, p(X), p(pv(packs, 1, "Wh")), p(pv(packs, 1, "Ws")),
+                                     p(pv(packs, 1, "tanc")), p(pv(packs, 0, "Ws")), p(pv(packs, 0, "tanc")), p(out1),
+                                     p(cw), p(p16.get((1, "Wh"))), p(z0), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    host = (C.c_ulonglong * (256 * 8 * 16))()
+    assert L.stpde_stamp_read(host) == 0
+    a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, 16).astype(np.int64)
+    for role, sl in (("producers (waves 0-3)", slice(0, 4)), ("consumers (waves 4-7)", slice(4, 8))):
+        r = a[:, sl, :]
+        t0 = r[:, :, 0:1]
+        print("== %s: mean cycles since the start of iteration 64" % role)
+        for i, nm in ((1, "arrive barrier 0"), (2, "leave  barrier 0"), (3, "arrive barrier 1"), (4, "leave  barrier 1"),
+                      (5, "arrive barrier 2"), (6, "leave  barrier 2"), (7, "arrive barrier 3"), (8, "leave  barrier 3"),
+                      (9, "epilogue start (consumers)")):
+            v = (r[:, :, i:i + 1] - t0)
+            ok = (r[:, :, i:i + 1] > 0) & (t0 > 0)
+            if ok.any():
+                print("  %-28s %9.1f" % (nm, v[ok].mean()))
+
+
 def run(bf16=False):
     import torch
     from space_time_pde_amd import _lib
@@ -96,5 +217,10 @@ def run(bf16=False):
 if __name__ == "__main__":
     if sys.argv[1:] == ["build"]:
         build()
+        build_stamp()
+    elif sys.argv[1] == "stamp_spec":
+        stamp_spec()
+    elif sys.argv[1] == "stamp":
+        stamp(bf16="bf16" in sys.argv[2:])
     else:
         run(bf16="bf16" in sys.argv[2:])
