@@ -159,6 +159,14 @@ int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const 
                         float* act_param_bar, const void* WhT_pack_bf16 /* as Wh_pack_bf16, of WhT_pack */,
                         float* abar0_tan, const float* z0, void* stream);
 
+/* The same input gradient of a hidden layer (first_hidden == 0) written to a SEPARATE buffer abar_in instead of over the
+ * stashed pre-activations in_pre (which stay intact): lets the whole input-gradient chain run before the weight gradients
+ * -- "dgrad-first" order, so that the partial d latent of a rank is complete, and its all-reduce in flight, while the weight
+ * gradients are still being computed (the overlap DistributedDataParallel gets from bucketed all-reduces inside
+ * loss.backward(), experiments/rb2d/train_ddp.py:401-406). */
+int stpde_jet_layer_bwd_to(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, const float* in_pre,
+                           float* abar_in, const float* cw, float* act_param_bar, const void* WhT_pack_bf16, void* stream);
+
 /* Weight gradient of one layer: dW_aug[16*MT][16*(KT+3)] += sum_rows abar_out (x) [act_jet(in_pre) ; X_aug]
  * (columns: hidden inputs, then r(3), latent(c), bias, pad).  abar_out [tile][SP][MT] (SP = S, or 1+S1 for layer 0)
  * and in_pre [tile][S][KT] are the ordinary (column-major) layer buffers -- call it BEFORE stpde_jet_layer_bwd of the
@@ -246,6 +254,8 @@ typedef struct {
   float* abar3x;
   float* tan0;
   float* abar0;
+  float* abar1x;   /* dgrad-first order only: fresh adjoint buffer of fc1's output rows (size of pre[1]) */
+  float* abar0x;   /* dgrad-first order only: fresh layer-0 adjoint [nt][MT_0][block] (the z0 stash stays intact) */
   float* xrows;
   int* perm;
   int* start;
@@ -259,6 +269,11 @@ typedef struct {
 #define STPDE_F_DETERMINISTIC 16 /* backward: d latent by per-node sums in a fixed order instead of fp32 atomics */
 #define STPDE_F_WGRAD 32         /* backward: compute the weight gradients */
 #define STPDE_F_WGRAD_FP32 64    /* fp32x3 mode: keep the wide layers' weight gradients on the exact-fp32 MFMA */
+/* Backward in two calls, "dgrad-first" (needs workspace.abar1x / abar0x, the fused tail and the tangent row sums):
+ * PHASE_A = corner-reduction adjoint, fc5 weight gradient, the whole input-gradient chain into fresh buffers, d latent;
+ * PHASE_B = the remaining weight gradients (fc4 .. fc0).  Between the two the caller may start the all-reduce of d latent. */
+#define STPDE_F_PHASE_A 128
+#define STPDE_F_PHASE_B 256
 /* cfg_mlp = streams the layer kernels carry, cfg_out = streams of `jets` (they differ for piecewise-linear activations,
  * see stpde_lig_reduce_fwd); jets points at the first point of the chunk inside [S_out][n_out][ldp]. */
 int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* plan, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,

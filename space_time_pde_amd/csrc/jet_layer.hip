@@ -71,10 +71,34 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
   return dispatch_streams(a, 0, (hipStream_t)stream);
 }
 
+static int layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, const float* in_pre,
+                     float* abar_in, const float* X, const float* W0s_pack, const float* tanc0, float* abar0,
+                     const float* cw, float* act_param_bar, const void* WhT_pack_bf16, float* abar0_tan, const float* z0,
+                     void* stream);
+
 extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
                                    float* in_pre, const float* X, const float* W0s_pack, const float* tanc0,
                                    float* abar0, const float* cw, float* act_param_bar,
                                    const void* WhT_pack_bf16, float* abar0_tan, const float* z0, void* stream) {
+  return layer_bwd(d, abar_out, WhT_pack, in_pre, in_pre, X, W0s_pack, tanc0, abar0, cw, act_param_bar, WhT_pack_bf16,
+                   abar0_tan, z0, stream);
+}
+
+extern "C" int stpde_jet_layer_bwd_to(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack,
+                                      const float* in_pre, float* abar_in, const float* cw, float* act_param_bar,
+                                      const void* WhT_pack_bf16, void* stream) {
+  if (!d || d->first_hidden || !abar_in) {
+    stpde_set_error("jet_layer_bwd_to: hidden layers only (the first hidden layer already writes to abar0), abar_in required");
+    return STPDE_E_BADARG;
+  }
+  return layer_bwd(d, abar_out, WhT_pack, in_pre, abar_in, nullptr, nullptr, nullptr, nullptr, cw, act_param_bar,
+                   WhT_pack_bf16, nullptr, nullptr, stream);
+}
+
+static int layer_bwd(const stpde_layer_desc* d, const float* abar_out, const float* WhT_pack, const float* in_pre,
+                     float* abar_in, const float* X, const float* W0s_pack, const float* tanc0, float* abar0,
+                     const float* cw, float* act_param_bar, const void* WhT_pack_bf16, float* abar0_tan, const float* z0,
+                     void* stream) {
   int rc = check_cfg(d);
   if (rc) return rc;
   // GEMM roles swap: contraction over this layer's MT output tiles, result over its KT input tiles.
@@ -110,10 +134,11 @@ extern "C" int stpde_jet_layer_bwd(const stpde_layer_desc* d, const float* abar_
     a.Z0 = const_cast<float*>(z0);
     return dispatch_streams(a, 3, (hipStream_t)stream);
   }
-  if (!in_pre) {
+  if (!in_pre || !abar_in) {
     stpde_set_error("jet_layer_bwd: null in_pre");
     return STPDE_E_BADARG;
   }
-  a.Out = in_pre;
+  a.Out = abar_in;
+  a.Pre = in_pre;
   return dispatch_streams(a, 2, (hipStream_t)stream);
 }

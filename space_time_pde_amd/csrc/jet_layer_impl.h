@@ -49,7 +49,8 @@ struct LayerArgs {
   const float* tanc0;  // [3][KT or MT][256]   layer-0 tangent constants W0[:, d]
   const float* Wsp;    // [XT][MT][256] packed skip weights (EPI_FWD)
   const float* tanc;   // [3][MT][256]  skip tangent constants (EPI_FWD)
-  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: in place over pre-activations; EPI_ADJ_L0: [tile][1+S1][MT][256]
+  float* Out;          // EPI_FWD: [tile][S][MT][256]; EPI_ADJ: the adjoints (== Pre: in place); EPI_ADJ_L0: [tile][1+S1][MT][256]
+  const float* Pre;    // EPI_ADJ: stashed pre-activations [tile][S][MT][256] the adjoint is taken against (may be Out)
   const float* cw;     // [P][8] per-point weights of the combined second-order stream (S2 == 1), else unused
   const void* Wp16;    // [nsplit][KT/2][MT][64] x 8 bf16: A operand of the bf16-MFMA variants (two k-tiles per block), or null
   int nsplit;          // 1: operands rounded to bf16 (configs[3]);  3: fp32 operands split into three bf16 terms each
@@ -108,7 +109,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
       f32x4 pre[S], ab[S];
       if (EPI == EPI_ADJ) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Pre + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
       } else {
         pre[0] = ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {

@@ -155,48 +155,42 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   const stpde_jet_cfg& cfg = *cfg_mlp;
   const int S = 1 + cfg.S1 + cfg.S2, SP0 = 1 + cfg.S1;
   const bool wgrad = (flags & STPDE_F_WGRAD) && dW_flat;
+  const bool phaseA = flags & STPDE_F_PHASE_A, phaseB = flags & STPDE_F_PHASE_B;
+  const bool dfirst = phaseA || phaseB;                 // dgrad-first order, two calls
   Seq seq;
-  // adjoint of the fc5 output rows (overwrites the forward's output buffer)
-  seq([&] { return stpde_lig_reduce_bwd(cfg_out, S, gd->P, p->cout, jets_bar, ldp, ws->coef, ws->pre[NL - 1], stream); });
   const int MT0 = p->MT[0];
   const bool split0 = SP0 == 4 && (flags & STPDE_F_TAN0_ROWSUM) && ws->tan0;
   if (!split0 && SP0 != 1 && !ws->abar0) {
     stpde_set_error("lig_imnet_jet_bwd: workspace.abar0 needed without the tangent row sums");
     return STPDE_E_BADARG;
   }
-  float* z0 = ws->pre[0];
-  float* abar0 = (split0 || SP0 == 1) ? z0 : ws->abar0;   // value-stream-only layer-0 adjoint goes over the z0 stash
   const bool tail = (flags & STPDE_F_FUSED_TAIL) && tail_ok(p, cfg, ws->cw, false) && ws->abar2x && ws->abar3x;
+  if (dfirst && !(tail && (split0 || SP0 == 1) && ws->abar1x && ws->abar0x)) {
+    stpde_set_error("lig_imnet_jet_bwd: the dgrad-first phases need the fused tail, the tangent row sums and workspace.abar1x / abar0x");
+    return STPDE_E_BADARG;
+  }
+  float* z0 = ws->pre[0];
+  // value-stream-only layer-0 adjoint: over the z0 stash (each lane reads before it writes), or -- dgrad-first -- into a
+  // fresh buffer, because the weight gradient of the first hidden layer still needs z0 afterwards
+  float* abar0 = dfirst ? ws->abar0x : ((split0 || SP0 == 1) ? z0 : ws->abar0);
   float* abar[8];
   for (int l = 1; l < NL; ++l) abar[l] = ws->pre[l];      // where the adjoint of layer l's output rows lives once it exists
-  for (int l = NL - 1; l >= 1; --l) {
-    const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
-    stpde_layer_desc d = layer_desc(nt, p, l, cfg, w16 ? p->mfma_bf16 : 0);
-    // weight gradient: same operand mode as the layer kernels; only the wide layers (MT >= 8) have bf16-pipe kernels
-    stpde_layer_desc dwg = layer_desc(nt, p, l, cfg, (w16 && p->MT[l] >= 8 && (p->mfma_bf16 == 1 || !(flags & STPDE_F_WGRAD_FP32))) ? p->mfma_bf16 : 0);
-    if (wgrad)
-      seq([&] {
-        return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->XR, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
-                               stream);
-      });
-    if (tail && l >= 3) {
-      if (l == 5) {
-        abar[3] = ws->abar3x;
-        abar[2] = ws->abar2x;
-        const float* WhT[3] = {p->WhT[3], p->WhT[4], p->WhT[5]};
-        const float* pre[3] = {ws->pre[2], ws->pre[3], ws->pre[4]};
-        float* outs[3] = {abar[2], abar[3], ws->pre[4]};
-        seq([&] { return stpde_jet_tail_bwd(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, stream); });
-      }
-      continue;
-    }
-    seq([&] {
-      return stpde_jet_layer_bwd(&d, abar[l], p->WhT[l], l > 1 ? ws->pre[l - 1] : nullptr, ws->X, p->Ws[0], p->tanc[0], abar0,
-                                 ws->cw, act_param_bar, w16, (l == 1 && split0) ? ws->tan0 : nullptr, l == 1 ? z0 : nullptr,
-                                 stream);
-    });
+  if (tail) {
+    abar[3] = ws->abar3x;
+    abar[2] = ws->abar2x;
   }
-  if (wgrad) {
+  if (dfirst) abar[1] = ws->abar1x;
+
+  auto wgrad_l = [&](int l) {
+    const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
+    // same operand mode as the layer kernels; only the wide layers (MT >= 8) have bf16-pipe weight-gradient kernels
+    stpde_layer_desc dwg = layer_desc(nt, p, l, cfg, (w16 && p->MT[l] >= 8 && (p->mfma_bf16 == 1 || !(flags & STPDE_F_WGRAD_FP32))) ? p->mfma_bf16 : 0);
+    seq([&] {
+      return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->XR, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
+                             stream);
+    });
+  };
+  auto wgrad_0 = [&] {
     stpde_layer_desc d = layer_desc(nt, p, 0, cfg, 0);
     d.first_hidden = 0;
     float* dw0 = dW_flat + p->dw_off[0];
@@ -207,8 +201,30 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     } else {
       seq([&] { return stpde_jet_wgrad(&d, SP0, abar0, nullptr, ws->XR, nullptr, dw0, ws->cw, stream); });
     }
-  }
-  if (dlatent) {
+  };
+  auto tail_bwd = [&] {
+    const float* WhT[3] = {p->WhT[3], p->WhT[4], p->WhT[5]};
+    const float* pre[3] = {ws->pre[2], ws->pre[3], ws->pre[4]};
+    float* outs[3] = {abar[2], abar[3], ws->pre[4]};
+    seq([&] { return stpde_jet_tail_bwd(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, stream); });
+  };
+  auto dgrad_l = [&](int l) {
+    const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
+    stpde_layer_desc d = layer_desc(nt, p, l, cfg, w16 ? p->mfma_bf16 : 0);
+    if (l > 1 && abar[l - 1] != ws->pre[l - 1]) {       // into a fresh buffer: the pre-activations stay intact
+      seq([&] {
+        return stpde_jet_layer_bwd_to(&d, abar[l], p->WhT[l], ws->pre[l - 1], abar[l - 1], ws->cw, act_param_bar, w16, stream);
+      });
+      return;
+    }
+    seq([&] {
+      return stpde_jet_layer_bwd(&d, abar[l], p->WhT[l], l > 1 ? ws->pre[l - 1] : nullptr, ws->X, p->Ws[0], p->tanc[0], abar0,
+                                 ws->cw, act_param_bar, w16, (l == 1 && split0) ? ws->tan0 : nullptr, l == 1 ? z0 : nullptr,
+                                 stream);
+    });
+  };
+  auto dlatent_part = [&] {
+    if (!dlatent) return;
     stpde_xbar_desc xd{};
     xd.ntiles = nt;
     xd.nlayers = 5;
@@ -233,6 +249,36 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
         return stpde_lig_dlatent_reduce(gd->B, gd->n0, gd->n1, gd->n2, p->cin, ws->xrows, ws->perm, ws->start, dlatent, stream);
       });
     }
+  };
+
+  if (dfirst) {
+    if (phaseA) {
+      // adjoint of the fc5 output rows (overwrites the forward's output buffer); fc5's weight gradient needs the
+      // pre-activations of fc4's output, which the fused chain overwrites with abar4
+      seq([&] { return stpde_lig_reduce_bwd(cfg_out, S, gd->P, p->cout, jets_bar, ldp, ws->coef, ws->pre[NL - 1], stream); });
+      if (wgrad) wgrad_l(5);
+      tail_bwd();
+      dgrad_l(2);
+      dgrad_l(1);
+      dlatent_part();
+    }
+    if (phaseB && wgrad) {
+      for (int l = 4; l >= 1; --l) wgrad_l(l);
+      wgrad_0();
+    }
+    return seq.rc;
   }
+  // one call: weight gradient of layer l, then its input gradient (which overwrites what the weight gradient read)
+  seq([&] { return stpde_lig_reduce_bwd(cfg_out, S, gd->P, p->cout, jets_bar, ldp, ws->coef, ws->pre[NL - 1], stream); });
+  for (int l = NL - 1; l >= 1; --l) {
+    if (wgrad) wgrad_l(l);
+    if (tail && l >= 3) {
+      if (l == 5) tail_bwd();
+      continue;
+    }
+    dgrad_l(l);
+  }
+  if (wgrad) wgrad_0();
+  dlatent_part();
   return seq.rc;
 }

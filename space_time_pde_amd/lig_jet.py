@@ -420,8 +420,12 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return s
 
 
-def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
-    """_backward_chunk through ONE library call (+ allocation of its scratch)."""
+def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None):
+    """_backward_chunk through ONE library call (+ allocation of its scratch).
+
+    after_dlatent (callable or None): "dgrad-first" order in TWO calls -- phase A runs the whole input-gradient chain into
+    fresh adjoint buffers and finishes d latent, after_dlatent() is called (the point-sharded step starts the all-reduce of
+    d latent there), phase B computes the remaining weight gradients while that all-reduce is in flight."""
     plan, S = meta.plan, meta.S
     Pc, ws, gd = saved["Pc"], saved["ws"], saved["gd"]
     nt = Pc // 2
@@ -446,10 +450,24 @@ def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None)
         nb = int(_lib.lib().stpde_lig_sort_tmp_bytes(Pc, n_nodes))
         ws.sort_tmp, ws.sort_tmp_bytes = buf(nb, torch.uint8), nb
     pd = _plan_desc(meta, packs)
-    check(_lib.lib().stpde_lig_imnet_jet_bwd(C.byref(pd), C.byref(meta.cfg), C.byref(meta.cfg_out), C.byref(meta.cfg_val),
-                                             C.byref(gd), C.byref(ws), C.c_void_p(jets_bar.data_ptr() + 4 * saved["p0"]),
-                                             jets_bar.shape[2], ptr(dw_flat), ptr(dlatent), ptr(pbar), _flags(meta, True),
-                                             stream_ptr()))
+    flags = _flags(meta, True)
+    two_phase = (after_dlatent is not None and fused_tail and tan0_rowsum and plan.nf in (16, 32) and SP0 in (1, 4)
+                 and (meta.cfg.S1, meta.cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2)) and (meta.cfg.S2 != 1 or saved["cw"] is not None))
+
+    def call(fl):
+        check(_lib.lib().stpde_lig_imnet_jet_bwd(C.byref(pd), C.byref(meta.cfg), C.byref(meta.cfg_out), C.byref(meta.cfg_val),
+                                                 C.byref(gd), C.byref(ws), C.c_void_p(jets_bar.data_ptr() + 4 * saved["p0"]),
+                                                 jets_bar.shape[2], ptr(dw_flat), ptr(dlatent), ptr(pbar), fl, stream_ptr()))
+
+    if two_phase:
+        ws.abar1x, ws.abar0x = buf(saved["bufs"][1].numel()), buf(nt * MT0 * _FRAG)
+        call(flags | _lib.F_PHASE_A)
+        after_dlatent()
+        call(flags | _lib.F_PHASE_B)
+    else:
+        call(flags)
+        if after_dlatent is not None:
+            after_dlatent()
 
 
 def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
@@ -525,11 +543,11 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw, z0=z0)
 
 
-def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
+def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None):
     """reduce_bwd -> for l = 5..1: wgrad_l (reads abar_l and the still intact pre-activations of layer l-1), then
     dgrad_l (overwrites them with abar_{l-1}) -> wgrad_0 -> xbar/scatter."""
     if "ws" in saved:
-        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar)
+        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar, after_dlatent)
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()
@@ -627,7 +645,13 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None):
                 start = torch.cumsum(counts, 0, dtype=torch.int32)     # start[c] = number of points in cells < c
                 check(L.stpde_lig_dlatent_reduce(meta.B, meta.grid_shape[0], meta.grid_shape[1], meta.grid_shape[2],
                                                  plan.cin, ptr(xrows), ptr(perm), ptr(start), ptr(dlatent), st))
+    if after_dlatent is not None:      # per-kernel (profiling) path: weight gradients first, nothing left to overlap
+        after_dlatent()
 
+
+# {"dlatent": f(tensor) -> work | None, "dw": f(tensor) -> work | None}: collectives of the point-sharded step, started from
+# inside the backward (set / cleared by train_step.sharded_step; the first LigJetFunction.backward of the step consumes them)
+sync_hooks = None
 
 stats = {"recompute_steps": 0}     # calls whose backward rebuilt the stash chunk by chunk (memory plan below)
 
@@ -727,18 +751,42 @@ class LigJetFunction(torch.autograd.Function):
         dw_flat = torch.zeros(meta.plan.n_dw, device=dev) if meta.need_wgrad else None
         dlatent = torch.zeros(ctx.lat_shape, device=dev) if need_lat else None
         pbar = torch.zeros(_lib.PBAR_SLOTS, device=dev) if ctx.needs_input_grad[3] else None
+        # Point-sharded multi-GPU step (train_step.sharded_step sets ``sync_hooks``): the all-reduce of the partial d latent is
+        # started as soon as the LAST chunk has finished it and runs behind that chunk's weight gradients (dgrad-first order);
+        # the IM-NET gradients are all-reduced in place in their flat buffer before they are unpacked.
+        hooks = sync_hooks if (sync_hooks and not sync_hooks.get("used")) else None
+        works = []
+
+        def start_dlatent_sync():
+            if hooks and need_lat and hooks.get("dlatent"):
+                works.append(hooks["dlatent"](dlatent))
+                hooks["dlatent_done"] = True
+
         if rebuild:
             latent, pts = ctx.inputs
             scratch = torch.empty(meta.S_out, meta.plan.cout, pts.shape[0], device=pts.device)
-            for p0 in range(0, pts.shape[0], meta.chunk):
+            starts = list(range(0, pts.shape[0], meta.chunk))
+            for p0 in starts:
                 s = _forward_chunk(meta, ctx.packs, latent, pts[p0:p0 + meta.chunk], scratch, p0, True)
-                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar)
+                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
+                                start_dlatent_sync if (hooks and p0 == starts[-1]) else None)
                 s = None
         else:
-            for s in ctx.saved:
-                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar)
+            for k, s in enumerate(ctx.saved):
+                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
+                                start_dlatent_sync if (hooks and k == len(ctx.saved) - 1) else None)
                 s["bufs"] = s["z0"] = None  # release the stash chunk by chunk
         ctx.saved = []
+        if hooks:
+            hooks["used"] = True
+            if meta.need_wgrad and hooks.get("dw"):
+                works.append(hooks["dw"](dw_flat))
+                if pbar is not None:                      # adjoint of the learnable swish beta: same treatment
+                    works.append(hooks["dw"](pbar))
+                hooks["dw_done"] = True
+            for wk in works:
+                if wk is not None:
+                    wk.wait()
         grads = [None] * ctx.n_params
         if meta.need_wgrad:
             g = meta.plan.unpack_grads(dw_flat, ctx.params)

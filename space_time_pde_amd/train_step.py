@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, lig_jet
 from .local_implicit_grid import query_local_implicit_grid
 
 
@@ -29,6 +29,9 @@ class _SumGradAcrossRanks(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        hooks = lig_jet.sync_hooks
+        if hooks and hooks.get("dlatent_done"):
+            return g          # already summed over ranks inside the HIP backward (behind the IM-NET weight gradients)
         g = g.contiguous()
         dist.all_reduce(g)
         return g
@@ -121,8 +124,17 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
     stack = base if (base is not None and base.numel() == sum(r.numel() for r in res)) else torch.stack(res, dim=0)
     pde = loss_sum(stack, None, loss_type) / (len(res) * b * n_points_global)
     loss = alpha_reg * reg + alpha_pde * pde
-    loss.backward()
-    if distributed:
+    hooks = None
+    if distributed and os.environ.get("STPDE_OVERLAP_SYNC", "1") != "0":
+        # collectives issued from inside the HIP backward: d latent asynchronously behind the IM-NET weight gradients, the
+        # IM-NET gradients in place in their flat buffer (no cat / copy-back); both are waited for before backward returns
+        hooks = dict(dlatent=lambda t: dist.all_reduce(t, async_op=True), dw=lambda t: dist.all_reduce(t, async_op=True))
+    lig_jet.sync_hooks = hooks
+    try:
+        loss.backward()
+    finally:
+        lig_jet.sync_hooks = None
+    if distributed and not (hooks and hooks.get("dw_done")):
         grads = [p.grad for p in imnet.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat)
@@ -130,6 +142,7 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
         for g in grads:
             g.copy_(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
+    if distributed:
         if sync_unet_grads:
             ug = [p.grad for p in unet.parameters() if p.grad is not None]
             uflat = torch.cat([g.reshape(-1) for g in ug])

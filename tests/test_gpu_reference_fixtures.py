@@ -244,6 +244,48 @@ def test_one_call_per_direction_equals_the_per_kernel_path(hiplib, act, monkeypa
         assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
 
 
+@pytest.mark.parametrize("act", ["softplus", "leakyrelu", "swish"])
+def test_dgrad_first_two_phase_backward_equals_one_call(hiplib, act):
+    """The order the point-sharded step uses (train_step.sharded_step -> lig_jet.sync_hooks): phase A = the whole
+    input-gradient chain into fresh adjoint buffers + d latent, then the collective hook, then phase B = the weight gradients
+    (stpde_lig_imnet_jet_bwd with STPDE_F_PHASE_A / _B, stpde_jet_layer_bwd_to).  With no-op hooks on one rank the result must
+    equal the one-call order: d latent bit for bit, weight gradients to fp32-atomic rounding; the hooks must see d latent
+    complete (first hook) and the finished flat IM-NET gradient."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, nonlinearities
+    g = torch.Generator().manual_seed(61)
+    lat = 0.5 * torch.randn(1, 4, 5, 6, 32, generator=g)
+    pts = 0.02 + 0.96 * torch.rand(1, 900, 3, generator=g)
+    torch.manual_seed(8)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES[act]).to(DEV)
+    combo = {(1, 1): 1.0, (2, 2): 0.25}
+    out, cot, seen = [], None, []
+    for two_phase in (False, True):
+        for p in net.parameters():
+            p.grad = None
+        latd = lat.to(DEV).requires_grad_(True)
+        jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=512, combo=combo)
+        if cot is None:
+            cot = torch.randn(jets.shape, generator=g).to(DEV)
+        if two_phase:
+            lig_jet.sync_hooks = dict(dlatent=lambda t: seen.append(("dlatent", t.clone())) or None,
+                                      dw=lambda t: seen.append(("dw", t.numel())) or None)
+        try:
+            with _lib.dispatch_trace() as tr:
+                (jets * cot).sum().backward()
+                torch.cuda.synchronize()
+        finally:
+            hooks, lig_jet.sync_hooks = lig_jet.sync_hooks, None
+        if two_phase:
+            assert hooks["used"] and hooks["dlatent_done"] and hooks["dw_done"]
+            assert tr.has("k_layer_coop", "EPI = 1") and tr.has("k_tail_bwd"), "\n".join(tr.kernels)
+        out.append((latd.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+    assert seen[0][0] == "dlatent" and torch.equal(seen[0][1], out[1][0])          # complete when the hook fires
+    assert torch.equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+
+
 def test_cell_sort_on_device_matches_torch(hiplib):
     """stpde_lig_cell_sort: stable order of the points by cell + exclusive cell offsets == torch.sort(stable) + bincount."""
     import ctypes as C
