@@ -14,10 +14,15 @@
 //              4 k-tile pairs deep that runs across steps and row tiles (the weights do not depend on the tile), then the
 //              skip GEMM / tangent constants / stores of the finished tile
 // Every SIMD hosts one producer and one consumer wave, so its VALU and MFMA pipes work at the same time; one barrier per
-// step.  Arithmetic (operand rounding, accumulation order over the k-tile pairs) is exactly that of
-// k_layer_coop<..., BF = true>: results are bit-identical.
+// step.  Arithmetic: operand rounding and the accumulation order over the k-tile pairs are those of
+// k_layer_coop<..., BF = true>; the skip GEMM is added during the steps instead of after the last one (fp32 rounding only).
+// Measured (tools/micro/ablate_layer.py stamp_spec, profiles/r3_stamp_fc1_fwd_spec.txt): a step takes 3.0-3.5 k cycles for
+// either role against 2.2 k cycles of MFMA-pipe time per SIMD (80 bf16 + 18-27 fp32 MFMAs) and 1.5 k of VALU time: 29.8 ->
+// 23.2 ms per 2^20 points.  Tried without effect: s_setprio on either role, 8 waves x 2 output tiles at 4 waves per SIMD for
+// the cooperative kernel (slower), persistent workgroups for the cooperative kernel (+-0).
 #pragma once
 #include <type_traits>
+
 
 // NST = steps (groups of 8 k-tiles) per row tile = KT / 8, compile-time so that every ring / register-array index is static.
 // Nothing in the producers' loop reads global memory except the prefetch of the next tile's raw input: their layer-0 weight

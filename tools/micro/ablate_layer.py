@@ -36,15 +36,15 @@ def build():
         print("variant", n, "rc", p.returncode, out.decode()[-300:] if p.returncode else "")
 
 
-def build_stamp():
+def build_stamp(extra=(), tag="stamp"):
     os.makedirs(OUT, exist_ok=True)
-    so = os.path.join(OUT, "libabl_stamp.so")
+    so = os.path.join(OUT, "libabl_%s.so" % tag)
     srcs = [os.path.join(CSRC, f) for f in ("jet_layer.hip", "jet_layer_s31.hip", "api.cpp")]
     stub = os.path.join(OUT, "stub.cpp")
     open(stub, "w").write('#include <hip/hip_runtime.h>\nstruct LayerArgs;\n' + "".join(
         "int stpde_layer_launch_%s(const LayerArgs&, int, hipStream_t) { return 2; }\n" % k
         for k in ("0_0", "0_3", "3_0", "3_2", "3_6")))
-    r = subprocess.run(["hipcc"] + FLAGS + ["-DSTPDE_STAMP=1", "-shared", "-o", so] + srcs + [stub], stdout=subprocess.PIPE,
+    r = subprocess.run(["hipcc"] + FLAGS + ["-DSTPDE_STAMP=1"] + list(extra) + ["-shared", "-o", so] + srcs + [stub], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT)
     print("stamp build rc", r.returncode, r.stdout.decode()[-300:] if r.returncode else "")
 
@@ -111,7 +111,7 @@ def stamp(bf16=False):
         print("  %-18s n=%5d  mean %9.1f ticks" % ("TOTAL wave life", ok.sum(), tot[ok].mean()))
 
 
-def stamp_spec():
+def stamp_spec(tag="stamp"):
     """Step timeline of the wave-specialised bf16 forward (k_fc1_fwd_spec): iteration 64 of every workgroup; per role the mean
     cycles from the start of the iteration to the arrival at each step barrier and to its release."""
     import numpy as np
@@ -131,16 +131,21 @@ def stamp_spec():
     z0 = torch.empty(nt * plan.layers[0]["MT"] * 256, device=dev)
     pv = plan.pack_view
     p16 = plan.pack_bf16(packs, 1)
-    L = C.CDLL(os.path.join(OUT, "libabl_stamp.so"))
+    L = C.CDLL(os.path.join(OUT, "libabl_%s.so" % tag))
     L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
     d = _lib.LayerDesc()
     d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, 1
     p = _lib.ptr
-    for _ in range(2):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(3):
+        if it == 1:
+            e0.record()
         assert L.stpde_jet_layer_fwd(C.byref(d), None, p(X), p(pv(packs, 1, "Wh")), p(pv(packs, 1, "Ws")),
                                      p(pv(packs, 1, "tanc")), p(pv(packs, 0, "Ws")), p(pv(packs, 0, "tanc")), p(out1),
                                      p(cw), p(p16.get((1, "Wh"))), p(z0), _lib.stream_ptr()) == 0
+    e1.record()
     torch.cuda.synchronize()
+    print("== %s: %.3f ms per launch (2^18 points)" % (tag, e0.elapsed_time(e1) / 2))
     host = (C.c_ulonglong * (256 * 8 * 16))()
     assert L.stpde_stamp_read(host) == 0
     a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, 16).astype(np.int64)
@@ -219,7 +224,7 @@ if __name__ == "__main__":
         build()
         build_stamp()
     elif sys.argv[1] == "stamp_spec":
-        stamp_spec()
+        stamp_spec(sys.argv[2] if len(sys.argv) > 2 else "stamp")
     elif sys.argv[1] == "stamp":
         stamp(bf16="bf16" in sys.argv[2:])
     else:
