@@ -61,7 +61,20 @@ struct GatherArgs {
   float* cw;
 };
 
-// one thread per (tile, xt, lane): writes one float4 of X
+// Clipped coordinate and cell index of one dimension (the part of point_geom every lane needs): the same fp32 expression
+// sequence, so the index is bit-identical.
+__device__ __forceinline__ int cell_index_1d(float x, float lo, float hi, float cs, int n, float& q) {
+  q = fmaxf(fminf(x, hi), lo);
+  int i0 = (int)floorf(q / cs);
+  return i0 < 0 ? 0 : (i0 > n - 2 ? n - 2 : i0);        // only NaN / out-of-box inputs ever hit the clamp
+}
+
+// one thread per (tile, xt, lane): writes one float4 of X.
+// Round 3: a lane evaluates only what ITS slot needs -- the three IEEE divisions of the cell index always, the relative
+// coordinates only in the 16 lanes that hold them (tile 0, lane group 0), the full geometry (weights, weight derivatives,
+// clip derivative: 21 more divisions) only in the one lane per point that writes the coefficients (the first version ran
+// point_geom in all 192 lanes of a row tile).  Same results bit for bit; the launch time did not move (1.45 ms per 2^20
+// points either way): the kernel is bound by its 6 KiB of X / XR stores per point, not by the divisions.
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int ntiles = a.d.P / 2;
@@ -75,10 +88,13 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   const int bit[3] = {(corner >> 2) & 1, (corner >> 1) & 1, corner & 1};
   const int n[3] = {a.d.n0, a.d.n1, a.d.n2};
   float pt[3] = {a.pts[(size_t)p * 3], a.pts[(size_t)p * 3 + 1], a.pts[(size_t)p * 3 + 2]};
-  PointGeom gm = point_geom(pt, a.d.lo_c, a.d.hi_c, a.d.cube, n);
+  float q[3];
+  int i0[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) i0[d] = cell_index_1d(pt[d], a.d.lo_c[d], a.d.hi_c[d], a.d.cube[d], n[d], q[d]);
   int b = (a.d.p_base + p) / a.d.N;
   b = b > a.d.B - 1 ? a.d.B - 1 : b;
-  const size_t node0 = (((size_t)b * n[0] + gm.i0[0]) * n[1] + gm.i0[1]) * n[2] + gm.i0[2];
+  const size_t node0 = (((size_t)b * n[0] + i0[0]) * n[1] + i0[1]) * n[2] + i0[2];
   const size_t node = node0 + ((size_t)bit[0] * n[1] + bit[1]) * n[2] + bit[2];
   const int C = a.d.C;
   f32x4 v;
@@ -88,10 +104,14 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
     const int f = xt < XT - 1 ? 16 * xt + 4 * g + r : (r == 0 ? 16 * xt + g : 16 * XT);
     float val = 0.f;
     if (f < 3) {
-      const float r0 = bit[0] ? gm.rel[1][0] : gm.rel[0][0];
-      const float r1 = bit[1] ? gm.rel[1][1] : gm.rel[0][1];
-      const float r2 = bit[2] ? gm.rel[1][2] : gm.rel[0][2];
-      val = sel3(f, r0, r1, r2);
+      // relative coordinate of this corner along dimension f: (q - pos) / cube, pos = (i0 + bit) * cube (reference :69-76)
+      const float cs = sel3(f, a.d.cube[0], a.d.cube[1], a.d.cube[2]);
+      const float qq = sel3(f, q[0], q[1], q[2]);
+      const int ii = f == 0 ? i0[0] : (f == 1 ? i0[1] : i0[2]);
+      const int bb = f == 0 ? bit[0] : (f == 1 ? bit[1] : bit[2]);
+      const float i0f = (float)ii;
+      const float pos = bb ? (i0f + 1.f) * cs : i0f * cs;
+      val = (qq - pos) / cs;
     } else if (f < 3 + C)
       val = a.latent[node * C + (f - 3)];
     else if (f == 3 + C)
@@ -101,6 +121,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   st4(a.X + gid * 4, v);
   if (a.XR) st_R(a.XR + (gid >> 6) * 256, lane, v);
   if (xt == 0 && g == 0 && corner == 0) {
+    const PointGeom gm = point_geom(pt, a.d.lo_c, a.d.hi_c, a.d.cube, n);
     float* cf = a.coef + (size_t)p * 16;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {

@@ -12,17 +12,21 @@ import sys
 def parse(path):
     out = {}
     for ln in open(path).read().split("\n")[2:]:
-        m = re.match(r"(k_\w+<[^>]*>)\s+(\d+)\s+([\d.]+)\s+([\d.]+)", ln.strip())
+        m = re.match(r"(k_\w+(?:<[^>]*>|\([^)]*\)))\s+(\d+)\s+([\d.]+)\s+([\d.]+)", ln.strip())
         if m:
             out[m.group(1)] = float(m.group(4)) * 1024.0      # KiB per call -> bytes
     return out
 
 
 def bench_name(sym):
+    if sym.startswith("k_gather("):
+        return "gather"
+    if sym.startswith("k_fc1_fwd_spec<3,"):
+        return "layer1_fwd"
     if re.match(r"k_\w+<0,\d,", sym):      # value-only / value-tile kernels of bench.py's inference side figure, not the training step
         return None
     m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?(?:,[\w,]+)?>", sym)
-    if m and m.group(8) in (None, "false"):
+    if m and (m.group(8) in (None, "false") or BF16):
         pro, epi = int(m.group(4)), int(m.group(5))
         if pro == 2 and epi == 0:
             return "layer1_fwd"
@@ -33,12 +37,18 @@ def bench_name(sym):
     if m:
         return {2: "layer1_dgrad", 1: "layer2_dgrad"}.get(int(m.group(4)))
     m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+?)(?:,(\w+))?(?:,\d+)?>", sym)
-    if m and int(m.group(3)) == 1 and m.group(6) == "false" and m.group(7) in (None, "false"):
+    if m and int(m.group(3)) == 1 and m.group(6) == "false" and (m.group(7) in (None, "false") or BF16):
         return "layer1_wgrad"
+    if m and int(m.group(3)) == 0 and int(m.group(5)) == 4 and m.group(6) == "false" and (m.group(7) in (None, "false") or BF16):
+        return "layer2_wgrad"
     return None
 
 
+BF16 = False     # True (6th argument "bf16"): accept the bf16-operand instantiations (configs[3] profile)
+
+
 if __name__ == "__main__":
+    BF16 = len(sys.argv) > 6 and sys.argv[6] == "bf16"
     fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
     kernels = {}
     for sym in set(fetch) | set(write):
@@ -48,4 +58,4 @@ if __name__ == "__main__":
             kernels[name] = dict(symbol=sym, fetch_bytes_corrected=f, write_bytes=w, hbm_bytes_per_launch=f + w)
     json.dump(dict(chunk=int(sys.argv[3]), act=sys.argv[4], kernels=kernels,
                    source="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
-                          "profiles/r2_pmc_fetch_size.txt / r2_pmc_write_size.txt"), open(sys.argv[5], "w"), indent=1)
+                          "profiles/r3_pmc_fetch_size*.txt / r3_pmc_write_size*.txt"), open(sys.argv[5], "w"), indent=1)
