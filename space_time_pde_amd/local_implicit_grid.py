@@ -73,6 +73,41 @@ def _xmin_is_zero(xmin, xmax=None, shape3=None):
     return all(float(v) == 0 for v in xmin)
 
 
+def _query_data_parallel(dp, latent_grid, query_pts, xmin, xmax, req):
+    """The reference's default multi-GPU mechanism (experiments/rb2d/train.py:352-355 wraps the decoder in nn.DataParallel):
+    the rows of the decoder input are scattered over ``dp.device_ids``.  Here the QUERY POINTS are: every device gets a
+    replica of the IM-NET (``torch.nn.parallel.replicate``: gradients flow back to the wrapped module, summed), a copy of the
+    latent grid and its share of the points, and runs the HIP jet path on them; the jets are gathered on the first device.
+    One process drives all devices, as nn.DataParallel does (``train_step.sharded_step`` -- one process per GPU over RCCL --
+    is the scalable route)."""
+    devs = list(dp.device_ids)
+    B, N = query_pts.shape[0], query_pts.shape[1]
+    chunks = [c for c in torch.chunk(query_pts, len(devs), dim=1) if c.shape[1] > 0]
+    devs = devs[:len(chunks)]
+    replicas = torch.nn.parallel.replicate(dp.module, devs, detach=not torch.is_grad_enabled())
+    want_jets = req is not None and req.x is query_pts
+    outs, pairs = [], None
+    for rep, dev, pts_c in zip(replicas, devs, chunks):
+        d = torch.device("cuda", dev)
+        with torch.cuda.device(d):
+            lat_d, pts_d = latent_grid.to(d), pts_c.to(d).contiguous()
+            if want_jets:
+                jets, pairs = lig_jet.lig_jets(rep, lat_d, pts_d, xmin, xmax, req.first, req.pairs, combo=req.combo)
+            else:
+                jets, _ = lig_jet.lig_jets(rep, lat_d, pts_d, xmin, xmax, False, ())
+        # [S, n_out, B * n_d] (batch-major) -> [S, n_out, B, n_d] on the output device
+        outs.append(jets.reshape(jets.shape[0], jets.shape[1], B, pts_c.shape[1]).to(query_pts.device))
+    jets = torch.cat(outs, dim=3).reshape(outs[0].shape[0], outs[0].shape[1], B * N)
+    stats["data_parallel_calls"] = stats.get("data_parallel_calls", 0) + 1
+    y = jets[0].t().reshape(B, N, jets.shape[1])
+    if want_jets:
+        stats["hip_jet_calls"] += 1
+        req.y, req.jets, req.pairs_out = y, jets, pairs
+    else:
+        stats["hip_value_calls"] += 1
+    return y
+
+
 def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
     """Query a local implicit grid: y = sum_j w_j * model([x_rel_j ; latent_j]) (reference :47-59).
 
@@ -84,6 +119,10 @@ def query_local_implicit_grid(model, latent_grid, query_pts, xmin, xmax):
     # wrapper is the identity, so the HIP path reads the wrapped module's parameters directly
     if isinstance(model, torch.nn.DataParallel) and len(model.device_ids or []) <= 1:
         model = model.module
+    if isinstance(model, torch.nn.DataParallel) and _fast_eligible(model.module, latent_grid, query_pts) \
+            and _xmin_is_zero(xmin, xmax, tuple(latent_grid.shape[1:4])) \
+            and ((req is not None and req.x is query_pts) or not (query_pts.requires_grad and torch.is_grad_enabled())):
+        return _query_data_parallel(model, latent_grid, query_pts, xmin, xmax, req)
     if _fast_eligible(model, latent_grid, query_pts) and _xmin_is_zero(xmin, xmax, tuple(latent_grid.shape[1:4])):
         wants_point_grad = query_pts.requires_grad and torch.is_grad_enabled()
         if req is not None and req.x is query_pts:
