@@ -387,10 +387,14 @@ def main(argv=None):
             if by:
                 gbs = by * rows_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e9
                 roofline.update(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
-                                traffic=None, traffic_source=None,
                                 note="bf16-MFMA mode: achieved = algorithmic stash bytes of the dominant kernel / launch "
-                                     "time; MFMA-side figures (executed_tflops vs the 2500 TFLOP/s bf16 peak) for reference",
+                                     "time; traffic = its measured HBM bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same "
+                                     "configuration) when committed; MFMA-side figures (executed_tflops vs the 2500 TFLOP/s "
+                                     "bf16 peak) for reference",
                                 executed_frac=round(exe / 2500.0, 4), bytes_per_launch=by * rows_per_launch)
+                if traffic:
+                    roofline["measured_GBps"] = round(traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e9, 1)
+                    roofline["measured_frac"] = round(traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / 8000.0, 4)
                 roofline.pop("step_frac_per_gpu", None)
         if args.mlp_precision == "fp32x3":
             # exact-split mode: the wide layers issue SIX bf16 MFMA products per fp32 product, so the pipe that bounds them is
