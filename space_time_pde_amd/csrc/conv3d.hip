@@ -44,6 +44,36 @@ __device__ __forceinline__ int tap_neighbour(const stpde_conv3d_desc& d, const V
   return ((c.b * d.T + t) * d.Z + z) * d.X + x;
 }
 
+// Cheap neighbour indexing (round 3): the linear index of a voxel and nine validity bits (bit 3 * dim + delta + 1: the
+// neighbour at delta = -1 / 0 / +1 along dim exists) are computed ONCE per voxel; a tap then costs an AND, a compare, an add
+// and a select instead of the ~15 integer instructions of tap_neighbour -- on the fp32 MFMA every VALU instruction is paid in
+// MFMA time, and the 16-channel 3x3x3 convolutions of the full-resolution levels spent more cycles on indices than on MFMAs.
+struct VoxN {
+  int lin;
+  unsigned ok;
+};
+__device__ __forceinline__ VoxN vox_prepare(const stpde_conv3d_desc& d, const Vox& c) {
+  VoxN v;
+  v.lin = ((c.b * d.T + c.t) * d.Z + c.z) * d.X + c.x;
+  v.ok = (c.t > 0 ? 1u : 0u) | 2u | (c.t + 1 < d.T ? 4u : 0u) | (c.z > 0 ? 8u : 0u) | 16u | (c.z + 1 < d.Z ? 32u : 0u) |
+         (c.x > 0 ? 64u : 0u) | 128u | (c.x + 1 < d.X ? 256u : 0u);
+  return v;
+}
+// wave-uniform part of a tap: validity mask and linear offset
+__device__ __forceinline__ void tap_uniform(const stpde_conv3d_desc& d, int tap, unsigned& mask, int& off) {
+  if (d.ksize == 1) {
+    mask = 0u;
+    off = 0;
+    return;
+  }
+  const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+  mask = (1u << (dt + 1)) | (1u << (3 + dz + 1)) | (1u << (6 + dx + 1));
+  off = (dt * d.Z + dz) * d.X + dx;
+}
+__device__ __forceinline__ int tap_nb(const VoxN& v, unsigned mask, int off) {
+  return (v.ok & mask) == mask ? v.lin + off : -1;
+}
+
 // VT voxel tiles (16 voxels each) per wave: every weight block that is loaded feeds VT*4 MFMAs per output tile.
 // SPLIT (small volumes = the deep U-Net levels, where a handful of waves would otherwise walk 27 taps x all channel
 // tiles serially): blockIdx.z owns a slice of the taps and adds its partial sums to the zero-filled output with fp32
@@ -59,12 +89,13 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
   const int ntap = a.d.ksize == 3 ? 27 : 1;
   int v[VT];
   bool vin[VT];
-  Vox c[VT];
+  VoxN vn[VT];
 #pragma unroll
   for (int t = 0; t < VT; ++t) {
     v[t] = (tile0 + t) * 16 + j;
     vin[t] = v[t] < a.nvox;
-    c[t] = vox_coords(a.d, vin[t] ? v[t] : 0);
+    vn[t] = vox_prepare(a.d, vox_coords(a.d, vin[t] ? v[t] : 0));
+    if (!vin[t]) vn[t].ok = 0u;          // voxels past the end: no tap is valid (ksize 1 handled below)
   }
   // large volumes: one wave walks all output-channel chunks of its voxels (inputs stay hot in L1);
   // small volumes (deep U-Net levels): the chunks are spread over blockIdx.y so that the chip is not idle
@@ -80,9 +111,12 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
       int nb[VT];
       const float* src[VT];
+      unsigned tmask;
+      int toff;
+      tap_uniform(a.d, tap, tmask, toff);
 #pragma unroll
       for (int t = 0; t < VT; ++t) {
-        nb[t] = vin[t] ? tap_neighbour(a.d, c[t], tap) : -1;
+        nb[t] = vin[t] ? tap_nb(vn[t], tmask, toff) : -1;
         src[t] = a.x + (size_t)(nb[t] < 0 ? 0 : nb[t]) * Ci + 4 * g;
       }
       if (SPLIT && VT == 1 && __ballot(nb[0] >= 0) == 0) continue;   // wave-uniform: nothing to add for this tap
@@ -152,34 +186,68 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
 #pragma unroll
       for (int ki = 0; ki < KCW; ++ki) acc[tg][mi][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (a.nvox + 15) / 16;
-#pragma unroll 1
-  for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
+  // Operand fragments of one voxel tile: 4 k-steps (4 voxels each) x (MCW ybar + TG * KCW shifted-x dwords).
+  struct Frag {
+    float pa[4][MCW];
+    float qb[4][TG][KCW];
+  };
+  unsigned tmask[TG];
+  int toff[TG];
+#pragma unroll
+  for (int tg = 0; tg < TG; ++tg) tap_uniform(a.d, tap0 + tg, tmask[tg], toff[tg]);
+  auto load = [&](int tile, Frag& f) {
+    // coordinates of this lane's voxel of k-step 0 by division, of the following k-steps (+4 voxels each) by carry
+    const int v0 = tile * 16 + kk;
+    Vox c = vox_coords(a.d, v0 < a.nvox ? v0 : 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int v = tile * 16 + 4 * s + kk;
+      const int v = v0 + 4 * s;
       const bool vin = v < a.nvox;
-      const Vox c = vox_coords(a.d, vin ? v : 0);
-      float pa[MCW];
+      if (s > 0) {
+        c.x += 4;
+        while (c.x >= a.d.X) {          // X may be smaller than 4 on the deepest levels
+          c.x -= a.d.X;
+          if (++c.z >= a.d.Z) {
+            c.z = 0;
+            if (++c.t >= a.d.T) {
+              c.t = 0;
+              ++c.b;
+            }
+          }
+        }
+      }
+      const VoxN vn = vox_prepare(a.d, c);
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         const int mt = mb * MCW + mi;
-        pa[mi] = (vin && mt < MT) ? a.ybar[(size_t)v * Co + 16 * mt + i] : 0.f;
+        f.pa[s][mi] = (vin && mt < MT) ? a.ybar[(size_t)v * Co + 16 * mt + i] : 0.f;
       }
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg) {
-        const int nb = vin ? tap_neighbour(a.d, c, tap0 + tg) : -1;
-        float qb[KCW];
+        const int nb = vin ? tap_nb(vn, tmask[tg], toff[tg]) : -1;
 #pragma unroll
         for (int ki = 0; ki < KCW; ++ki) {
           const int kt = kb * KCW + ki;
-          qb[ki] = (nb >= 0 && kt < KT) ? a.x[(size_t)nb * Ci + 16 * kt + i] : 0.f;
+          f.qb[s][tg][ki] = (nb >= 0 && kt < KT) ? a.x[(size_t)nb * Ci + 16 * kt + i] : 0.f;
         }
+      }
+    }
+  };
+  // (prefetching the next tile's fragments while the MFMAs of the current one run was measured: no gain, one wave per
+  // SIMD less -- the kernel is bound by its index / address arithmetic and, for 32 channels, by re-reading the activations
+  // once per tap group)
+#pragma unroll 1
+  for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
+    Frag cur;
+    load(tile, cur);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg)
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
-          for (int ki = 0; ki < KCW; ++ki) acc[tg][mi][ki] = mfma4(pa[mi], qb[ki], acc[tg][mi][ki]);
-      }
-    }
+          for (int ki = 0; ki < KCW; ++ki) acc[tg][mi][ki] = mfma4(cur.pa[s][mi], cur.qb[s][tg][ki], acc[tg][mi][ki]);
   }
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
