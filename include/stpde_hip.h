@@ -112,6 +112,13 @@ typedef struct {
    * below 2^-24 of the result, i.e. below fp32 rounding.  6 bf16 MFMAs (K = 32) replace 8 fp32 MFMAs at 1/16 of the
    * per-instruction time. */
   int mfma_bf16;
+  /* PACKED layer buffers (round 3, bf16 mode only): a buffer whose every consumer is a bf16-operand kernel may keep its
+   * value stream in fp32 and its derivative streams in bf16 -- per row tile [MT][64][4] fp32, then [S-1][MT][64][4] bf16,
+   * MT * (1024 + (S-1) * 512) bytes instead of MT * S * 1024.  Bit mask: 1 = in_pre (hidden input / the pre-activations a
+   * backward kernel takes its adjoint against) is packed, 2 = the buffer this call WRITES (out_pre of a forward call, the
+   * adjoint destination of stpde_jet_layer_bwd / _bwd_to) is packed, 4 = abar_out (input of the backward / weight-gradient
+   * kernels) is packed. */
+  int packed;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
  * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16.
@@ -200,6 +207,8 @@ typedef struct {
   int ntiles, nlayers, C, n1, n2;
   int MT[8];
   int SP[8];
+  int packed[8];   /* != 0: abar[l] is a packed layer buffer (stpde_layer_desc.packed) of S[l] streams */
+  int S[8];        /* streams of a packed buffer (only read where packed[l] != 0) */
 } stpde_xbar_desc;
 /* abar / WsL_pack: HOST arrays of nlayers device pointers.  WsL_pack[l] = [MT_l][XL][64 lanes][4]: A operand of W_s,l^T
  * restricted to the latent channels, XL = ceil(C / 16) tiles of 16 channels (lane (g, j), register r holds
@@ -241,6 +250,8 @@ typedef struct {
   const void* Wh16[8];         /* bf16 packs of the wide layers or NULL */
   const void* WhT16[8];
   int mfma_bf16;               /* 0 / 1 / 3 as stpde_layer_desc.mfma_bf16 */
+  int packed_mask;             /* bit l: pre[l] (and the adjoint buffers that replace it) is a packed layer buffer
+                                  (stpde_layer_desc.packed); only with mfma_bf16 == 1 and bf16-operand kernels on both sides */
   long dw_off[8];              /* offset (floats) of layer l's dW_aug block [16 MT][16 (KT + 3)] in dW_flat */
 } stpde_imnet_plan;
 typedef struct {

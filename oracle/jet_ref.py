@@ -64,13 +64,16 @@ def round_bf16(t):
     return t.float().to(torch.bfloat16).to(t.dtype)
 
 
-def mlp_jets(params, act_name, x, dim, second, beta=None, bf16_layers=()):
+def mlp_jets(params, act_name, x, dim, second, beta=None, bf16_layers=(), bf16_pre_tangents=()):
     """Jets of IM-NET w.r.t. its first ``dim`` inputs.
 
     x [rows, dim+c].  Returns list of streams, each [rows, out]: [value, d/dr_0..d/dr_{dim-1}, d2/dr_a dr_b for
     (a,b) in second].
     bf16_layers: layer indices whose hidden-to-hidden product is taken on bf16-rounded operands (weights and input
     streams), accumulated in the working precision -- the emulation of the library's config-4 "bf16 MFMA" mode.
+    bf16_pre_tangents: layer indices whose OUTPUT pre-activations are kept in the library's packed form (round 3: value
+    stream fp32, derivative streams rounded to bf16 when they are stored) -- every later use of those derivative streams sees
+    the rounded values.
     """
     rows = x.shape[0]
     nlayers = len(params)
@@ -98,6 +101,8 @@ def mlp_jets(params, act_name, x, dim, second, beta=None, bf16_layers=()):
                 ad = [ad[d] + ws[:, d].unsqueeze(0) for d in range(dim)]
         if last:
             return [a] + ad + add
+        if l in bf16_pre_tangents:
+            ad, add = [round_bf16(t) for t in ad], [round_bf16(t) for t in add]
         s0, s1, s2, _ = act_derivs(act_name, a, beta)
         h = s0
         hd = [s1 * t for t in ad]
@@ -105,7 +110,7 @@ def mlp_jets(params, act_name, x, dim, second, beta=None, bf16_layers=()):
 
 
 def lig_jets(params, act_name, latent_grid, pts, xmin=0.0, xmax=1.0, second=((1, 1), (2, 2)), beta=None,
-             bf16_layers=()):
+             bf16_layers=(), bf16_pre_tangents=()):
     """Jets of y = query_local_implicit_grid(...) w.r.t. the query point coordinates.
 
     latent_grid [b, n1..nd, c], pts [b,p,d].  Returns tensor [S, b, p, out] with S = 1 + d + len(second):
@@ -142,7 +147,8 @@ def lig_jets(params, act_name, latent_grid, pts, xmin=0.0, xmax=1.0, second=((1,
         dom = torch.sign(t) / cube * s                            # d omega / d q (abs'(0)=0, quirk a-Q3)
         rel = (q - pos) / cube
         x = torch.cat([rel, lat], dim=-1).reshape(b * p, -1)
-        f = [t_.reshape(b, p, -1) for t_ in mlp_jets(params, act_name, x, dim, list(second), beta, bf16_layers)]
+        f = [t_.reshape(b, p, -1) for t_ in mlp_jets(params, act_name, x, dim, list(second), beta, bf16_layers,
+                                                          bf16_pre_tangents)]
         w = torch.prod(om, dim=-1, keepdim=True)
 
         def dw(d):

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libstpde_hip.so")
 _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
-ABI_VERSION = 302   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 303   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
@@ -35,19 +35,19 @@ class GatherDesc(C.Structure):
 
 class LayerDesc(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg),
-                ("mfma_bf16", C.c_int)]
+                ("mfma_bf16", C.c_int), ("packed", C.c_int)]
 
 
 class XbarDesc(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("nlayers", C.c_int), ("C", C.c_int), ("n1", C.c_int), ("n2", C.c_int),
-                ("MT", C.c_int * 8), ("SP", C.c_int * 8)]
+                ("MT", C.c_int * 8), ("SP", C.c_int * 8), ("packed", C.c_int * 8), ("S", C.c_int * 8)]
 
 
 class ImNetPlanDesc(C.Structure):       # stpde_imnet_plan
     _fields_ = [("nlayers", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("nf16", C.c_int), ("KT", C.c_int * 8),
                 ("MT", C.c_int * 8), ("Wh", C.c_void_p * 8), ("WhT", C.c_void_p * 8), ("Ws", C.c_void_p * 8),
                 ("WsL", C.c_void_p * 8), ("tanc", C.c_void_p * 8), ("Wh16", C.c_void_p * 8), ("WhT16", C.c_void_p * 8),
-                ("mfma_bf16", C.c_int), ("dw_off", C.c_long * 8)]
+                ("mfma_bf16", C.c_int), ("packed_mask", C.c_int), ("dw_off", C.c_long * 8)]
 
 
 class LigWorkspace(C.Structure):        # stpde_lig_workspace

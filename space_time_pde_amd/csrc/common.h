@@ -54,6 +54,46 @@ __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// PACKED layer buffers (round 3, bf16 mode): a buffer that is only ever consumed as a bf16 MFMA operand or as the argument of
+// an activation jet keeps its VALUE stream in fp32 and its derivative streams in bf16 --
+//   tile t:  [MT][64 lanes][4] fp32 (stream 0)  then  [S - 1][MT][64 lanes][4] bf16 (streams 1 .. S-1)
+// = MT * (1024 + (S - 1) * 512) bytes per row tile instead of MT * S * 1024: -40 % of the bytes of the HBM-bound kernels
+// around the widest stash (S = 5).  `packed` is wave-uniform; `st` is a compile-time index at every call site.
+__host__ __device__ inline size_t packed_tile_bytes(int S, int MT) { return (size_t)MT * (1024 + (S - 1) * 512); }
+__device__ __forceinline__ f32x4 ld_blk(const float* buf, bool packed, size_t tile, int S, int MT, int st, int mt, int lane) {
+  if (!packed) return ld4(buf + ((tile * S + st) * MT + mt) * 256 + lane * 4);
+  const char* t = reinterpret_cast<const char*>(buf) + tile * packed_tile_bytes(S, MT);
+  if (st == 0) return ld4(reinterpret_cast<const float*>(t + (size_t)mt * 1024) + lane * 4);
+  return bf4_to_f32(*reinterpret_cast<const bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8));
+}
+// The same load WITHOUT the bf16 -> fp32 conversion of a packed derivative block: the 8 bytes land in the first two
+// registers of the result and blk_val() converts them where the value is used -- for loads that are issued a whole row tile
+// ahead of their use (weight-gradient P operand), where a conversion at the load site would wait for the load at once.
+__device__ __forceinline__ f32x4 ld_blk_raw(const float* buf, bool packed, size_t tile, int S, int MT, int st, int mt, int lane) {
+  if (!packed || st == 0) return ld_blk(buf, packed, tile, S, MT, st, mt, lane);
+  const char* t = reinterpret_cast<const char*>(buf) + tile * packed_tile_bytes(S, MT);
+  const float2 v = *reinterpret_cast<const float2*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8);
+  return f32x4{v.x, v.y, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 blk_val(f32x4 raw, bool packed, int st) {
+  if (!packed || st == 0) return raw;
+  float2 v;
+  v.x = raw[0];
+  v.y = raw[1];
+  return bf4_to_f32(__builtin_bit_cast(bf16x4, v));
+}
+__device__ __forceinline__ void st_blk(float* buf, bool packed, size_t tile, int S, int MT, int st, int mt, int lane, f32x4 v) {
+  if (!packed) {
+    st4(buf + ((tile * S + st) * MT + mt) * 256 + lane * 4, v);
+    return;
+  }
+  char* t = reinterpret_cast<char*>(buf) + tile * packed_tile_bytes(S, MT);
+  if (st == 0)
+    st4(reinterpret_cast<float*>(t + (size_t)mt * 1024) + lane * 4, v);
+  else
+    *reinterpret_cast<bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8) = to_bf4(v);
+}
+
 // Optional 16-byte stores without a branch: a raw buffer descriptor over [base, base + bytes) -- built from wave-uniform
 // values only -- drops every store that falls outside it, so bytes = 0 switches the stores off in hardware and the
 // surrounding basic block stays in one piece (a uniform `if (ptr)` would split the MFMA / VALU interleaving of the loop).
@@ -77,6 +117,10 @@ __device__ __forceinline__ u32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, int lane_byt
 }
 __device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_byte_off, uniform_byte_off, 0);
+}
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void buf_st8(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off, bf16x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane_byte_off, uniform_byte_off, 0);
 }
 __device__ __forceinline__ void opt_st4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);

@@ -52,6 +52,7 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
   a.MT = d->MT;
   a.ntiles = d->ntiles;
   a.cfg = d->cfg;
+  a.pk = d->packed & 3;      // 1: in_pre packed, 2: out_pre packed
   if (!X || !Ws_pack || !out_pre || (d->cfg.S1 && !tanc)) {
     stpde_set_error("jet_layer_fwd: null pointer");
     return STPDE_E_BADARG;
@@ -116,6 +117,8 @@ static int layer_bwd(const stpde_layer_desc* d, const float* abar_out, const flo
   a.MT = d->KT;
   a.ntiles = d->ntiles;
   a.cfg = d->cfg;
+  // abar_out is this kernel's B operand, in_pre what the adjoint is taken against, abar_in where it goes
+  a.pk = ((d->packed & 4) ? 1 : 0) | ((d->packed & 2) ? 2 : 0) | ((d->packed & 1) ? 4 : 0);
   if (!abar_out || !WhT_pack || d->KT <= 0) {
     stpde_set_error("jet_layer_bwd: null pointer / no hidden input");
     return STPDE_E_BADARG;

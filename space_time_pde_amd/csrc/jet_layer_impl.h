@@ -62,6 +62,7 @@ struct LayerArgs {
                        // (may alias Out when Out holds the value stream only: each lane reads its element before it writes it)
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
+  int pk;              // packed-buffer flags (common.h: ld_blk / st_blk): 1 = Bin, 2 = Out, 4 = Pre
   stpde_jet_cfg cfg;
 };
 
@@ -82,7 +83,9 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 // Epilogue of one output tile `mt` held in acc[S] (D image): forward = skip GEMM + tangent constants + store of the
 // pre-activations; dgrad = activation-jet adjoint against the stored pre-activations (first hidden layer: the z0 stash of
 // the forward kernel + the constant tangent columns; its tangent-stream adjoints leave as per-tile row sums).
-template <int S1, int S2, int EPI, int ACT>
+// PKM: compile-time packed-buffer mask (LayerArgs.pk: 2 = Out, 4 = Pre); a run-time flag would put a branch in front of every
+// block load / store and split the MFMA basic blocks (measured: +40 % on the kernels that took it)
+template <int S1, int S2, int EPI, int ACT, int PKM = 0>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
                                                const f32x4 (*xbv)[XT], const float* cq, float& pacc) {
   constexpr int S = 1 + S1 + S2;
@@ -104,12 +107,12 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         for (int d = 0; d < 3; ++d) acc[mi][1 + d] += ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
       }
 #pragma unroll
-      for (int st = 0; st < S; ++st) st4(a.Out + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[mi][st]);
+      for (int st = 0; st < S; ++st) st_blk(a.Out, (PKM & 2) != 0, tile, S, MT, st, mt, lane, acc[mi][st]);
     } else {
       f32x4 pre[S], ab[S];
       if (EPI == EPI_ADJ) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Pre + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Pre, (PKM & 4) != 0, tile, S, MT, st, mt, lane);
       } else {
         pre[0] = ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {
@@ -140,7 +143,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         }
       } else {
 #pragma unroll
-        for (int st = 0; st < SO; ++st) st4(a.Out + (((size_t)tile * SO + st) * MT + mt) * 256 + lo, ab[st]);
+        for (int st = 0; st < SO; ++st) st_blk(a.Out, EPI == EPI_ADJ && (PKM & 2) != 0, tile, SO, MT, st, mt, lane, ab[st]);
       }
     }
 }
@@ -175,7 +178,6 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
   }
-  const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
   const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
 
   // the wave walks all output chunks of its tile: the B blocks it re-reads stay hot in this CU's L1/L2
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
       }
     } else {
 #pragma unroll
-      for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT + kt) * 256);
+      for (int st = 0; st < S; ++st) raw[st] = ld_blk(a.Bin, false, tile, S, KT, st, kt, lane);
     }
   };
   auto load_w = [&](int kt, f32x4* w) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // instead of 8 fp32 MFMAs (8 x 33 cycles): the fp32 matrix pipe of gfx950 runs at the VECTOR fp32 rate, the bf16 pipe 16 x
 // faster.  The split of the activations is done once per workgroup in the produce stage, that of the weights on the host.
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1, bool WRING = false,
-          int SPL = 1>
+          int SPL = 1, int PKM = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, GK = NW * PK;
   static_assert(!WRING || (!BF && GK == 4), "the weight ring is written for 4 k-tiles per group, fp32");
@@ -314,7 +316,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
   }
-  const float* bin = a.Bin + (size_t)tile * S * KT * 256 + lo;
   const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
 
   // produce the B block of k-tile kt (this wave's turn) into ring slot (buf, slot)
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
     } else {
 #pragma unroll
-      for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT + kt) * 256);
+      for (int st = 0; st < S; ++st) raw[st] = ld_blk(a.Bin, (PKM & 1) != 0, tile, S, KT, st, kt, lane);
     }
     if (PRO == PRO_NONE || STPDE_ABLATE == 1) {
 #pragma unroll
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     }
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
-      layer_epilogue<S1, S2, EPI, ACT>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc);
+      layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc);
     STAMP(13);
   }
   flush_pbar<EPI, ACT>(a, pacc, lane);
@@ -493,6 +494,10 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
   a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
   const int nblocks = a.split ? (a.ntiles + 7) / 8 * 8 * a.split : a.ntiles;
+  if (a.pk && !(a.Wp16 && a.nsplit == 1)) {
+    stpde_set_error("packed layer buffers are a bf16-operand mode (stpde_layer_desc.mfma_bf16 == 1)");
+    return STPDE_E_UNSUPPORTED;
+  }
   if (a.Wp16 && a.nsplit == 3) {
     if constexpr (S1 + S2 <= 4 && NW == 4)     // split mode: compiled for the wide-layer shapes of the training stream sets
       STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 1, false, 3>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
@@ -500,10 +505,25 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
       stpde_set_error("bf16x3 split mode is not compiled for this stream set / workgroup shape");
       return STPDE_E_UNSUPPORTED;
     }
-  } else if (a.Wp16 && a.KT % (2 * NW) == 0)
-    STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 2>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
-  else if (a.Wp16)
-    STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+  } else if (a.Wp16) {
+    // the packed-buffer mask this (PRO, EPI) kind may be launched with (stpde_layer_desc.packed, mapped by jet_layer.hip)
+    constexpr int PKA = (PRO == PRO_L0 && EPI == EPI_FWD) ? 2 : (PRO == PRO_ACT ? 1 : (EPI == EPI_ADJ ? 6 : 1));
+    if (a.pk != 0 && a.pk != PKA) {
+      stpde_set_error("packed layer buffers: combination %d not compiled for this kernel kind (expects %d)", a.pk, PKA);
+      return STPDE_E_UNSUPPORTED;
+    }
+    if (a.KT % (2 * NW) == 0) {
+      if (a.pk)
+        STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 2, false, 1, PKA>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+      else
+        STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 2>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+    } else {
+      if (a.pk)
+        STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 1, false, 1, PKA>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+      else
+        STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+    }
+  }
   else {
     // 4 output tiles per wave: weight fragments through the 3-deep register ring (-2.5 % on the forward of the widest
     // layer; no gain for the 2-tile-per-wave shapes).  STPDE_WRING=0 switches it off.
@@ -533,6 +553,10 @@ static int launch_coop_act(const LayerArgs& a, hipStream_t stream) {
 
 template <int S1, int S2, int MC, int PRO, int EPI, int ACT, bool GUARD>
 static int launch_layer(const LayerArgs& a, hipStream_t stream) {
+  if (a.pk) {
+    stpde_set_error("packed layer buffers need the cooperative bf16 kernels (shape not served by them)");
+    return STPDE_E_UNSUPPORTED;
+  }
   dim3 grid((a.ntiles + 3) / 4);
   STPDE_LAUNCH((k_layer<S1, S2, MC, PRO, EPI, ACT, GUARD>), grid, dim3(256), 0, stream, a);
   return stpde_check_launch("k_layer");

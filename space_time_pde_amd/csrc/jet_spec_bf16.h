@@ -165,6 +165,18 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
       }
     };
     auto epilogue = [&](int tile) {
+      if (a.pk & 2) {      // packed output buffer (common.h): value stream fp32, derivative streams bf16
+        const unsigned tb = (unsigned)packed_tile_bytes(S, MT);
+        const auto ors = load_rsrc(reinterpret_cast<const char*>(a.Out) + (size_t)tile * tb, tb);
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi) {
+          buf_st16(ors, wlane, (mt0 + mi) * 1024, acc[mi][0]);
+#pragma unroll
+          for (int st = 1; st < S; ++st)
+            buf_st8(ors, lane * 8, MT * 1024 + ((st - 1) * MT + mt0 + mi) * 512, to_bf4(acc[mi][st]));
+        }
+        return;
+      }
       const auto ors = load_rsrc(a.Out + (size_t)tile * S * MT * 256, (unsigned)S * MT * 1024u);
 #pragma unroll
       for (int mi = 0; mi < MCg; ++mi)

@@ -33,6 +33,7 @@ struct WgradArgs {
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
   int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
+  int pk;              // packed-buffer flags (common.h: ld_blk): 1 = Q (the layer input's pre-activations), 4 = P (abar_out)
   int xfold;           // fp32 hidden-group launches: the (k-group, k-slot) pairs 0 .. XT-1 also contract their abar blocks with
                        // raw-input tile 0 .. XT-1 (one extra 16x16 tile per wave, the XR fragment straight from memory), and all
                        // of them keep the row sums of the tangent-stream adjoints (the tangent "input" of a skip connection is the
@@ -76,7 +77,8 @@ __device__ __forceinline__ f32x4 lds_get_R(const float* blk, int lane) {     // 
 // (hi + mid + lo) and the six partial products of weight >= 2^-16 are accumulated (see k_layer_coop); the abar blocks are
 // split once per tile when they are packed, the activated-input blocks when they leave the LDS ring (up to two VALU
 // instructions issue for free behind every bf16 MFMA).
-template <int S1, int S2, int MODE, int ACT, int KC, bool HASX, bool BF = false, int SPL = 1>
+// PKM: compile-time packed-buffer mask (WgradArgs.pk: 1 = Q, 4 = P), see layer_epilogue
+template <int S1, int S2, int MODE, int ACT, int KC, bool HASX, bool BF = false, int SPL = 1, int PKM = 0>
 __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");
   constexpr int S = 1 + S1 + S2, MCW = 2, NW = 8, RS = 8;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         }
       } else {
 #pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld4(a.Q + (((size_t)tile * S + st) * KT + kq) * 256 + lo);
+        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKM & 1) != 0, tile, S, KT, st, kq, lane);
       }
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
@@ -181,13 +183,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   };
   // this wave's abar blocks of row tile `tile`: column-major loads, transposed through the private patch
   auto load_p_raw = [&](int tile, f32x4 (*raw)[MCW]) {
-    const float* pbase = a.P + (size_t)tile * SP * MT * 256 + lo;
 #pragma unroll
     for (int st = 0; st < S; ++st)
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
-        raw[st][mi] = st < SP ? ld4(pbase + ((size_t)st * MT + mt) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        raw[st][mi] = st < SP ? ld_blk_raw(a.P, (PKM & 4) != 0, tile, SP, MT, st, mt, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   };
   auto transpose_p = [&](f32x4 (*raw)[MCW], f32x4 (*pa)[MCW]) {
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) {
           bf16x4 t0[SPL], t1[SPL];
-          terms(raw_[2 * sp][mi], t0);
-          if (2 * sp + 1 < S) terms(raw_[2 * sp + 1][mi], t1);
+          terms(blk_val(raw_[2 * sp][mi], (PKM & 4) != 0 && 2 * sp < SP, 2 * sp), t0);
+          if (2 * sp + 1 < S) terms(blk_val(raw_[2 * sp + 1][mi], (PKM & 4) != 0 && 2 * sp + 1 < SP, 2 * sp + 1), t1);
 #pragma unroll
           for (int k = 0; k < SPL; ++k) pa8[k][sp][mi] = cat8(t0[k], 2 * sp + 1 < S ? t1[k] : zero4);
         }
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] += wgt * raw_[1 + d][mi];
+        for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] += wgt * blk_val(raw_[1 + d][mi], (PKM & 4) != 0, 1 + d);
     }
   };
   if (tile < a.ntiles) {
@@ -645,7 +646,7 @@ static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
 // returns -1 when the shape is not served by the per-wave kernel
 template <int S1, int S2, int ACT>
 static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
-  if (a.MT > 4 || a.SP != 1 + S1 + S2 || a.bf16) return -1;
+  if (a.MT > 4 || a.SP != 1 + S1 + S2 || a.bf16 || a.pk) return -1;
   if constexpr (S1 + S2 > 5) {
     return -1;                             // S = 10: the accumulators + operands would not fit the register file
   } else {
@@ -701,8 +702,17 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
       }
     } else if (HAS_BF && a.bf16) {
       if constexpr (HAS_BF) {
-        if (part == 0)
+        constexpr int PKA = MODE == 1 ? 4 : 1;      // first hidden layer: packed abar; later layers: packed input stash
+        if (a.pk != 0 && a.pk != PKA) {
+          stpde_set_error("packed layer buffers: combination %d not compiled for this weight-gradient kind", a.pk);
+          return STPDE_E_UNSUPPORTED;
+        }
+        if (part == 0 && a.pk)
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 1, PKA>), grid, dim3(512), 0, stream, a);
+        else if (part == 0)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true>), grid, dim3(512), 0, stream, a);
+        else if (a.pk)
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, true, 1, PKA>), grid, dim3(512), 0, stream, a);
         else
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, true>), grid, dim3(512), 0, stream, a);
       }

@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
     const int MT = a.d.MT[l], SP = a.d.SP[l];
     const float* ab = a.abar[l] + lo;  // stream 0 of tile t starts at (size_t)t * SP * MT * 256
     const float* w = a.wsl[l] + lo;
-    const size_t tstride = (size_t)SP * MT * 256;
+    // floats between the value streams of consecutive tiles (packed buffers: value stream first, common.h)
+    const size_t tstride = a.d.packed[l] ? packed_tile_bytes(a.d.S[l], MT) / 4 : (size_t)SP * MT * 256;
     // two output tiles per iteration (MT is even for every hidden layer): their loads are issued together
     for (int mt = 0; mt + 1 < MT; mt += 2) {
       f32x4 B0[XR], B1[XR], w0[XL], w1[XL];

@@ -20,6 +20,14 @@ struct Seq {                       // first error wins, later launches are skipp
   }
 };
 
+bool is_packed(const stpde_imnet_plan* p, int l) { return l >= 1 && ((p->packed_mask >> l) & 1); }
+
+// packed flags of a call on layer l (stpde_layer_desc.packed): 1 = its hidden input pre[l-1], 2 = the buffer it writes,
+// 4 = its abar_out; `writes` = index of the layer buffer the call writes (fwd: l, bwd: l - 1), -1 = none
+int packed_flags(const stpde_imnet_plan* p, int l, int writes) {
+  return (is_packed(p, l - 1) ? 1 : 0) | ((writes >= 1 && is_packed(p, writes)) ? 2 : 0) | (is_packed(p, l) ? 4 : 0);
+}
+
 stpde_layer_desc layer_desc(int ntiles, const stpde_imnet_plan* p, int l, const stpde_jet_cfg& cfg, int bf16) {
   stpde_layer_desc d{};
   d.ntiles = ntiles;
@@ -133,6 +141,7 @@ extern "C" int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* p, const stpde_je
     }
     const void* w16 = p->mfma_bf16 ? p->Wh16[l] : nullptr;
     stpde_layer_desc d = layer_desc(lnt, p, l, lcfg, w16 ? p->mfma_bf16 : 0);
+    d.packed = packed_flags(p, l, l) & 3;
     seq([&] {
       return stpde_jet_layer_fwd(&d, prev, ws->X, p->Wh[l], p->Ws[l], p->tanc[l], p->Ws[0], p->tanc[0], ws->pre[l], ws->cw, w16,
                                  (l == 1 && stash) ? ws->pre[0] : nullptr, stream);
@@ -185,6 +194,7 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
     // same operand mode as the layer kernels; only the wide layers (MT >= 8) have bf16-pipe weight-gradient kernels
     stpde_layer_desc dwg = layer_desc(nt, p, l, cfg, (w16 && p->MT[l] >= 8 && (p->mfma_bf16 == 1 || !(flags & STPDE_F_WGRAD_FP32))) ? p->mfma_bf16 : 0);
+    dwg.packed = packed_flags(p, l, -1) & 5;
     seq([&] {
       return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->XR, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
                              stream);
@@ -211,6 +221,7 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   auto dgrad_l = [&](int l) {
     const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
     stpde_layer_desc d = layer_desc(nt, p, l, cfg, w16 ? p->mfma_bf16 : 0);
+    d.packed = packed_flags(p, l, l - 1);
     if (l > 1 && abar[l - 1] != ws->pre[l - 1]) {       // into a fresh buffer: the pre-activations stay intact
       seq([&] {
         return stpde_jet_layer_bwd_to(&d, abar[l], p->WhT[l], ws->pre[l - 1], abar[l - 1], ws->cw, act_param_bar, w16, stream);
@@ -236,6 +247,8 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     for (int l = 0; l < 5; ++l) {
       xd.MT[l] = p->MT[l];
       xd.SP[l] = l == 0 ? (split0 ? 1 : SP0) : S;
+      xd.packed[l] = is_packed(p, l) ? 1 : 0;
+      xd.S[l] = S;
       ab[l] = l == 0 ? abar0 : abar[l];
       wt[l] = p->WsL[l];
     }

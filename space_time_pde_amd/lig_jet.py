@@ -326,11 +326,28 @@ class _Meta:
     pass
 
 
-def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=0):
+def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=0, packed=0):
     d = LayerDesc()
     d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg = ntiles, lay["KT"], lay["MT"], int(first_hidden), cfg
     d.mfma_bf16 = int(bf16)
+    d.packed = int(packed)
     return d
+
+
+def _buf_floats(meta, l, nt):
+    """floats of the layer buffer of layer l's output rows for nt row tiles: [S][MT] fp32 blocks, or the PACKED form (bf16
+    mode: value stream fp32, derivative streams bf16; include/stpde_hip.h, stpde_layer_desc.packed)."""
+    mt = meta.plan.layers[l]["MT"]
+    if (meta.packed_mask >> l) & 1:
+        return nt * mt * (256 + (meta.S - 1) * 128)
+    return nt * meta.S * mt * _FRAG
+
+
+def _pk(meta, l, writes):
+    """stpde_layer_desc.packed of a call on layer l that writes the buffer of layer `writes` (-1: none)."""
+    m = meta.packed_mask
+    return (1 if (l >= 2 and (m >> (l - 1)) & 1) else 0) | (2 if (writes >= 1 and (m >> writes) & 1) else 0) | \
+        (4 if (m >> l) & 1 else 0)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -358,6 +375,7 @@ def _plan_desc(meta, packs):
             d.Wh16[l], d.WhT16[l] = _dp(meta.packs16.get((l, "Wh"))), _dp(meta.packs16.get((l, "WhT")))
         d.dw_off[l] = plan.dw_off[l][0]
     d.mfma_bf16 = meta.nsplit if meta.packs16 else 0
+    d.packed_mask = meta.packed_mask
     return d
 
 
@@ -405,7 +423,7 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     s["cw"] = torch.empty(Pc * 8, device=dev) if meta.cfg_out.combo else None
     s["coef"] = torch.empty(Pc * 16, device=dev)
     s["cell"] = torch.empty(Pc, device=dev, dtype=torch.int32)
-    s["bufs"] = [None] + [torch.empty(nt * S * plan.layers[l]["MT"] * _FRAG, device=dev) for l in range(1, 6)]
+    s["bufs"] = [None] + [torch.empty(_buf_floats(meta, l, nt), device=dev) for l in range(1, 6)]
     s["z0"] = torch.empty(nt * plan.layers[0]["MT"] * _FRAG, device=dev) if need_grad else None
     ws.X, ws.XR, ws.coef, ws.cw, ws.cell = (_dp(s[k]) for k in ("X", "XR", "coef", "cw", "cell"))
     ws.pre[0] = _dp(s["z0"])
@@ -523,9 +541,9 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
                                            arr([pv(packs, k, "tanc") for k in (3, 4, 5)]), arr(outs), ptr(cw), st))
             bufs += outs
             break
-        out = torch.empty(nt * S * lay["MT"] * _FRAG, device=dev)
+        out = torch.empty(_buf_floats(meta, l, nt), device=dev)
         w16 = meta.packs16.get((l, "Wh")) if meta.packs16 else None
-        d = _layer_desc(lnt, lay, lcfg, l == 1, meta.nsplit if w16 is not None else 0)
+        d = _layer_desc(lnt, lay, lcfg, l == 1, meta.nsplit if w16 is not None else 0, _pk(meta, l, l) & 3)
         if l == 1 and need_grad:
             # value stream of the layer-0 pre-activations, kept for the layer-1 input-gradient kernel (which then writes
             # the layer-0 adjoint over it): reading 2 KB per row back is cheaper than regenerating it on the fp32 MFMA
@@ -579,12 +597,12 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
-        d = _layer_desc(nt, lay, cfg, l == 1, meta.nsplit if w16 is not None else 0)
+        d = _layer_desc(nt, lay, cfg, l == 1, meta.nsplit if w16 is not None else 0, _pk(meta, l, l - 1))
         # weight gradient: same operand mode as the layer kernels (STPDE_WGRAD_SPLIT=0 keeps it on exact-fp32 MFMA in
         # "fp32x3" mode, for A/B timing); only the wide layers, MT >= 8, have bf16-pipe weight-gradient kernels --
         # flagging a narrow layer would take it off its per-wave kernel
         dwg = _layer_desc(nt, lay, cfg, l == 1, (meta.nsplit if wgrad_split or meta.nsplit == 1 else 0)
-                          if (w16 is not None and lay["MT"] >= 8) else 0)
+                          if (w16 is not None and lay["MT"] >= 8) else 0, _pk(meta, l, -1) & 5)
         off, mp, ka = plan.dw_off[l]
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
@@ -627,6 +645,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
         for l in range(5):
             xd.MT[l] = plan.layers[l]["MT"]
             xd.SP[l] = (1 if split0 else SP0) if l == 0 else S
+            xd.packed[l], xd.S[l] = (meta.packed_mask >> l) & 1 if l else 0, S
             ab[l] = (abar0 if l == 0 else abar[l]).data_ptr()
             wt[l] = pv(packs, l, "WsL").data_ptr()
         if not deterministic_dlatent:
@@ -823,6 +842,7 @@ value_tiles = os.environ.get("STPDE_VALUE_TILES", "1") != "0"
 # layer-0 tangent-stream adjoints as per-tile row sums (STPDE_TAN0_ROWSUM=0: full fragment blocks, for A/B timing)
 tan0_rowsum = os.environ.get("STPDE_TAN0_ROWSUM", "1") != "0"
 wgrad_split = os.environ.get("STPDE_WGRAD_SPLIT", "1") != "0"
+packed_stash = os.environ.get("STPDE_PACKED_STASH", "1") != "0"
 # forward of fc3 -> fc4 -> fc5 in one kernel (STPDE_FUSED_TAIL=0: three per-layer kernels)
 fused_tail = os.environ.get("STPDE_FUSED_TAIL", "1") != "0"
 
@@ -886,6 +906,10 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.bf16 = precision in ("bf16", "fp32x3")
     meta.nsplit = 3 if precision == "fp32x3" else 1
     meta.packs16 = None
+    # bf16 mode, reference width: the stash of fc1's output rows (47 % of the mode's HBM traffic) in the PACKED form -- all of
+    # its consumers are bf16-operand kernels (fc2 forward / weight gradient / dgrad, and as adjoint fc1's weight gradient /
+    # dgrad).  STPDE_PACKED_STASH=0: fp32 blocks as in rounds 1-2.
+    meta.packed_mask = 0
     # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
     # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams
     # go through the network and the reduction supplies the second derivatives from the weight cross terms
@@ -894,6 +918,8 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
         meta.cfg, meta.S, _ = make_cfg(act, prm, True, [])
     else:
         meta.cfg, meta.S = meta.cfg_out, meta.S_out
+    if precision == "bf16" and packed_stash and imnet.nf == 32 and meta.S <= 6:     # (S > 6 is not served by the bf16 kernels)
+        meta.packed_mask = 2
     meta.B, meta.N = B, N
     meta.grid_shape = tuple(latent_grid.shape[1:4])
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)

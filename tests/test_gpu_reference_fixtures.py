@@ -125,9 +125,10 @@ def _assert_bf16_kernels(tr, cfg, dump):
     for pro, epi in ((0, 2), (1, 0), (0, 1)):
         assert tr.has("k_layer_coop", "true", cfg, "PRO = %d" % pro, "EPI = %d" % epi), dump
     # bf16 weight gradients with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
-    assert tr.has("k_wgrad_coop", "false, true>)", cfg, "MODE = 1", "KC = 8"), dump
-    assert tr.has("k_wgrad_coop", "false, true>)", cfg, "MODE = 0", "KC = 4"), dump
-    assert not tr.has("k_wgrad_coop", "true, true>)", cfg), dump
+    # (the packed-stash instantiations carry two more template arguments: ..., false, true, 1, PKA>)
+    assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1", "KC = 8"), dump
+    assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 0", "KC = 4"), dump
+    assert not tr.has("k_wgrad_coop", "KC, true, true", cfg), dump
 
 
 @pytest.mark.parametrize("prec", ["fp32x3", "bf16"])
