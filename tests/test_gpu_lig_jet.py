@@ -379,7 +379,7 @@ def test_retain_graph_second_backward_rebuilds_the_stash(hiplib):
     latd.grad = None
     loss.backward()
     assert torch.equal(latd.grad, g1)
-    assert torch.allclose(net.fc[1].weight.grad, 2 * w1, rtol=1e-5, atol=1e-7 * float(w1.abs().max()))
+    assert torch.allclose(net.fc[1].weight.grad, 2 * w1, rtol=1e-5, atol=2e-6 * float(w1.abs().max()))   # fp32-atomic summation order
 
 
 @pytest.mark.parametrize("cin,nf", [(8, 16), (16, 32), (24, 16)])
