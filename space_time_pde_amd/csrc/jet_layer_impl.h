@@ -87,7 +87,8 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 // block load / store and split the MFMA basic blocks (measured: +40 % on the kernels that took it)
 template <int S1, int S2, int EPI, int ACT, int PKM = 0>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
-                                               const f32x4 (*xbv)[XT], const float* cq, float& pacc) {
+                                               const f32x4 (*xbv)[XT], const float* cq, float& pacc,
+                                               const f32x4* z0pre = nullptr) {
   constexpr int S = 1 + S1 + S2;
   constexpr bool VT = S1 == 0 && S2 > 0;     // value-tile mode: every stream is the value stream of its own row tile
   const int lo = lane * 4;
@@ -114,7 +115,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
 #pragma unroll
         for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Pre, (PKM & 4) != 0, tile, S, MT, st, mt, lane);
       } else {
-        pre[0] = ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
+        pre[0] = z0pre ? *z0pre : ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
@@ -356,6 +357,27 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
     }
   };
+  // PRO_NONE (input-gradient kernels: the B blocks are plain loads from the stash): the loads are ISSUED before the MFMAs of
+  // the current group and converted / written to the ring after them, so their HBM latency hides behind the MFMAs instead of
+  // sitting in front of the barrier (round 3; first-layer dgrad 92.1 -> 89.5 ms per step in fp32, 26.9 -> 23.6 ms with bf16
+  // operands).  The same split for PRO_ACT (loads early, activation late) was measured and dropped: fp32 +-0, bf16 layer-2
+  // forward 12.0 -> 16.6 ms.
+  auto store_block = [&](const f32x4* B, int buf, int slot) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      if constexpr (BF) {
+        f32x4 v = B[st];
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+          const bf16x4 h = to_bf4(v);
+          *reinterpret_cast<bf16x4*>(&hb[buf][slot][st][128 * t + lane * 2]) = h;
+          if (t + 1 < SPL) v -= bf4_to_f32(h);
+        }
+      } else {
+        st4(&hb[buf][slot][st][lo], B[st]);
+      }
+    }
+  };
   auto produce_group = [&](int g, int buf) {      // this wave's PK k-tiles of group g
 #pragma unroll
     for (int k = 0; k < PK; ++k) produce(GK * g + NW * k + wv, buf, NW * k + wv);
@@ -368,6 +390,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     for (int mi = 0; mi < MCg; ++mi)
 #pragma unroll
       for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // first hidden layer's input gradient: the z0 blocks its epilogue takes the adjoint against, fetched now
+    f32x4 z0p[EPI == EPI_ADJ_L0 ? MCg : 1];
+    if constexpr (EPI == EPI_ADJ_L0) {
+#pragma unroll
+      for (int mi = 0; mi < MCg; ++mi) z0p[mi] = ld4(a.Z0 + ((size_t)tile * MT + mt0 + mi) * 256 + lo);
+    }
     const float* wp = a.Wp + (size_t)mt0 * 256 + lo;
     f32x4 wr[WRING ? 4 : 1][MCg];
     if constexpr (WRING) {
@@ -384,6 +412,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     STAMP(3);
     for (int gi = 0; gi < ngroups; ++gi) {
       const int buf = gi & 1;
+      const int gnext = gi + 1 < ngroups ? gi + 1 : gi;
+      constexpr bool EARLY = PRO == PRO_NONE;     // B blocks are plain loads from the stash: issue them now
+      f32x4 rawn[EARLY ? PK : 1][S];
+      if constexpr (EARLY) {
+#pragma unroll
+        for (int k = 0; k < PK; ++k)
+#pragma unroll
+          for (int st = 0; st < S; ++st)
+            rawn[k][st] = ld_blk(a.Bin, (PKM & 1) != 0, tile, S, KT, st, GK * gnext + NW * k + wv, lane);
+      }
       if constexpr (BF) {
         const bf16x8* wp16 = reinterpret_cast<const bf16x8*>(a.Wp16) + (size_t)mt0 * 64 + lane;
 #pragma unroll
@@ -456,7 +494,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
-      if (STPDE_ABLATE != 5) produce_group(gi + 1 < ngroups ? gi + 1 : gi, buf ^ 1);
+      if constexpr (PRO == PRO_NONE) {
+#pragma unroll
+        for (int k = 0; k < PK; ++k) store_block(rawn[k], buf ^ 1, NW * k + wv);
+      } else {
+        if (STPDE_ABLATE != 5) produce_group(gnext, buf ^ 1);
+      }
       if (gi < 8) STAMP(4 + gi);
       if (STPDE_ABLATE != 2) __syncthreads();
     }
@@ -472,7 +515,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     }
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
-      layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc);
+      layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc,
+                                              EPI == EPI_ADJ_L0 ? &z0p[mi] : nullptr);
     STAMP(13);
   }
   flush_pbar<EPI, ACT>(a, pacc, lane);
