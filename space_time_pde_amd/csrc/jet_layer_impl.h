@@ -29,6 +29,9 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #ifndef STPDE_STAMP
 #define STPDE_STAMP 0
 #endif
+#ifndef STPDE_EARLY_L0
+#define STPDE_EARLY_L0 1
+#endif
 #if STPDE_STAMP
 #define STPDE_STAMP_B0 8192
 static __device__ unsigned long long g_stamp[256 * 8 * 16];
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       const int buf = gi & 1;
       const int gnext = gi + 1 < ngroups ? gi + 1 : gi;
       constexpr bool EARLY = PRO == PRO_NONE;     // B blocks are plain loads from the stash: issue them now
+      constexpr bool EARLY0 = PRO == PRO_L0 && !VT && STPDE_EARLY_L0;   // layer 0 on the fly: its weight / tangent fragments
       f32x4 rawn[EARLY ? PK : 1][S];
       if constexpr (EARLY) {
 #pragma unroll
@@ -421,6 +425,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
           for (int st = 0; st < S; ++st)
             rawn[k][st] = ld_blk(a.Bin, (PKM & 1) != 0, tile, S, KT, st, GK * gnext + NW * k + wv, lane);
+      }
+      f32x4 w0n[EARLY0 ? PK : 1][XT], tcn[EARLY0 ? PK : 1][3];
+      if constexpr (EARLY0) {
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+          const int kt = GK * gnext + NW * k + wv;
+#pragma unroll
+          for (int xt = 0; xt < XT; ++xt) w0n[k][xt] = ld4(a.W0s + ((size_t)xt * KT + kt) * 256 + lo);
+          if (S1 == 3) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) tcn[k][d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
+          }
+        }
       }
       if constexpr (BF) {
         const bf16x8* wp16 = reinterpret_cast<const bf16x8*>(a.Wp16) + (size_t)mt0 * 64 + lane;
@@ -497,6 +514,29 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       if constexpr (PRO == PRO_NONE) {
 #pragma unroll
         for (int k = 0; k < PK; ++k) store_block(rawn[k], buf ^ 1, NW * k + wv);
+      } else if constexpr (EARLY0) {
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+          const int kt = GK * gnext + NW * k + wv;
+          f32x4 raw[S], B[S], part[XT];
+#pragma unroll
+          for (int xt = 0; xt < XT; ++xt) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < x_live(xt); ++r) c = mfma4(w0n[k][xt][r], xb[0][xt][r], c);
+            part[xt] = c;
+          }
+          raw[0] = (part[0] + part[1]) + part[2];
+          opt_st4(z0r, kt * 1024 + lane * 16, raw[0]);
+          if (S1 == 3) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) raw[1 + d] = tcn[k][d];
+#pragma unroll
+            for (int p = 0; p < S2; ++p) raw[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
+          store_block(B, buf ^ 1, NW * k + wv);
+        }
       } else {
         if (STPDE_ABLATE != 5) produce_group(gnext, buf ^ 1);
       }
