@@ -138,6 +138,11 @@ int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
                        const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
                        float* const* out_pre, const float* cw, void* stream);
 
+/* The same with in_pre2 as a PACKED layer buffer (packed & 1; stpde_layer_desc.packed; bf16 mode, nf = 32, S1 = 3). */
+int stpde_jet_tail_fwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
+                         const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
+                         float* const* out_pre, const float* cw, int packed, void* stream);
+
 /* Fused input-gradient chain of the same three layers: abar5 (adjoint of fc5's output rows, from stpde_lig_reduce_bwd)
  * -> abar4 -> abar3 -> abar2; equivalent to stpde_jet_layer_bwd on layers 5, 4, 3, but the adjoints of layers 4 and 3 feed
  * the next GEMM from the registers.  pre[0..2]: stashed pre-activations of the outputs of fc2, fc3, fc4; abar_out[0..2]:
@@ -147,6 +152,12 @@ int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
 int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
                        const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar,
                        void* stream);
+
+/* The same with pre[0] read (packed & 1) and abar_out[0] written (packed & 2) as PACKED layer buffers; compiled for
+ * packed == 3 (bf16 mode, nf = 32, S1 = 3). */
+int stpde_jet_tail_bwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
+                         const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar, int packed,
+                         void* stream);
 
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):

@@ -591,7 +591,8 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     }
   } else if (a.Wp16) {
     // the packed-buffer mask this (PRO, EPI) kind may be launched with (stpde_layer_desc.packed, mapped by jet_layer.hip)
-    constexpr int PKA = (PRO == PRO_L0 && EPI == EPI_FWD) ? 2 : (PRO == PRO_ACT ? 1 : (EPI == EPI_ADJ ? 6 : 1));
+    // (bf16 mode packs the buffers of fc1's AND fc2's rows: fc1 forward writes one, fc2 forward reads one and writes one, ...)
+    constexpr int PKA = (PRO == PRO_L0 && EPI == EPI_FWD) ? 2 : (PRO == PRO_ACT ? 3 : (EPI == EPI_ADJ ? 7 : 1));
     if (a.pk != 0 && a.pk != PKA) {
       stpde_set_error("packed layer buffers: combination %d not compiled for this kernel kind (expects %d)", a.pk, PKA);
       return STPDE_E_UNSUPPORTED;

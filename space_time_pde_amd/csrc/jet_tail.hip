@@ -15,10 +15,12 @@ struct TailArgs {
   float* out[3];                 // [tile][S][MT_l][256]
   const float* cw;
   int ntiles;
+  int packed;                    // 1: in2 is a packed layer buffer
   stpde_jet_cfg cfg;
 };
 
-template <int S1, int S2, int ACT, int NFT>
+// PIN: in2 is a PACKED layer buffer (bf16 mode, common.h ld_blk: value stream fp32, derivative streams bf16)
+template <int S1, int S2, int ACT, int NFT, bool PIN = false>
 __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
   constexpr int S = 1 + S1 + S2;
   constexpr int KT3 = 4 * NFT, MT3 = 2 * NFT, MT4 = NFT, MT5 = 1;
@@ -61,10 +63,9 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
 #pragma unroll
     for (int st = 0; st < S; ++st) acc3[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const float* bin = a.in2 + (size_t)tile * S * KT3 * 256 + lo;
     f32x4 raw[S], w[MT3];
 #pragma unroll
-    for (int st = 0; st < S; ++st) raw[st] = ld4(bin + ((size_t)st * KT3) * 256);
+    for (int st = 0; st < S; ++st) raw[st] = ld_blk_raw(a.in2, PIN, tile, S, KT3, st, 0, lane);
 #pragma unroll
     for (int mi = 0; mi < MT3; ++mi) w[mi] = ld4(a.Wh[0] + ((size_t)mi) * 256 + lo);
 #pragma unroll
@@ -72,9 +73,12 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
       const int kn = kt + 1 < KT3 ? kt + 1 : kt;
       f32x4 rawn[S], wn[MT3], B[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) rawn[st] = ld4(bin + ((size_t)st * KT3 + kn) * 256);
+      for (int st = 0; st < S; ++st) rawn[st] = ld_blk_raw(a.in2, PIN, tile, S, KT3, st, kn, lane);
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi) wn[mi] = ld4(a.Wh[0] + ((size_t)kn * MT3 + mi) * 256 + lo);
+      // (packed derivative blocks are converted here, not at the load a k-tile ahead)
+#pragma unroll
+      for (int st = 0; st < S; ++st) raw[st] = blk_val(raw[st], PIN, st);
       act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi)
@@ -133,6 +137,16 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
 template <int S1, int S2, int ACT>
 static int launch_tail_nft(const TailArgs& a, int nft, hipStream_t stream) {
   const dim3 grid((a.ntiles + 3) / 4);
+  if (a.packed & 1) {
+    if constexpr (S1 == 3) {       // packed stash: the training stream sets of the bf16 mode, reference width only
+      if (nft == 2) {
+        STPDE_LAUNCH((k_tail_fwd<S1, S2, ACT, 2, true>), grid, dim3(256), 0, stream, a);
+        return stpde_check_launch("k_tail_fwd");
+      }
+    }
+    stpde_set_error("jet_tail_fwd: packed input is compiled for nf = 32 and S1 = 3 only");
+    return STPDE_E_UNSUPPORTED;
+  }
   if (nft == 2)
     STPDE_LAUNCH((k_tail_fwd<S1, S2, ACT, 2>), grid, dim3(256), 0, stream, a);
   else
@@ -152,9 +166,24 @@ static int launch_tail_act(const TailArgs& a, int nft, hipStream_t stream) {
   }
 }
 
+static int tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
+                    const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
+                    float* const* out_pre, const float* cw, int packed, void* stream);
+
 extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                                   const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
                                   float* const* out_pre, const float* cw, void* stream) {
+  return tail_fwd(cfg, ntiles, nf16, in_pre2, X, Wh_pack, Ws_pack, tanc, out_pre, cw, 0, stream);
+}
+extern "C" int stpde_jet_tail_fwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
+                                    const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
+                                    float* const* out_pre, const float* cw, int packed, void* stream) {
+  return tail_fwd(cfg, ntiles, nf16, in_pre2, X, Wh_pack, Ws_pack, tanc, out_pre, cw, packed, stream);
+}
+
+static int tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
+                    const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
+                    float* const* out_pre, const float* cw, int packed, void* stream) {
   if (!cfg || ntiles <= 0 || (nf16 != 1 && nf16 != 2) || !in_pre2 || !X || !Wh_pack || !Ws_pack || !tanc || !out_pre ||
       cfg->act < 0 || cfg->act > 5) {
     stpde_set_error("jet_tail_fwd: bad argument (nf must be 16 or 32)");
@@ -175,6 +204,7 @@ extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16
   }
   a.cw = cw;
   a.ntiles = ntiles;
+  a.packed = packed;
   a.cfg = *cfg;
   const int S1 = cfg->S1, S2 = cfg->S2;
   if (S1 == 0 && S2 == 0) return launch_tail_act<0, 0>(a, nf16, (hipStream_t)stream);
@@ -201,10 +231,12 @@ struct TailBwdArgs {
   const float* cw;
   float* pbar;
   int ntiles;
+  int packed;                    // 1: pre[0] (stash of fc2's output rows) is packed, 2: out[0] (their adjoint) is written packed
   stpde_jet_cfg cfg;
 };
 
-template <int S1, int S2, int ACT, int NFT>
+// PK2: compile-time copy of TailBwdArgs.packed
+template <int S1, int S2, int ACT, int NFT, int PK2 = 0>
 __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
   constexpr int S = 1 + S1 + S2;
   constexpr int T2 = 4 * NFT, T3 = 2 * NFT, T4 = NFT;     // feature tiles of the outputs of layers 2, 3, 4
@@ -222,13 +254,14 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
     const float* buf_in = a.pre[l];
     float* buf = a.out[l];
     f32x4 pre[S], ab[S];
+    const bool pin = l == 0 && (PK2 & 1), pout = l == 0 && (PK2 & 2);     // compile-time after inlining (l is a literal)
 #pragma unroll
-    for (int st = 0; st < S; ++st) pre[st] = ld4(buf_in + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+    for (int st = 0; st < S; ++st) pre[st] = ld_blk(buf_in, pin, tile, S, MT, st, mt, lane);
     act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc, ab, cq);
     if (swish) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc, cq);
 #pragma unroll
     for (int st = 0; st < S; ++st) {
-      st4(buf + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
+      st_blk(buf, pout, tile, S, MT, st, mt, lane, ab[st]);
       acc[st] = ab[st];
     }
   };
@@ -297,6 +330,16 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
 template <int S1, int S2, int ACT>
 static int launch_tailb_nft(const TailBwdArgs& a, int nft, hipStream_t stream) {
   const dim3 grid((a.ntiles + 3) / 4);
+  if (a.packed) {
+    if constexpr (S1 == 3) {
+      if (nft == 2 && a.packed == 3) {
+        STPDE_LAUNCH((k_tail_bwd<S1, S2, ACT, 2, 3>), grid, dim3(256), 0, stream, a);
+        return stpde_check_launch("k_tail_bwd");
+      }
+    }
+    stpde_set_error("jet_tail_bwd: packed buffers are compiled for nf = 32, S1 = 3, packed = 3 only");
+    return STPDE_E_UNSUPPORTED;
+  }
   if (nft == 2)
     STPDE_LAUNCH((k_tail_bwd<S1, S2, ACT, 2>), grid, dim3(256), 0, stream, a);
   else
@@ -316,9 +359,24 @@ static int launch_tailb_act(const TailBwdArgs& a, int nft, hipStream_t stream) {
   }
 }
 
+static int tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
+                    const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar, int packed,
+                    void* stream);
+
 extern "C" int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5,
                                   const float* const* WhT_pack, const float* const* pre, float* const* abar_out,
                                   const float* cw, float* act_param_bar, void* stream) {
+  return tail_bwd(cfg, ntiles, nf16, abar5, WhT_pack, pre, abar_out, cw, act_param_bar, 0, stream);
+}
+extern "C" int stpde_jet_tail_bwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5,
+                                    const float* const* WhT_pack, const float* const* pre, float* const* abar_out,
+                                    const float* cw, float* act_param_bar, int packed, void* stream) {
+  return tail_bwd(cfg, ntiles, nf16, abar5, WhT_pack, pre, abar_out, cw, act_param_bar, packed, stream);
+}
+
+static int tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
+                    const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar, int packed,
+                    void* stream) {
   if (!cfg || ntiles <= 0 || (nf16 != 1 && nf16 != 2) || !abar5 || !WhT_pack || !pre || !abar_out || cfg->act < 0 ||
       cfg->act > 5) {
     stpde_set_error("jet_tail_bwd: bad argument (nf must be 16 or 32)");
@@ -338,6 +396,7 @@ extern "C" int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16
   a.cw = cw;
   a.pbar = act_param_bar;
   a.ntiles = ntiles;
+  a.packed = packed;
   a.cfg = *cfg;
   const int S1 = cfg->S1, S2 = cfg->S2;
   if (S1 == 0 && S2 == 0) return launch_tailb_act<0, 0>(a, nf16, (hipStream_t)stream);

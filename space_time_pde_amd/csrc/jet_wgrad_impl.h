@@ -532,7 +532,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 // a private 2.5 KB patch with wave-local barriers only, and 3-4 waves per SIMD overlap each other's latencies.  The
 // four waves of a block are summed through LDS before the atomics.
 // ------------------------------------------------------------------------------------------------------------
-template <int S1, int S2, int ACT, int MCW, int KTT>
+// QPK: Q (the layer input's pre-activations) is a packed layer buffer (bf16 mode: fc3 reading the packed stash of fc2's rows)
+template <int S1, int S2, int ACT, int MCW, int KTT, bool QPK = false>
 __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
   constexpr int S = 1 + S1 + S2, NK = KTT + XT;
   constexpr int TP = 24, TBLK = 16 * TP;
@@ -586,12 +587,11 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(raw[st][mi]);
     }
-    const float* qbase = a.Q + (size_t)tile * S * KTT * 256 + lo;
 #pragma unroll
     for (int ki = 0; ki < KTT; ++ki) {
       f32x4 pre[S], H[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) pre[st] = ld4(qbase + ((size_t)st * KTT + ki) * 256);
+      for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, QPK, tile, S, KTT, st, ki, lane);
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) {
@@ -661,6 +661,16 @@ static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
   int gx = 768 / gy;                       // ~3 waves per SIMD over the chip
   if (gx > (a.ntiles + 3) / 4) gx = (a.ntiles + 3) / 4;
   if (gx < 1) gx = 1;
+  if (a.pk) {
+    if constexpr (KTT == 8 && MCW == 4 && S1 == 3) {       // fc3 of the reference width, training stream sets
+      if (a.pk == 1) {
+        STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT, true>), dim3(gx, gy), dim3(256), 0, stream, a);
+        return stpde_check_launch("k_wgrad_wave");
+      }
+    }
+    stpde_set_error("jet_wgrad: packed input not compiled for this narrow-layer shape");
+    return STPDE_E_UNSUPPORTED;
+  }
   STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT>), dim3(gx, gy), dim3(256), 0, stream, a);
   return stpde_check_launch("k_wgrad_wave");
 }
@@ -668,7 +678,7 @@ static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
 // returns -1 when the shape is not served by the per-wave kernel
 template <int S1, int S2, int ACT>
 static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
-  if (a.MT > 4 || a.SP != 1 + S1 + S2 || a.bf16 || a.pk) return -1;
+  if (a.MT > 4 || a.SP != 1 + S1 + S2 || a.bf16) return -1;
   if constexpr (S1 + S2 > 5) {
     return -1;                             // S = 10: the accumulators + operands would not fit the register file
   } else {
@@ -724,7 +734,7 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
       }
     } else if (HAS_BF && a.bf16) {
       if constexpr (HAS_BF) {
-        constexpr int PKA = MODE == 1 ? 4 : 1;      // first hidden layer: packed abar; later layers: packed input stash
+        constexpr int PKA = MODE == 1 ? 4 : 5;      // first hidden layer: packed abar; layer 2: packed input stash AND packed abar
         if (a.pk != 0 && a.pk != PKA) {
           stpde_set_error("packed layer buffers: combination %d not compiled for this weight-gradient kind", a.pk);
           return STPDE_E_UNSUPPORTED;

@@ -136,7 +136,9 @@ extern "C" int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* p, const stpde_je
       const float* Wsk[3] = {p->Ws[3], p->Ws[4], p->Ws[5]};
       const float* tc[3] = {p->tanc[3], p->tanc[4], p->tanc[5]};
       float* outs[3] = {ws->pre[3], ws->pre[4], ws->pre[5]};
-      seq([&] { return stpde_jet_tail_fwd(&lcfg, lnt, p->nf16, prev, ws->X, Wh, Wsk, tc, outs, ws->cw, stream); });
+      seq([&] {
+        return stpde_jet_tail_fwd_p(&lcfg, lnt, p->nf16, prev, ws->X, Wh, Wsk, tc, outs, ws->cw, is_packed(p, 2) ? 1 : 0, stream);
+      });
       break;
     }
     const void* w16 = p->mfma_bf16 ? p->Wh16[l] : nullptr;
@@ -216,7 +218,10 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     const float* WhT[3] = {p->WhT[3], p->WhT[4], p->WhT[5]};
     const float* pre[3] = {ws->pre[2], ws->pre[3], ws->pre[4]};
     float* outs[3] = {abar[2], abar[3], ws->pre[4]};
-    seq([&] { return stpde_jet_tail_bwd(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, stream); });
+    seq([&] {
+      return stpde_jet_tail_bwd_p(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, is_packed(p, 2) ? 3 : 0,
+                                  stream);
+    });
   };
   auto dgrad_l = [&](int l) {
     const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;

@@ -535,10 +535,11 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
             outs = [torch.empty(nt * S * plan.layers[k]["MT"] * _FRAG, device=dev) for k in (3, 4, 5)]
             arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
             with _timed("tail_fwd"):
-                check(L.stpde_jet_tail_fwd(C.byref(lcfg), lnt, plan.nf // 16, ptr(prev), ptr(X),
-                                           arr([pv(packs, k, "Wh") for k in (3, 4, 5)]),
-                                           arr([pv(packs, k, "Ws") for k in (3, 4, 5)]),
-                                           arr([pv(packs, k, "tanc") for k in (3, 4, 5)]), arr(outs), ptr(cw), st))
+                check(L.stpde_jet_tail_fwd_p(C.byref(lcfg), lnt, plan.nf // 16, ptr(prev), ptr(X),
+                                             arr([pv(packs, k, "Wh") for k in (3, 4, 5)]),
+                                             arr([pv(packs, k, "Ws") for k in (3, 4, 5)]),
+                                             arr([pv(packs, k, "tanc") for k in (3, 4, 5)]), arr(outs), ptr(cw),
+                                             (meta.packed_mask >> 2) & 1, st))
             bufs += outs
             break
         out = torch.empty(_buf_floats(meta, l, nt), device=dev)
@@ -613,10 +614,10 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
                 abar[3], abar[2] = torch.empty_like(bufs[3]), torch.empty_like(bufs[2])
                 arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
                 with _timed("tail_dgrad"):
-                    check(L.stpde_jet_tail_bwd(C.byref(cfg), nt, plan.nf // 16, ptr(bufs[5]),
-                                               arr([pv(packs, k, "WhT") for k in (3, 4, 5)]),
-                                               arr([bufs[2], bufs[3], bufs[4]]), arr([abar[2], abar[3], abar[4]]),
-                                               ptr(cw), ptr(pbar), st))
+                    check(L.stpde_jet_tail_bwd_p(C.byref(cfg), nt, plan.nf // 16, ptr(bufs[5]),
+                                                 arr([pv(packs, k, "WhT") for k in (3, 4, 5)]),
+                                                 arr([bufs[2], bufs[3], bufs[4]]), arr([abar[2], abar[3], abar[4]]),
+                                                 ptr(cw), ptr(pbar), 3 if (meta.packed_mask >> 2) & 1 else 0, st))
             continue
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(abar[l]), ptr(pv(packs, l, "WhT")),
@@ -906,9 +907,9 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.bf16 = precision in ("bf16", "fp32x3")
     meta.nsplit = 3 if precision == "fp32x3" else 1
     meta.packs16 = None
-    # bf16 mode, reference width: the stash of fc1's output rows (47 % of the mode's HBM traffic) in the PACKED form -- all of
-    # its consumers are bf16-operand kernels (fc2 forward / weight gradient / dgrad, and as adjoint fc1's weight gradient /
-    # dgrad).  STPDE_PACKED_STASH=0: fp32 blocks as in rounds 1-2.
+    # bf16 mode, reference width: the stashes of fc1's and fc2's output rows (70 % of the mode's HBM traffic) in the PACKED
+    # form -- their consumers are the bf16-operand kernels of layers 1-2 and the fused fc3 -> fc5 kernels / fc3's weight
+    # gradient, which read the packed form.  STPDE_PACKED_STASH=0: fp32 blocks as in rounds 1-2.
     meta.packed_mask = 0
     # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
     # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams
@@ -918,8 +919,10 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
         meta.cfg, meta.S, _ = make_cfg(act, prm, True, [])
     else:
         meta.cfg, meta.S = meta.cfg_out, meta.S_out
-    if precision == "bf16" and packed_stash and imnet.nf == 32 and meta.S <= 6:     # (S > 6 is not served by the bf16 kernels)
-        meta.packed_mask = 2
+    # (S > 6 is not served by the bf16 kernels; the packed buffer of fc2's rows is read by the fused fc3 -> fc5 kernels)
+    if precision == "bf16" and packed_stash and imnet.nf == 32 and meta.S <= 6:
+        tail_ok = fused_tail and meta.cfg.S1 == 3 and (meta.cfg.S2 != 1 or bool(meta.cfg_out.combo))
+        meta.packed_mask = 6 if tail_ok else 0      # (the bf16 kernels are compiled for "both boundaries packed" or none)
     meta.B, meta.N = B, N
     meta.grid_shape = tuple(latent_grid.shape[1:4])
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)

@@ -253,9 +253,9 @@ def test_bf16_mfma_mode_config4(hiplib, act):
     jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, pairs, chunk_points=128, precision="bf16")
     with torch.no_grad():
         jets32, _ = lig_jet.lig_jets(net, lat.to(dev), pts.to(dev), 0., 1., True, pairs, chunk_points=128)
-    # the stash of fc1's output rows is PACKED in this mode (derivative streams stored as bf16): emulated as well
+    # the stashes of fc1's and fc2's output rows are PACKED in this mode (derivative streams stored as bf16): emulated as well
     emu = J.lig_jets(_params64(net), act, lat.double(), pts.double(), 0., 1., second=tuple(pp),
-                     bf16_layers=_bf16_layers(32), bf16_pre_tangents=(1,))
+                     bf16_layers=_bf16_layers(32), bf16_pre_tangents=(1, 2))
     emu = emu.permute(0, 3, 1, 2).reshape(emu.shape[0], 4, -1)
     p64 = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in _params64(net)]
     lat64 = lat.double().requires_grad_(True)
