@@ -138,10 +138,15 @@ int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
                        const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
                        float* const* out_pre, const float* cw, void* stream);
 
-/* The same with in_pre2 as a PACKED layer buffer (packed & 1; stpde_layer_desc.packed; bf16 mode, nf = 32, S1 = 3). */
+/* bf16 mode (stpde_imnet_plan.mfma_bf16 == 1; nf = 32, S1 = 3): the same chain with the hidden-to-hidden products on the
+ * bf16 MFMA and PACKED layer buffers (stpde_layer_desc.packed).  packed: 1 = in_pre2 is packed, 2 = out_pre[0] / [1] are
+ * written packed (out_pre[2], the rows of the output layer, stays fp32 blocks); Wh16_pack: the bf16 A-operand packs of the
+ * three layers in TWO terms, [2][KT/2][MT][64] x 8 bf16 (hi, then lo = bf16(w - hi); two k-tiles per block) -- these layers
+ * are narrow, so both operands of a product are split into two bf16 terms and the product is three bf16 MFMAs (2^-16
+ * relative).  Compiled for packed == 3 with all three packs; packed == 0 and Wh16_pack == NULL: stpde_jet_tail_fwd. */
 int stpde_jet_tail_fwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                          const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
-                         float* const* out_pre, const float* cw, int packed, void* stream);
+                         float* const* out_pre, const float* cw, int packed, const void* const* Wh16_pack, void* stream);
 
 /* Fused input-gradient chain of the same three layers: abar5 (adjoint of fc5's output rows, from stpde_lig_reduce_bwd)
  * -> abar4 -> abar3 -> abar2; equivalent to stpde_jet_layer_bwd on layers 5, 4, 3, but the adjoints of layers 4 and 3 feed
@@ -153,11 +158,12 @@ int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
                        const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar,
                        void* stream);
 
-/* The same with pre[0] read (packed & 1) and abar_out[0] written (packed & 2) as PACKED layer buffers; compiled for
- * packed == 3 (bf16 mode, nf = 32, S1 = 3). */
+/* bf16 mode: the same chain on the bf16 MFMA with every pre[] / abar_out[] a PACKED layer buffer (packed == 3);
+ * WhT16_pack: bf16 packs of the transposed weights of layers 3 and 4 ([MT/2][KT][64] x 8 bf16; entry [2] is not read,
+ * the product through the output layer stays fp32).  packed == 0 and WhT16_pack == NULL: stpde_jet_tail_bwd. */
 int stpde_jet_tail_bwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
                          const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar, int packed,
-                         void* stream);
+                         const void* const* WhT16_pack, void* stream);
 
 /* Backward of the same layer w.r.t. its hidden input (the autograd backward of the addmm/activation graph,
  * i.e. what loss.backward() at experiments/rb2d/train.py:77 does through src/implicit_net.py:48-54):

@@ -47,6 +47,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const __bf16* p) {
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// v_mfma_f32_16x16x16_bf16: lane l holds A[l&15][4*(l>>4)+e], B[4*(l>>4)+e][l&15], e = 0..3
+__device__ __forceinline__ f32x4 mfma_bf16k(bf16x4 a, bf16x4 b, f32x4 c) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

@@ -15,12 +15,12 @@ struct TailArgs {
   float* out[3];                 // [tile][S][MT_l][256]
   const float* cw;
   int ntiles;
-  int packed;                    // 1: in2 is a packed layer buffer
+  const void* Wh16[3];           // bf16 A-operand packs of the three layers (k_tail_fwd_bf) or null
+  int packed;                    // k_tail_fwd_bf: 1 = in2 is a packed layer buffer, 2 = out[0] / out[1] are written packed
   stpde_jet_cfg cfg;
 };
 
-// PIN: in2 is a PACKED layer buffer (bf16 mode, common.h ld_blk: value stream fp32, derivative streams bf16)
-template <int S1, int S2, int ACT, int NFT, bool PIN = false>
+template <int S1, int S2, int ACT, int NFT>
 __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
   constexpr int S = 1 + S1 + S2;
   constexpr int KT3 = 4 * NFT, MT3 = 2 * NFT, MT4 = NFT, MT5 = 1;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
   {
     f32x4 raw[S], w[MT3];
 #pragma unroll
-    for (int st = 0; st < S; ++st) raw[st] = ld_blk_raw(a.in2, PIN, tile, S, KT3, st, 0, lane);
+    for (int st = 0; st < S; ++st) raw[st] = ld4(a.in2 + (((size_t)tile * S + st) * KT3) * 256 + lo);
 #pragma unroll
     for (int mi = 0; mi < MT3; ++mi) w[mi] = ld4(a.Wh[0] + ((size_t)mi) * 256 + lo);
 #pragma unroll
@@ -73,12 +73,9 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
       const int kn = kt + 1 < KT3 ? kt + 1 : kt;
       f32x4 rawn[S], wn[MT3], B[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) rawn[st] = ld_blk_raw(a.in2, PIN, tile, S, KT3, st, kn, lane);
+      for (int st = 0; st < S; ++st) rawn[st] = ld4(a.in2 + (((size_t)tile * S + st) * KT3 + kn) * 256 + lo);
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi) wn[mi] = ld4(a.Wh[0] + ((size_t)kn * MT3 + mi) * 256 + lo);
-      // (packed derivative blocks are converted here, not at the load a k-tile ahead)
-#pragma unroll
-      for (int st = 0; st < S; ++st) raw[st] = blk_val(raw[st], PIN, st);
       act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi)
@@ -134,17 +131,167 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
   finish(2, MT5, 0, acc5);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 mode (BASELINE configs[3]), reference width: the same chain on the bf16 matrix pipe, every layer buffer in the PACKED
+// form (common.h: value stream fp32, derivative streams bf16).
+// These three layers are narrow (128 -> 64 -> 32 -> out): a rounding error of an operand is averaged over few terms, and the
+// oracle puts plain bf16 operands here at 2e-2 ... 5e-2 on the second-derivative streams (against 1e-3 for the two wide
+// layers together).  So both operands are split into TWO bf16 terms (x = hi + lo, 16 mantissa bits) and a product is three
+// v_mfma_f32_16x16x32_bf16 (lo x hi, hi x lo, hi x hi; fp32 accumulation): 315 MFMAs of 16 cycles per row tile instead of 840
+// of 33, at 2^-16 relative accuracy -- the mode's error stays that of the wide layers.  Two accumulator tiles of a layer,
+// activated and split, are lane by lane the B operands of one K = 32 step of the next layer -- the k-order of the bf16 weight
+// packs (lig_jet.ImNetPlan.pack_bf16: fp32 blocks (2q, mt) and (2q + 1, mt) lane by lane; [2][KT/2][MT][64] = hi, lo).  The
+// skip GEMM with the raw input stays on the exact fp32 MFMA (63 per tile), as in the wide bf16 layers.  The packed stores
+// round the derivative streams for the BACKWARD pass only: the chain itself runs on the unrounded accumulators.
+template <int S1, int S2, int ACT>
+__global__ __launch_bounds__(256, 2) void k_tail_fwd_bf(TailArgs a) {
+  constexpr int S = 1 + S1 + S2;
+  constexpr int KT3 = 8, MT3 = 4, MT4 = 2;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.ntiles) return;
+  const int lo = lane * 4;
+  float cq[6];
+  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  f32x4 xb[XT];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+
+  // epilogue of one layer: skip GEMM (fp32), tangent constants, store (packed: derivative streams rounded in place)
+  auto finish = [&](int l, int MT, int mt, f32x4* acc, bool pk) {
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+      const f32x4 w = ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
+#pragma unroll
+      for (int r = 0; r < x_live(xt); ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) acc[1 + d] += ld4(a.tanc[l] + ((size_t)d * MT + mt) * 256 + lo);
+    if (!pk) {
+#pragma unroll
+      for (int st = 0; st < S; ++st) st4(a.out[l] + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[st]);
+      return;
+    }
+    char* t = reinterpret_cast<char*>(a.out[l]) + (size_t)tile * packed_tile_bytes(S, MT);
+    st4(reinterpret_cast<float*>(t + (size_t)mt * 1024) + lo, acc[0]);
+#pragma unroll
+    for (int st = 1; st < S; ++st)
+      *reinterpret_cast<bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8) = to_bf4(acc[st]);
+  };
+  // two activated blocks -> the B operands (hi, lo) of one K = 32 step
+  auto pair_b = [&](const f32x4* p0, const f32x4* p1, bf16x8 (*B8)[2]) {
+    f32x4 h0[S], h1[S];
+    act_jet_fwd<S1, S2, ACT>(a.cfg, p0, h0, cq);
+    act_jet_fwd<S1, S2, ACT>(a.cfg, p1, h1, cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      const bf16x4 a0 = to_bf4(h0[st]), a1 = to_bf4(h1[st]);
+      B8[st][0] = cat8(a0, a1);
+      B8[st][1] = cat8(to_bf4(h0[st] - bf4_to_f32(a0)), to_bf4(h1[st] - bf4_to_f32(a1)));   // residuals: exact in fp32
+    }
+  };
+  // one K = 32 step of the two-term product, smallest partial products first
+  auto mma3 = [&](const bf16x8* w8, const bf16x8* b8, f32x4 c) -> f32x4 {
+    c = mfma_bf(w8[1], b8[0], c);
+    c = mfma_bf(w8[0], b8[1], c);
+    return mfma_bf(w8[0], b8[0], c);
+  };
+
+  // ---- fc3: B operands from the packed stash of fc2's rows (the next pair of k-tiles in flight)
+  f32x4 acc3[MT3][S];
+#pragma unroll
+  for (int mi = 0; mi < MT3; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc3[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const bf16x8* W3 = reinterpret_cast<const bf16x8*>(a.Wh16[0]) + lane;      // [2][KT3 / 2][MT3][64]
+    f32x4 raw[2][S];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int st = 0; st < S; ++st) raw[e][st] = ld_blk_raw(a.in2, true, tile, S, KT3, st, e, lane);
+#pragma unroll
+    for (int q = 0; q < KT3 / 2; ++q) {
+      const int qn = q + 1 < KT3 / 2 ? q + 1 : q;
+      f32x4 rawn[2][S];
+      bf16x8 w8[MT3][2], B8[S][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < S; ++st) rawn[e][st] = ld_blk_raw(a.in2, true, tile, S, KT3, st, 2 * qn + e, lane);
+#pragma unroll
+      for (int mi = 0; mi < MT3; ++mi)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) w8[mi][t] = W3[(((size_t)t * (KT3 / 2) + q) * MT3 + mi) * 64];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < S; ++st) raw[e][st] = blk_val(raw[e][st], true, st);
+      pair_b(raw[0], raw[1], B8);
+#pragma unroll
+      for (int mi = 0; mi < MT3; ++mi)
+#pragma unroll
+        for (int st = 0; st < S; ++st) acc3[mi][st] = mma3(w8[mi], B8[st], acc3[mi][st]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < S; ++st) raw[e][st] = rawn[e][st];
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT3; ++mi) finish(0, MT3, mi, acc3[mi], true);
+
+  // ---- fc4
+  f32x4 acc4[MT4][S];
+#pragma unroll
+  for (int mi = 0; mi < MT4; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc4[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const bf16x8* W4 = reinterpret_cast<const bf16x8*>(a.Wh16[1]) + lane;      // [2][MT3 / 2][MT4][64]
+#pragma unroll
+    for (int q = 0; q < MT3 / 2; ++q) {
+      bf16x8 B8[S][2];
+      pair_b(acc3[2 * q], acc3[2 * q + 1], B8);
+#pragma unroll
+      for (int mi = 0; mi < MT4; ++mi) {
+        bf16x8 w8[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) w8[t] = W4[(((size_t)t * (MT3 / 2) + q) * MT4 + mi) * 64];
+#pragma unroll
+        for (int st = 0; st < S; ++st) acc4[mi][st] = mma3(w8, B8[st], acc4[mi][st]);
+      }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT4; ++mi) finish(1, MT4, mi, acc4[mi], true);
+
+  // ---- fc5 (no activation after it; its rows go to the reduction as fp32 blocks)
+  f32x4 acc5[S];
+#pragma unroll
+  for (int st = 0; st < S; ++st) acc5[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    bf16x8 B8[S][2];
+    pair_b(acc4[0], acc4[1], B8);
+    const bf16x8 w8[2] = {reinterpret_cast<const bf16x8*>(a.Wh16[2])[lane],         // [2][1][1][64]
+                          reinterpret_cast<const bf16x8*>(a.Wh16[2])[64 + lane]};
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc5[st] = mma3(w8, B8[st], acc5[st]);
+  }
+  finish(2, 1, 0, acc5, false);
+}
+
 template <int S1, int S2, int ACT>
 static int launch_tail_nft(const TailArgs& a, int nft, hipStream_t stream) {
   const dim3 grid((a.ntiles + 3) / 4);
-  if (a.packed & 1) {
-    if constexpr (S1 == 3) {       // packed stash: the training stream sets of the bf16 mode, reference width only
-      if (nft == 2) {
-        STPDE_LAUNCH((k_tail_fwd<S1, S2, ACT, 2, true>), grid, dim3(256), 0, stream, a);
-        return stpde_check_launch("k_tail_fwd");
+  if (a.packed || a.Wh16[0]) {
+    if constexpr (S1 == 3) {       // bf16 mode: the training stream sets, reference width, every layer buffer packed
+      if (nft == 2 && a.packed == 3 && a.Wh16[0] && a.Wh16[1] && a.Wh16[2]) {
+        STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT>), grid, dim3(256), 0, stream, a);
+        return stpde_check_launch("k_tail_fwd_bf");
       }
     }
-    stpde_set_error("jet_tail_fwd: packed input is compiled for nf = 32 and S1 = 3 only");
+    stpde_set_error("jet_tail_fwd: the bf16-operand kernel is compiled for nf = 32, S1 = 3, packed = 3 with all three bf16 packs");
     return STPDE_E_UNSUPPORTED;
   }
   if (nft == 2)
@@ -168,22 +315,23 @@ static int launch_tail_act(const TailArgs& a, int nft, hipStream_t stream) {
 
 static int tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                     const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
-                    float* const* out_pre, const float* cw, int packed, void* stream);
+                    float* const* out_pre, const float* cw, int packed, const void* const* Wh16_pack, void* stream);
 
 extern "C" int stpde_jet_tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                                   const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
                                   float* const* out_pre, const float* cw, void* stream) {
-  return tail_fwd(cfg, ntiles, nf16, in_pre2, X, Wh_pack, Ws_pack, tanc, out_pre, cw, 0, stream);
+  return tail_fwd(cfg, ntiles, nf16, in_pre2, X, Wh_pack, Ws_pack, tanc, out_pre, cw, 0, nullptr, stream);
 }
 extern "C" int stpde_jet_tail_fwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                                     const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
-                                    float* const* out_pre, const float* cw, int packed, void* stream) {
-  return tail_fwd(cfg, ntiles, nf16, in_pre2, X, Wh_pack, Ws_pack, tanc, out_pre, cw, packed, stream);
+                                    float* const* out_pre, const float* cw, int packed, const void* const* Wh16_pack,
+                                    void* stream) {
+  return tail_fwd(cfg, ntiles, nf16, in_pre2, X, Wh_pack, Ws_pack, tanc, out_pre, cw, packed, Wh16_pack, stream);
 }
 
 static int tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* in_pre2, const float* X,
                     const float* const* Wh_pack, const float* const* Ws_pack, const float* const* tanc,
-                    float* const* out_pre, const float* cw, int packed, void* stream) {
+                    float* const* out_pre, const float* cw, int packed, const void* const* Wh16_pack, void* stream) {
   if (!cfg || ntiles <= 0 || (nf16 != 1 && nf16 != 2) || !in_pre2 || !X || !Wh_pack || !Ws_pack || !tanc || !out_pre ||
       cfg->act < 0 || cfg->act > 5) {
     stpde_set_error("jet_tail_fwd: bad argument (nf must be 16 or 32)");
@@ -205,6 +353,7 @@ static int tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float*
   a.cw = cw;
   a.ntiles = ntiles;
   a.packed = packed;
+  for (int l = 0; l < 3; ++l) a.Wh16[l] = Wh16_pack ? Wh16_pack[l] : nullptr;
   a.cfg = *cfg;
   const int S1 = cfg->S1, S2 = cfg->S2;
   if (S1 == 0 && S2 == 0) return launch_tail_act<0, 0>(a, nf16, (hipStream_t)stream);
@@ -231,12 +380,12 @@ struct TailBwdArgs {
   const float* cw;
   float* pbar;
   int ntiles;
-  int packed;                    // 1: pre[0] (stash of fc2's output rows) is packed, 2: out[0] (their adjoint) is written packed
+  const void* WhT16[3];          // bf16 packs of the transposed weights of layers 3, 4 (k_tail_bwd_bf; [2] unused) or null
+  int packed;                    // k_tail_bwd_bf: 3 = every pre[] / out[] is a packed layer buffer
   stpde_jet_cfg cfg;
 };
 
-// PK2: compile-time copy of TailBwdArgs.packed
-template <int S1, int S2, int ACT, int NFT, int PK2 = 0>
+template <int S1, int S2, int ACT, int NFT>
 __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
   constexpr int S = 1 + S1 + S2;
   constexpr int T2 = 4 * NFT, T3 = 2 * NFT, T4 = NFT;     // feature tiles of the outputs of layers 2, 3, 4
@@ -254,14 +403,13 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
     const float* buf_in = a.pre[l];
     float* buf = a.out[l];
     f32x4 pre[S], ab[S];
-    const bool pin = l == 0 && (PK2 & 1), pout = l == 0 && (PK2 & 2);     // compile-time after inlining (l is a literal)
 #pragma unroll
-    for (int st = 0; st < S; ++st) pre[st] = ld_blk(buf_in, pin, tile, S, MT, st, mt, lane);
+    for (int st = 0; st < S; ++st) pre[st] = ld4(buf_in + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
     act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc, ab, cq);
     if (swish) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc, cq);
 #pragma unroll
     for (int st = 0; st < S; ++st) {
-      st_blk(buf, pout, tile, S, MT, st, mt, lane, ab[st]);
+      st4(buf + (((size_t)tile * S + st) * MT + mt) * 256 + lo, ab[st]);
       acc[st] = ab[st];
     }
   };
@@ -327,17 +475,140 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 mode: the input-gradient chain on the bf16 pipe, every layer buffer packed (see k_tail_fwd_bf).  The adjoint blocks
+// of a layer, as they are stored (derivative streams bf16), are pairwise the B operand of the transposed product in front;
+// the narrow product through fc5 (K = one 16-feature tile) stays on the fp32 MFMA.  All stash blocks of layers 3 / 4 are
+// requested at the head of the kernel, those of layer 2 one pair of tiles ahead of their use.
+template <int S1, int S2, int ACT>
+__global__ __launch_bounds__(256, 2) void k_tail_bwd_bf(TailBwdArgs a) {
+  constexpr int S = 1 + S1 + S2;
+  constexpr int T2 = 8, T3 = 4, T4 = 2;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.ntiles) return;
+  const int lo = lane * 4;
+  float cq[6];
+  load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
+  float pacc = 0.f;
+  const bool swish = (ACT == STPDE_ACT_SWISH) && a.pbar;
+
+  f32x4 b5[S], p4[T4][S], p3[T3][S], p2[2][S];
+#pragma unroll
+  for (int st = 0; st < S; ++st) b5[st] = ld4(a.abar5 + ((size_t)tile * S + st) * 256 + lo);
+#pragma unroll
+  for (int mi = 0; mi < T4; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) p4[mi][st] = ld_blk_raw(a.pre[2], true, tile, S, T4, st, mi, lane);
+#pragma unroll
+  for (int mi = 0; mi < T3; ++mi)
+#pragma unroll
+    for (int st = 0; st < S; ++st) p3[mi][st] = ld_blk_raw(a.pre[1], true, tile, S, T3, st, mi, lane);
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int st = 0; st < S; ++st) p2[e][st] = ld_blk_raw(a.pre[0], true, tile, S, T2, st, e, lane);
+
+  // hbar (accumulator tile) + raw stash blocks -> adjoint: stored packed, returned as the bf16 blocks of the next B operand
+  auto adjoint = [&](int l, int MT, int mt, const f32x4* praw, const f32x4* hbar, bf16x4* ob) {
+    f32x4 pre[S], ab[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) pre[st] = blk_val(praw[st], true, st);
+    act_jet_adj<S1, S2, ACT>(a.cfg, pre, hbar, ab, cq);
+    if (swish) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, hbar, cq);
+    char* t = reinterpret_cast<char*>(a.out[l]) + (size_t)tile * packed_tile_bytes(S, MT);
+    st4(reinterpret_cast<float*>(t + (size_t)mt * 1024) + lo, ab[0]);
+    ob[0] = to_bf4(ab[0]);
+#pragma unroll
+    for (int st = 1; st < S; ++st) {
+      ob[st] = to_bf4(ab[st]);
+      *reinterpret_cast<bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8) = ob[st];
+    }
+  };
+
+  // ---- through fc5 (fp32: K = 16): abar_5 -> hbar_4 [T4 tiles] -> abar_4
+  bf16x4 o4[T4][S];
+#pragma unroll
+  for (int mi = 0; mi < T4; ++mi) {
+    const f32x4 w = ld4(a.WhT[2] + ((size_t)mi) * 256 + lo);
+    f32x4 hb[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) hb[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int st = 0; st < S; ++st) hb[st] = mfma4(w[r], b5[st][r], hb[st]);
+    adjoint(2, T4, mi, p4[mi], hb, o4[mi]);
+  }
+  // ---- through fc4: abar_4 (one K = 32 step) -> hbar_3 [T3 tiles] -> abar_3
+  bf16x4 o3[T3][S];
+  {
+    const bf16x8* W4T = reinterpret_cast<const bf16x8*>(a.WhT16[1]) + lane;      // [T4 / 2][T3][64]
+    bf16x8 B8[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) B8[st] = cat8(o4[0][st], o4[1][st]);
+#pragma unroll
+    for (int mi = 0; mi < T3; ++mi) {
+      const bf16x8 w8 = W4T[(size_t)mi * 64];
+      f32x4 hb[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) hb[st] = mfma_bf(w8, B8[st], f32x4{0.f, 0.f, 0.f, 0.f});
+      adjoint(1, T3, mi, p3[mi], hb, o3[mi]);
+    }
+  }
+  // ---- through fc3: abar_3 (two K = 32 steps) -> hbar_2 [T2 tiles] -> abar_2, two output tiles at a time
+  {
+    const bf16x8* W3T = reinterpret_cast<const bf16x8*>(a.WhT16[0]) + lane;      // [T3 / 2][T2][64]
+    bf16x8 B8[2][S];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int st = 0; st < S; ++st) B8[q][st] = cat8(o3[2 * q][st], o3[2 * q + 1][st]);
+#pragma unroll
+    for (int m0 = 0; m0 < T2; m0 += 2) {
+      const int mn = m0 + 2 < T2 ? m0 + 2 : m0;
+      f32x4 p2n[2][S];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < S; ++st) p2n[e][st] = ld_blk_raw(a.pre[0], true, tile, S, T2, st, mn + e, lane);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x4 hb[S];
+        bf16x4 o2[S];
+#pragma unroll
+        for (int st = 0; st < S; ++st) hb[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bf16x8 w8 = W3T[((size_t)q * T2 + m0 + e) * 64];
+#pragma unroll
+          for (int st = 0; st < S; ++st) hb[st] = mfma_bf(w8, B8[q][st], hb[st]);
+        }
+        adjoint(0, T2, m0 + e, p2[e], hb, o2);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < S; ++st) p2[e][st] = p2n[e][st];
+    }
+  }
+  if (swish) {
+    const float v = wave_sum(pacc);
+    if (lane == 0) atomicAdd(a.pbar + (blockIdx.x % STPDE_PBAR_SLOTS), v);
+  }
+}
+
 template <int S1, int S2, int ACT>
 static int launch_tailb_nft(const TailBwdArgs& a, int nft, hipStream_t stream) {
   const dim3 grid((a.ntiles + 3) / 4);
-  if (a.packed) {
+  if (a.packed || a.WhT16[0]) {
     if constexpr (S1 == 3) {
-      if (nft == 2 && a.packed == 3) {
-        STPDE_LAUNCH((k_tail_bwd<S1, S2, ACT, 2, 3>), grid, dim3(256), 0, stream, a);
-        return stpde_check_launch("k_tail_bwd");
+      if (nft == 2 && a.packed == 3 && a.WhT16[0] && a.WhT16[1]) {
+        STPDE_LAUNCH((k_tail_bwd_bf<S1, S2, ACT>), grid, dim3(256), 0, stream, a);
+        return stpde_check_launch("k_tail_bwd_bf");
       }
     }
-    stpde_set_error("jet_tail_bwd: packed buffers are compiled for nf = 32, S1 = 3, packed = 3 only");
+    stpde_set_error("jet_tail_bwd: the bf16-operand kernel is compiled for nf = 32, S1 = 3, packed = 3 with the bf16 packs of fc3 / fc4");
     return STPDE_E_UNSUPPORTED;
   }
   if (nft == 2)
@@ -361,22 +632,23 @@ static int launch_tailb_act(const TailBwdArgs& a, int nft, hipStream_t stream) {
 
 static int tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
                     const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar, int packed,
-                    void* stream);
+                    const void* const* WhT16_pack, void* stream);
 
 extern "C" int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5,
                                   const float* const* WhT_pack, const float* const* pre, float* const* abar_out,
                                   const float* cw, float* act_param_bar, void* stream) {
-  return tail_bwd(cfg, ntiles, nf16, abar5, WhT_pack, pre, abar_out, cw, act_param_bar, 0, stream);
+  return tail_bwd(cfg, ntiles, nf16, abar5, WhT_pack, pre, abar_out, cw, act_param_bar, 0, nullptr, stream);
 }
 extern "C" int stpde_jet_tail_bwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5,
                                     const float* const* WhT_pack, const float* const* pre, float* const* abar_out,
-                                    const float* cw, float* act_param_bar, int packed, void* stream) {
-  return tail_bwd(cfg, ntiles, nf16, abar5, WhT_pack, pre, abar_out, cw, act_param_bar, packed, stream);
+                                    const float* cw, float* act_param_bar, int packed, const void* const* WhT16_pack,
+                                    void* stream) {
+  return tail_bwd(cfg, ntiles, nf16, abar5, WhT_pack, pre, abar_out, cw, act_param_bar, packed, WhT16_pack, stream);
 }
 
 static int tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
                     const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar, int packed,
-                    void* stream) {
+                    const void* const* WhT16_pack, void* stream) {
   if (!cfg || ntiles <= 0 || (nf16 != 1 && nf16 != 2) || !abar5 || !WhT_pack || !pre || !abar_out || cfg->act < 0 ||
       cfg->act > 5) {
     stpde_set_error("jet_tail_bwd: bad argument (nf must be 16 or 32)");
@@ -397,6 +669,7 @@ static int tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float*
   a.pbar = act_param_bar;
   a.ntiles = ntiles;
   a.packed = packed;
+  for (int l = 0; l < 3; ++l) a.WhT16[l] = WhT16_pack ? WhT16_pack[l] : nullptr;
   a.cfg = *cfg;
   const int S1 = cfg->S1, S2 = cfg->S2;
   if (S1 == 0 && S2 == 0) return launch_tailb_act<0, 0>(a, nf16, (hipStream_t)stream);

@@ -532,8 +532,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 // a private 2.5 KB patch with wave-local barriers only, and 3-4 waves per SIMD overlap each other's latencies.  The
 // four waves of a block are summed through LDS before the atomics.
 // ------------------------------------------------------------------------------------------------------------
-// QPK: Q (the layer input's pre-activations) is a packed layer buffer (bf16 mode: fc3 reading the packed stash of fc2's rows)
-template <int S1, int S2, int ACT, int MCW, int KTT, bool QPK = false>
+// PKW (bf16 mode): 1 = Q (the layer input's pre-activations) is a PACKED layer buffer, 2 = P (the adjoint) as well; the
+// contraction over the rows then runs on v_mfma_f32_16x16x16_bf16 (BFM): the four fp32 k-steps of a transposed block pair
+// are one bf16 MFMA on the rounded blocks (same (lane group, element) -> row map on both operands, so the sum is the same).
+// The raw-input columns (exact skip operand) stay on the fp32 MFMA.
+template <int S1, int S2, int ACT, int MCW, int KTT, int PKW = 0, bool BFM = false>
 __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
   constexpr int S = 1 + S1 + S2, NK = KTT + XT;
   constexpr int TP = 24, TBLK = 16 * TP;
@@ -573,33 +576,38 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
     load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
     f32x4 pa[S][MCW];
     {
-      const float* pbase = a.P + (size_t)tile * S * MT * 256 + lo;
       f32x4 raw[S][MCW];
 #pragma unroll
       for (int st = 0; st < S; ++st)
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) {
           const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
-          raw[st][mi] = ld4(pbase + ((size_t)st * MT + mt) * 256);
+          raw[st][mi] = ld_blk_raw(a.P, (PKW & 2) != 0, tile, S, MT, st, mt, lane);
         }
 #pragma unroll
       for (int st = 0; st < S; ++st)
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(raw[st][mi]);
+        for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(blk_val(raw[st][mi], (PKW & 2) != 0, st));
     }
 #pragma unroll
     for (int ki = 0; ki < KTT; ++ki) {
       f32x4 pre[S], H[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, QPK, tile, S, KTT, st, ki, lane);
+      for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKW & 1) != 0, tile, S, KTT, st, ki, lane);
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) {
         const f32x4 hr = transpose(H[st]);
+        if constexpr (BFM) {
+          const bf16x4 h16 = to_bf4(hr);
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi)
+          for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma_bf16k(to_bf4(pa[st][mi]), h16, acc[mi][ki]);
+        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mi][ki] = mfma4(pa[st][mi][r], hr[r], acc[mi][ki]);
+          for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ki] = mfma4(pa[st][mi][r], hr[r], acc[mi][ki]);
+        }
       }
     }
 #pragma unroll
@@ -662,13 +670,18 @@ static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
   if (gx > (a.ntiles + 3) / 4) gx = (a.ntiles + 3) / 4;
   if (gx < 1) gx = 1;
   if (a.pk) {
-    if constexpr (KTT == 8 && MCW == 4 && S1 == 3) {       // fc3 of the reference width, training stream sets
+    // bf16 mode, fc3 / fc4 / fc5 of the reference width: packed operands (WgradArgs.pk: 1 = Q, 4 = P), bf16 contraction
+    if constexpr (S1 == 3 && ((KTT == 8 && (MCW == 4 || MCW == 2)) || (KTT == 4 && MCW == 2) || (KTT == 2 && MCW == 1))) {
+      if (a.pk == 5) {
+        STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT, 3, true>), dim3(gx, gy), dim3(256), 0, stream, a);
+        return stpde_check_launch("k_wgrad_wave");
+      }
       if (a.pk == 1) {
-        STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT, true>), dim3(gx, gy), dim3(256), 0, stream, a);
+        STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT, 1, true>), dim3(gx, gy), dim3(256), 0, stream, a);
         return stpde_check_launch("k_wgrad_wave");
       }
     }
-    stpde_set_error("jet_wgrad: packed input not compiled for this narrow-layer shape");
+    stpde_set_error("jet_wgrad: packed operands (%d) not compiled for this narrow-layer shape", a.pk);
     return STPDE_E_UNSUPPORTED;
   }
   STPDE_LAUNCH((k_wgrad_wave<S1, S2, ACT, MCW, KTT>), dim3(gx, gy), dim3(256), 0, stream, a);
@@ -692,7 +705,8 @@ static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
       // of this HBM-bound kernel (the two-pass grid reads abar3 / pre2 twice: 11.4 -> 9.6 ms per step, 368 registers = one wave
       // per SIMD); STPDE_WGRAD_MCW4=0: two passes
       static const int mcw4 = getenv("STPDE_WGRAD_MCW4") ? atoi(getenv("STPDE_WGRAD_MCW4")) : 1;
-      if (a.KT == 8 && a.MT == 4 && mcw4) return launch_wgrad_wave<S1, S2, ACT, 4, 8>(a, stream);
+      static const int mcw4_bf = getenv("STPDE_WGRAD_MCW4_BF") ? atoi(getenv("STPDE_WGRAD_MCW4_BF")) : 1;
+      if (a.KT == 8 && a.MT == 4 && (a.pk ? mcw4_bf : mcw4)) return launch_wgrad_wave<S1, S2, ACT, 4, 8>(a, stream);
       if (a.KT == 8) return launch_wgrad_wave<S1, S2, ACT, 2, 8>(a, stream);
     }
     return -1;

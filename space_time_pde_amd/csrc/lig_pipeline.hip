@@ -137,7 +137,10 @@ extern "C" int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* p, const stpde_je
       const float* tc[3] = {p->tanc[3], p->tanc[4], p->tanc[5]};
       float* outs[3] = {ws->pre[3], ws->pre[4], ws->pre[5]};
       seq([&] {
-        return stpde_jet_tail_fwd_p(&lcfg, lnt, p->nf16, prev, ws->X, Wh, Wsk, tc, outs, ws->cw, is_packed(p, 2) ? 1 : 0, stream);
+        const void* w16[3] = {p->Wh16[3], p->Wh16[4], p->Wh16[5]};
+        const bool pk = is_packed(p, 2);      // bf16 mode: packed buffers on both sides, bf16-operand kernel
+        return stpde_jet_tail_fwd_p(&lcfg, lnt, p->nf16, prev, ws->X, Wh, Wsk, tc, outs, ws->cw, pk ? 3 : 0, pk ? w16 : nullptr,
+                                    stream);
       });
       break;
     }
@@ -219,8 +222,10 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     const float* pre[3] = {ws->pre[2], ws->pre[3], ws->pre[4]};
     float* outs[3] = {abar[2], abar[3], ws->pre[4]};
     seq([&] {
-      return stpde_jet_tail_bwd_p(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, is_packed(p, 2) ? 3 : 0,
-                                  stream);
+      const void* w16[3] = {p->WhT16[3], p->WhT16[4], nullptr};
+      const bool pk = is_packed(p, 2);
+      return stpde_jet_tail_bwd_p(&cfg, nt, p->nf16, ws->pre[5], WhT, pre, outs, ws->cw, act_param_bar, pk ? 3 : 0,
+                                  pk ? w16 : nullptr, stream);
     });
   };
   auto dgrad_l = [&](int l) {

@@ -177,22 +177,25 @@ class ImNetPlan:
 
     def pack_bf16(self, packs, nsplit=1):
         """bf16 A-operand packs of the hidden-to-hidden weights: block (q, mt) = the fp32 blocks (2q, mt) and (2q+1, mt)
-        lane by lane.  nsplit = 1 (config-4 path): rounded to bf16.  nsplit = 3 ("fp32x3"): each weight split exactly
-        into three bf16 terms hi + mid + lo (8 + 8 + 8 mantissa bits), stacked [3][...] -- the weight side of the
-        fp32-accurate six-product scheme of k_layer_coop<..., SPL = 3>.  Returns {(l, "Wh"|"WhT"): tensor}."""
+        lane by lane.  nsplit = 1 (config-4 path): rounded to bf16 -- except the forward packs of the three narrow layers
+        fc3 ... fc5, which carry TWO terms hi + lo stacked [2][...] for the two-term products of k_tail_fwd_bf (a kernel that
+        takes one term reads the hi part, which comes first).  nsplit = 3 ("fp32x3"): each weight split exactly into three
+        bf16 terms hi + mid + lo (8 + 8 + 8 mantissa bits), stacked [3][...] -- the weight side of the fp32-accurate
+        six-product scheme of k_layer_coop<..., SPL = 3>.  Returns {(l, "Wh"|"WhT"): tensor}."""
         out = {}
         for l in range(1, 6):
             kt, mt = self.layers[l]["KT"], self.layers[l]["MT"]
             for name, (ka, ma) in (("Wh", (kt, mt)), ("WhT", (mt, kt))):
                 if ka % 2 == 0:
                     w = self.pack_view(packs, l, name).view(ka // 2, 2, ma, 64, 4).permute(0, 2, 3, 1, 4)
+                    nterm = 2 if (nsplit == 1 and l >= 3 and name == "Wh") else nsplit
                     terms, r = [], w
-                    for t in range(nsplit):
+                    for t in range(nterm):
                         h = r.to(torch.bfloat16)
                         terms.append(h)
-                        if t + 1 < nsplit:
+                        if t + 1 < nterm:
                             r = r - h.float()
-                    out[(l, name)] = (torch.stack(terms, 0) if nsplit > 1 else terms[0]).contiguous()
+                    out[(l, name)] = (torch.stack(terms, 0) if nterm > 1 else terms[0]).contiguous()
         return out
 
     def pack_view(self, packs, l, name):
@@ -532,14 +535,16 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     for l in range(1, 6):
         lay = plan.layers[l]
         if tail and l == 3:
-            outs = [torch.empty(nt * S * plan.layers[k]["MT"] * _FRAG, device=dev) for k in (3, 4, 5)]
+            outs = [torch.empty(_buf_floats(meta, k, nt), device=dev) for k in (3, 4, 5)]
             arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            pk_tail = (meta.packed_mask >> 2) & 1         # bf16 mode: packed buffers on both sides, bf16-operand kernel
+            w16s = arr([meta.packs16[(k, "Wh")] for k in (3, 4, 5)]) if pk_tail else None
             with _timed("tail_fwd"):
                 check(L.stpde_jet_tail_fwd_p(C.byref(lcfg), lnt, plan.nf // 16, ptr(prev), ptr(X),
                                              arr([pv(packs, k, "Wh") for k in (3, 4, 5)]),
                                              arr([pv(packs, k, "Ws") for k in (3, 4, 5)]),
                                              arr([pv(packs, k, "tanc") for k in (3, 4, 5)]), arr(outs), ptr(cw),
-                                             (meta.packed_mask >> 2) & 1, st))
+                                             3 if pk_tail else 0, w16s, st))
             bufs += outs
             break
         out = torch.empty(_buf_floats(meta, l, nt), device=dev)
@@ -613,11 +618,14 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
             if l == 5:
                 abar[3], abar[2] = torch.empty_like(bufs[3]), torch.empty_like(bufs[2])
                 arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+                pk_tail = (meta.packed_mask >> 2) & 1
+                w16s = (C.c_void_p * 3)(meta.packs16[(3, "WhT")].data_ptr(), meta.packs16[(4, "WhT")].data_ptr(), None) \
+                    if pk_tail else None
                 with _timed("tail_dgrad"):
                     check(L.stpde_jet_tail_bwd_p(C.byref(cfg), nt, plan.nf // 16, ptr(bufs[5]),
                                                  arr([pv(packs, k, "WhT") for k in (3, 4, 5)]),
                                                  arr([bufs[2], bufs[3], bufs[4]]), arr([abar[2], abar[3], abar[4]]),
-                                                 ptr(cw), ptr(pbar), 3 if (meta.packed_mask >> 2) & 1 else 0, st))
+                                                 ptr(cw), ptr(pbar), 3 if pk_tail else 0, w16s, st))
             continue
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(abar[l]), ptr(pv(packs, l, "WhT")),
@@ -907,9 +915,9 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.bf16 = precision in ("bf16", "fp32x3")
     meta.nsplit = 3 if precision == "fp32x3" else 1
     meta.packs16 = None
-    # bf16 mode, reference width: the stashes of fc1's and fc2's output rows (70 % of the mode's HBM traffic) in the PACKED
-    # form -- their consumers are the bf16-operand kernels of layers 1-2 and the fused fc3 -> fc5 kernels / fc3's weight
-    # gradient, which read the packed form.  STPDE_PACKED_STASH=0: fp32 blocks as in rounds 1-2.
+    # bf16 mode, reference width: the stashes of the hidden layers' output rows and their adjoints in the PACKED form -- all
+    # of their consumers are bf16-operand kernels (layers 1-2: k_layer_coop / k_wgrad_coop; fc3 -> fc5: k_tail_fwd_bf /
+    # k_tail_bwd_bf and the bf16 variant of k_wgrad_wave).  STPDE_PACKED_STASH=0: fp32 blocks, fp32 MFMA in fc3 -> fc5.
     meta.packed_mask = 0
     # output streams (what the caller gets) vs MLP streams (what the layer kernels carry): for piecewise-linear
     # activations sigma'' = 0 makes every second-order MLP stream identically zero, so only value + gradient streams
@@ -922,7 +930,8 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     # (S > 6 is not served by the bf16 kernels; the packed buffer of fc2's rows is read by the fused fc3 -> fc5 kernels)
     if precision == "bf16" and packed_stash and imnet.nf == 32 and meta.S <= 6:
         tail_ok = fused_tail and meta.cfg.S1 == 3 and (meta.cfg.S2 != 1 or bool(meta.cfg_out.combo))
-        meta.packed_mask = 6 if tail_ok else 0      # (the bf16 kernels are compiled for "both boundaries packed" or none)
+        # the buffers of fc1 ... fc4's rows (the bf16 kernels are compiled for "every boundary packed" or none)
+        meta.packed_mask = 30 if tail_ok else 0
     meta.B, meta.N = B, N
     meta.grid_shape = tuple(latent_grid.shape[1:4])
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)

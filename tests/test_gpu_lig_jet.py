@@ -239,8 +239,10 @@ def _bf16_layers(nf):
 
 @pytest.mark.parametrize("act", ["softplus", "leakyrelu", "tanh"])
 def test_bf16_mfma_mode_config4(hiplib, act):
-    """BASELINE config 4: bf16 MFMA operands / fp32 accumulation in the wide layers.  Tolerances (explicit, looser
-    than the fp32 path): vs an oracle that rounds the same operands to bf16: 5e-4 (Frobenius); vs exact fp64: 3e-2."""
+    """BASELINE config 4: bf16 MFMA operands / fp32 accumulation in every hidden-to-hidden product (one bf16 term in the
+    wide layers, two in the narrow ones), packed layer buffers.  Tolerances (explicit, looser than the fp32 path): vs an
+    oracle that rounds the same operands / stored streams to bf16: 5e-4 (Frobenius); vs exact fp64: 3e-2."""
+    assert _bf16_layers(32) == (1, 2)
     from space_time_pde_amd import lig_jet
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(11)
@@ -248,12 +250,15 @@ def test_bf16_mfma_mode_config4(hiplib, act):
     pts = 0.02 + 0.96 * torch.rand(2, 150, 3, generator=g)
     pairs = ((1, 1), (2, 2))
     net = _net(act, nf=32).to(dev)
-    assert _bf16_layers(32) == (1, 2)
     latd = lat.to(dev).requires_grad_(True)
     jets, pp = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, pairs, chunk_points=128, precision="bf16")
     with torch.no_grad():
         jets32, _ = lig_jet.lig_jets(net, lat.to(dev), pts.to(dev), 0., 1., True, pairs, chunk_points=128)
-    # the stashes of fc1's and fc2's output rows are PACKED in this mode (derivative streams stored as bf16): emulated as well
+    # what the emulation covers: bf16 operands in the two wide layers, and their stored output rows (packed layer buffers:
+    # derivative streams kept as bf16), which the next layer's forward reads.  The three narrow layers run on TWO-term bf16
+    # operands (2^-16 relative: exact at this test's resolution); the packed stores of their rows are read by the backward
+    # pass only.  (One-term bf16 operands in the narrow layers would put the second-derivative streams 2e-2 ... 5e-2 from
+    # exact -- oracle, tools/micro/dbg_bf16_emul.py -- which is why they are not used.)
     emu = J.lig_jets(_params64(net), act, lat.double(), pts.double(), 0., 1., second=tuple(pp),
                      bf16_layers=_bf16_layers(32), bf16_pre_tangents=(1, 2))
     emu = emu.permute(0, 3, 1, 2).reshape(emu.shape[0], 4, -1)
