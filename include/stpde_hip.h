@@ -112,12 +112,16 @@ typedef struct {
    * below 2^-24 of the result, i.e. below fp32 rounding.  6 bf16 MFMAs (K = 32) replace 8 fp32 MFMAs at 1/16 of the
    * per-instruction time. */
   int mfma_bf16;
-  /* PACKED layer buffers (round 3, bf16 mode only): a buffer whose every consumer is a bf16-operand kernel may keep its
-   * value stream in fp32 and its derivative streams in bf16 -- per row tile [MT][64][4] fp32, then [S-1][MT][64][4] bf16,
-   * MT * (1024 + (S-1) * 512) bytes instead of MT * S * 1024.  Bit mask: 1 = in_pre (hidden input / the pre-activations a
-   * backward kernel takes its adjoint against) is packed, 2 = the buffer this call WRITES (out_pre of a forward call, the
-   * adjoint destination of stpde_jet_layer_bwd / _bwd_to) is packed, 4 = abar_out (input of the backward / weight-gradient
-   * kernels) is packed. */
+  /* PACKED layer buffers (round 3, bf16 mode only; every consumer of such a buffer is a bf16-operand kernel).  Two formats:
+   *   packed STASH   (buffers of pre-activations): value stream fp32, derivative streams bf16 -- per row tile
+   *                  [MT][64][4] fp32, then [S-1][MT][64][4] bf16: MT * (1024 + (S-1) * 512) bytes instead of MT * S * 1024;
+   *   packed ADJOINT (buffers of adjoints): every stream bf16 -- per row tile [S][MT][64][4] bf16, MT * S * 512 bytes (all
+   *                  consumers round every stream to a bf16 MFMA operand; the d-latent reduction reads stream 0).  An
+   *                  adjoint buffer never aliases the stash it belongs to.
+   * Bit mask: 1 = in_pre (hidden input of a forward call / the pre-activations a backward kernel takes its adjoint against)
+   * is a packed stash, 2 = the buffer this call WRITES is packed (out_pre of a forward call: stash; the adjoint destination
+   * of stpde_jet_layer_bwd / _bwd_to, including the layer-0 adjoint of a first-hidden-layer call: adjoint format),
+   * 4 = abar_out (input of the backward / weight-gradient kernels) is a packed adjoint buffer. */
   int packed;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
@@ -158,7 +162,8 @@ int stpde_jet_tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const flo
                        const float* const* pre, float* const* abar_out, const float* cw, float* act_param_bar,
                        void* stream);
 
-/* bf16 mode: the same chain on the bf16 MFMA with every pre[] / abar_out[] a PACKED layer buffer (packed == 3);
+/* bf16 mode: the same chain on the bf16 MFMA with every pre[] a packed stash and every abar_out[] a packed ADJOINT buffer
+ * (packed == 3; abar_out[l] must not alias pre[l]);
  * WhT16_pack: bf16 packs of the transposed weights of layers 3 and 4 ([MT/2][KT][64] x 8 bf16; entry [2] is not read,
  * the product through the output layer stays fp32).  packed == 0 and WhT16_pack == NULL: stpde_jet_tail_bwd. */
 int stpde_jet_tail_bwd_p(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float* abar5, const float* const* WhT_pack,
@@ -224,7 +229,7 @@ typedef struct {
   int ntiles, nlayers, C, n1, n2;
   int MT[8];
   int SP[8];
-  int packed[8];   /* != 0: abar[l] is a packed layer buffer (stpde_layer_desc.packed) of S[l] streams */
+  int packed[8];   /* != 0: abar[l] is a packed ADJOINT buffer (stpde_layer_desc.packed) of S[l] streams */
   int S[8];        /* streams of a packed buffer (only read where packed[l] != 0) */
 } stpde_xbar_desc;
 /* abar / WsL_pack: HOST arrays of nlayers device pointers.  WsL_pack[l] = [MT_l][XL][64 lanes][4]: A operand of W_s,l^T
@@ -267,8 +272,9 @@ typedef struct {
   const void* Wh16[8];         /* bf16 packs of the wide layers or NULL */
   const void* WhT16[8];
   int mfma_bf16;               /* 0 / 1 / 3 as stpde_layer_desc.mfma_bf16 */
-  int packed_mask;             /* bit l: pre[l] (and the adjoint buffers that replace it) is a packed layer buffer
-                                  (stpde_layer_desc.packed); only with mfma_bf16 == 1 and bf16-operand kernels on both sides */
+  int packed_mask;             /* bit l >= 1: pre[l] is a packed stash and the adjoint of layer l's rows a packed adjoint buffer
+                                  (stpde_layer_desc.packed); bit 0: the value-stream adjoint of layer 0 (workspace.abar0x) is
+                                  a packed adjoint buffer.  Only with mfma_bf16 == 1; the library serves 0, 30 and 31. */
   long dw_off[8];              /* offset (floats) of layer l's dW_aug block [16 MT][16 (KT + 3)] in dW_flat */
 } stpde_imnet_plan;
 typedef struct {
@@ -282,13 +288,15 @@ typedef struct {
   float* abar3x;
   float* tan0;
   float* abar0;
-  float* abar1x;   /* dgrad-first order only: fresh adjoint buffer of fc1's output rows (size of pre[1]) */
-  float* abar0x;   /* dgrad-first order only: fresh layer-0 adjoint [nt][MT_0][block] (the z0 stash stays intact) */
+  float* abar1x;   /* dgrad-first order / packed buffers: fresh adjoint buffer of fc1's output rows */
+  float* abar0x;   /* dgrad-first order / packed_mask bit 0: fresh layer-0 adjoint [nt][MT_0][block] (the z0 stash stays intact) */
   float* xrows;
   int* perm;
   int* start;
   void* sort_tmp;
   unsigned long sort_tmp_bytes;
+  float* abar4x;   /* packed buffers: adjoint buffer of fc4's output rows (abar2x / abar3x / abar4x / abar1x then hold packed
+                      ADJOINT buffers: nt * S * MT_l * 512 bytes) */
 } stpde_lig_workspace;
 #define STPDE_F_STASH 1          /* forward: keep what the backward needs (XR, z0) */
 #define STPDE_F_VALUE_TILES 2    /* forward-only value queries: four row tiles per pass over the weights */

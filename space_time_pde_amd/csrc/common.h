@@ -59,44 +59,56 @@ __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// PACKED layer buffers (round 3, bf16 mode): a buffer that is only ever consumed as a bf16 MFMA operand or as the argument of
-// an activation jet keeps its VALUE stream in fp32 and its derivative streams in bf16 --
-//   tile t:  [MT][64 lanes][4] fp32 (stream 0)  then  [S - 1][MT][64 lanes][4] bf16 (streams 1 .. S-1)
-// = MT * (1024 + (S - 1) * 512) bytes per row tile instead of MT * S * 1024: -40 % of the bytes of the HBM-bound kernels
-// around the widest stash (S = 5).  `packed` is wave-uniform; `st` is a compile-time index at every call site.
+// PACKED layer buffers (round 3, bf16 mode).  `mode` (wave-uniform, a compile-time constant at every call site):
+//   0  fp32 blocks           tile t: [S][MT][64 lanes][4] fp32
+//   1  packed STASH          tile t: [MT][64][4] fp32 (stream 0)  then  [S - 1][MT][64][4] bf16 (streams 1 .. S-1)
+//      a buffer of pre-activations: the value stream is the argument of the activation jets and stays fp32, the derivative
+//      streams are only ever multiplied into bf16 MFMA operands.  MT * (1024 + (S - 1) * 512) bytes per row tile
+//   2  packed ADJOINT        tile t: [S][MT][64][4] bf16
+//      a buffer of adjoints: every consumer rounds every stream to a bf16 MFMA operand anyway (input-gradient and
+//      weight-gradient products; the d-latent reduction reads the value stream).  MT * S * 512 bytes per row tile
+// against MT * S * 1024: -40 % / -50 % of the bytes of the HBM-bound kernels.  `st` is a compile-time index at every call site.
 __host__ __device__ inline size_t packed_tile_bytes(int S, int MT) { return (size_t)MT * (1024 + (S - 1) * 512); }
-__device__ __forceinline__ f32x4 ld_blk(const float* buf, bool packed, size_t tile, int S, int MT, int st, int mt, int lane) {
-  if (!packed) return ld4(buf + ((tile * S + st) * MT + mt) * 256 + lane * 4);
-  const char* t = reinterpret_cast<const char*>(buf) + tile * packed_tile_bytes(S, MT);
-  if (st == 0) return ld4(reinterpret_cast<const float*>(t + (size_t)mt * 1024) + lane * 4);
-  return bf4_to_f32(*reinterpret_cast<const bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8));
+__host__ __device__ inline size_t blk_tile_bytes(int mode, int S, int MT) {
+  return mode == 0 ? (size_t)S * MT * 1024 : (mode == 1 ? packed_tile_bytes(S, MT) : (size_t)S * MT * 512);
 }
-// The same load WITHOUT the bf16 -> fp32 conversion of a packed derivative block: the 8 bytes land in the first two
-// registers of the result and blk_val() converts them where the value is used -- for loads that are issued a whole row tile
-// ahead of their use (weight-gradient P operand), where a conversion at the load site would wait for the load at once.
-__device__ __forceinline__ f32x4 ld_blk_raw(const float* buf, bool packed, size_t tile, int S, int MT, int st, int mt, int lane) {
-  if (!packed || st == 0) return ld_blk(buf, packed, tile, S, MT, st, mt, lane);
-  const char* t = reinterpret_cast<const char*>(buf) + tile * packed_tile_bytes(S, MT);
-  const float2 v = *reinterpret_cast<const float2*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8);
+// byte offset of block (st, mt) inside its tile
+__device__ __forceinline__ size_t blk_off(int mode, int MT, int st, int mt) {
+  if (mode == 0) return ((size_t)st * MT + mt) * 1024;
+  if (mode == 2) return ((size_t)st * MT + mt) * 512;
+  return st == 0 ? (size_t)mt * 1024 : (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512;
+}
+__device__ __forceinline__ bool blk_is16(int mode, int st) { return mode == 2 || (mode == 1 && st > 0); }
+__device__ __forceinline__ f32x4 ld_blk(const float* buf, int mode, size_t tile, int S, int MT, int st, int mt, int lane) {
+  const char* b = reinterpret_cast<const char*>(buf) + tile * blk_tile_bytes(mode, S, MT) + blk_off(mode, MT, st, mt);
+  if (!blk_is16(mode, st)) return ld4(reinterpret_cast<const float*>(b) + lane * 4);
+  return bf4_to_f32(*reinterpret_cast<const bf16x4*>(b + lane * 8));
+}
+// The same load WITHOUT the bf16 -> fp32 conversion of a bf16 block: the 8 bytes land in the first two registers of the
+// result and blk_val() converts them where the value is used -- for loads that are issued a whole row tile ahead of their
+// use (weight-gradient P operand), where a conversion at the load site would wait for the load at once.
+__device__ __forceinline__ f32x4 ld_blk_raw(const float* buf, int mode, size_t tile, int S, int MT, int st, int mt, int lane) {
+  if (!blk_is16(mode, st)) return ld_blk(buf, mode, tile, S, MT, st, mt, lane);
+  const char* b = reinterpret_cast<const char*>(buf) + tile * blk_tile_bytes(mode, S, MT) + blk_off(mode, MT, st, mt);
+  const float2 v = *reinterpret_cast<const float2*>(b + lane * 8);
   return f32x4{v.x, v.y, 0.f, 0.f};
 }
-__device__ __forceinline__ f32x4 blk_val(f32x4 raw, bool packed, int st) {
-  if (!packed || st == 0) return raw;
+__device__ __forceinline__ bf16x4 raw_bf4(f32x4 raw) {
   float2 v;
   v.x = raw[0];
   v.y = raw[1];
-  return bf4_to_f32(__builtin_bit_cast(bf16x4, v));
+  return __builtin_bit_cast(bf16x4, v);
 }
-__device__ __forceinline__ void st_blk(float* buf, bool packed, size_t tile, int S, int MT, int st, int mt, int lane, f32x4 v) {
-  if (!packed) {
-    st4(buf + ((tile * S + st) * MT + mt) * 256 + lane * 4, v);
-    return;
-  }
-  char* t = reinterpret_cast<char*>(buf) + tile * packed_tile_bytes(S, MT);
-  if (st == 0)
-    st4(reinterpret_cast<float*>(t + (size_t)mt * 1024) + lane * 4, v);
+__device__ __forceinline__ f32x4 blk_val(f32x4 raw, int mode, int st) {
+  if (!blk_is16(mode, st)) return raw;
+  return bf4_to_f32(raw_bf4(raw));
+}
+__device__ __forceinline__ void st_blk(float* buf, int mode, size_t tile, int S, int MT, int st, int mt, int lane, f32x4 v) {
+  char* b = reinterpret_cast<char*>(buf) + tile * blk_tile_bytes(mode, S, MT) + blk_off(mode, MT, st, mt);
+  if (!blk_is16(mode, st))
+    st4(reinterpret_cast<float*>(b) + lane * 4, v);
   else
-    *reinterpret_cast<bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8) = to_bf4(v);
+    *reinterpret_cast<bf16x4*>(b + lane * 8) = to_bf4(v);
 }
 
 // Optional 16-byte stores without a branch: a raw buffer descriptor over [base, base + bytes) -- built from wave-uniform

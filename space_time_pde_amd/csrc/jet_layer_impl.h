@@ -65,7 +65,9 @@ struct LayerArgs {
                        // (may alias Out when Out holds the value stream only: each lane reads its element before it writes it)
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
-  int pk;              // packed-buffer flags (common.h: ld_blk / st_blk): 1 = Bin, 2 = Out, 4 = Pre
+  int pk;              // packed-buffer flags (common.h: ld_blk / st_blk): 1 = Bin, 2 = Out, 4 = Pre -- a forward kernel reads /
+                       // writes packed STASH buffers (mode 1); an input-gradient kernel reads its Pre as a stash, its Bin and
+                       // Out are packed ADJOINT buffers (mode 2)
   stpde_jet_cfg cfg;
 };
 
@@ -111,12 +113,12 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         for (int d = 0; d < 3; ++d) acc[mi][1 + d] += ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
       }
 #pragma unroll
-      for (int st = 0; st < S; ++st) st_blk(a.Out, (PKM & 2) != 0, tile, S, MT, st, mt, lane, acc[mi][st]);
+      for (int st = 0; st < S; ++st) st_blk(a.Out, (PKM & 2) ? 1 : 0, tile, S, MT, st, mt, lane, acc[mi][st]);
     } else {
       f32x4 pre[S], ab[S];
       if (EPI == EPI_ADJ) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Pre, (PKM & 4) != 0, tile, S, MT, st, mt, lane);
+        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Pre, (PKM & 4) ? 1 : 0, tile, S, MT, st, mt, lane);
       } else {
         pre[0] = z0pre ? *z0pre : ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {
@@ -134,7 +136,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         // Layer 0's tangent streams are the constant columns W0[:, d], so their adjoints enter d W0[:, d] only through
         // their sum over rows: reduce over the 16 rows of the tile here (DPP row reduction) and write 48 floats per
         // (tile, output tile) instead of three 1 KiB blocks -- the layer-0 adjoint shrinks to its value stream.
-        st4(a.Out + ((size_t)tile * MT + mt) * 256 + lo, ab[0]);
+        st_blk(a.Out, (PKM & 2) ? 2 : 0, tile, 1, MT, 0, mt, lane, ab[0]);      // (bf16 mode: the layer-0 adjoint as bf16 blocks)
         f32x4 ts[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -147,7 +149,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         }
       } else {
 #pragma unroll
-        for (int st = 0; st < SO; ++st) st_blk(a.Out, EPI == EPI_ADJ && (PKM & 2) != 0, tile, SO, MT, st, mt, lane, ab[st]);
+        for (int st = 0; st < SO; ++st) st_blk(a.Out, (PKM & 2) ? 2 : 0, tile, SO, MT, st, mt, lane, ab[st]);
       }
     }
 }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
       }
     } else {
 #pragma unroll
-      for (int st = 0; st < S; ++st) raw[st] = ld_blk(a.Bin, false, tile, S, KT, st, kt, lane);
+      for (int st = 0; st < S; ++st) raw[st] = ld_blk(a.Bin, 0, tile, S, KT, st, kt, lane);
     }
   };
   auto load_w = [&](int kt, f32x4* w) {
@@ -290,6 +292,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, GK = NW * PK;
   static_assert(!WRING || (!BF && GK == 4), "the weight ring is written for 4 k-tiles per group, fp32");
   static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");
+  // format of the B operand's buffer: a forward kernel reads a packed STASH, an input-gradient kernel a packed ADJOINT
+  constexpr int BMODE = (PKM & 1) ? (EPI == EPI_FWD ? 1 : 2) : 0;
   __shared__ __attribute__((aligned(16))) float hb[2][GK][S][BF ? 128 * SPL : 256];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
     } else {
 #pragma unroll
-      for (int st = 0; st < S; ++st) raw[st] = ld_blk(a.Bin, (PKM & 1) != 0, tile, S, KT, st, kt, lane);
+      for (int st = 0; st < S; ++st) raw[st] = ld_blk(a.Bin, BMODE, tile, S, KT, st, kt, lane);
     }
     if (PRO == PRO_NONE || STPDE_ABLATE == 1) {
 #pragma unroll
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
         for (int k = 0; k < PK; ++k)
 #pragma unroll
           for (int st = 0; st < S; ++st)
-            rawn[k][st] = ld_blk(a.Bin, (PKM & 1) != 0, tile, S, KT, st, GK * gnext + NW * k + wv, lane);
+            rawn[k][st] = ld_blk(a.Bin, BMODE, tile, S, KT, st, GK * gnext + NW * k + wv, lane);
       }
       f32x4 w0n[EARLY0 ? PK : 1][XT], tcn[EARLY0 ? PK : 1][3];
       if constexpr (EARLY0) {
@@ -592,7 +596,7 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   } else if (a.Wp16) {
     // the packed-buffer mask this (PRO, EPI) kind may be launched with (stpde_layer_desc.packed, mapped by jet_layer.hip)
     // (bf16 mode packs the buffers of fc1's AND fc2's rows: fc1 forward writes one, fc2 forward reads one and writes one, ...)
-    constexpr int PKA = (PRO == PRO_L0 && EPI == EPI_FWD) ? 2 : (PRO == PRO_ACT ? 3 : (EPI == EPI_ADJ ? 7 : 1));
+    constexpr int PKA = (PRO == PRO_L0 && EPI == EPI_FWD) ? 2 : (PRO == PRO_ACT ? 3 : (EPI == EPI_ADJ ? 7 : 3));
     if (a.pk != 0 && a.pk != PKA) {
       stpde_set_error("packed layer buffers: combination %d not compiled for this kernel kind (expects %d)", a.pk, PKA);
       return STPDE_E_UNSUPPORTED;

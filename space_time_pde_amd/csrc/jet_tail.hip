@@ -476,8 +476,9 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// bf16 mode: the input-gradient chain on the bf16 pipe, every layer buffer packed (see k_tail_fwd_bf).  The adjoint blocks
-// of a layer, as they are stored (derivative streams bf16), are pairwise the B operand of the transposed product in front;
+// bf16 mode: the input-gradient chain on the bf16 pipe; pre[] are packed STASH buffers, out[] packed ADJOINT buffers (common.h:
+// every stream bf16 -- out[l] must not alias pre[l]).  The adjoint blocks of a layer, as they are stored, are pairwise the B
+// operand of the transposed product in front (one bf16 term: a rounding error of an adjoint is averaged over the rows);
 // the narrow product through fc5 (K = one 16-feature tile) stays on the fp32 MFMA.  All stash blocks of layers 3 / 4 are
 // requested at the head of the kernel, those of layer 2 one pair of tiles ahead of their use.
 template <int S1, int S2, int ACT>
@@ -516,13 +517,11 @@ __global__ __launch_bounds__(256, 2) void k_tail_bwd_bf(TailBwdArgs a) {
     for (int st = 0; st < S; ++st) pre[st] = blk_val(praw[st], true, st);
     act_jet_adj<S1, S2, ACT>(a.cfg, pre, hbar, ab, cq);
     if (swish) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, hbar, cq);
-    char* t = reinterpret_cast<char*>(a.out[l]) + (size_t)tile * packed_tile_bytes(S, MT);
-    st4(reinterpret_cast<float*>(t + (size_t)mt * 1024) + lo, ab[0]);
-    ob[0] = to_bf4(ab[0]);
+    char* t = reinterpret_cast<char*>(a.out[l]) + (size_t)tile * blk_tile_bytes(2, S, MT);     // packed ADJOINT buffer
 #pragma unroll
-    for (int st = 1; st < S; ++st) {
+    for (int st = 0; st < S; ++st) {
       ob[st] = to_bf4(ab[st]);
-      *reinterpret_cast<bf16x4*>(t + (size_t)MT * 1024 + ((size_t)(st - 1) * MT + mt) * 512 + lane * 8) = ob[st];
+      *reinterpret_cast<bf16x4*>(t + ((size_t)st * MT + mt) * 512 + lane * 8) = ob[st];
     }
   };
 

@@ -77,10 +77,11 @@ __device__ __forceinline__ f32x4 lds_get_R(const float* blk, int lane) {     // 
 // (hi + mid + lo) and the six partial products of weight >= 2^-16 are accumulated (see k_layer_coop); the abar blocks are
 // split once per tile when they are packed, the activated-input blocks when they leave the LDS ring (up to two VALU
 // instructions issue for free behind every bf16 MFMA).
-// PKM: compile-time packed-buffer mask (WgradArgs.pk: 1 = Q, 4 = P), see layer_epilogue
+// PKM: compile-time packed-buffer mask (WgradArgs.pk: 1 = Q is a packed STASH, 4 = P is a packed ADJOINT buffer; common.h)
 template <int S1, int S2, int MODE, int ACT, int KC, bool HASX, bool BF = false, int SPL = 1, int PKM = 0>
 __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");
+  constexpr int PMODE = (PKM & 4) ? 2 : 0;      // format of the adjoint operand's buffer (common.h)
   constexpr int S = 1 + S1 + S2, MCW = 2, NW = 8, RS = 8;
   constexpr int NM = KC;                    // m-slots per workgroup; k-slots = NW / NM, each KC ring slots wide
   // SPLP (split mode): the ring holds the three bf16 terms of every activated-input fragment, split ONCE by the producing
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         }
       } else {
 #pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKM & 1) != 0, tile, S, KT, st, kq, lane);
+        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKM & 1) ? 1 : 0, tile, S, KT, st, kq, lane);
       }
     } else if (kq < KT + XT) {
       pre[0] = ld4(a.XR + ((size_t)tile * XT + (kq - KT)) * 256 + lo);
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
-        raw[st][mi] = st < SP ? ld_blk_raw(a.P, (PKM & 4) != 0, tile, SP, MT, st, mt, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+        raw[st][mi] = st < SP ? ld_blk_raw(a.P, PMODE, tile, SP, MT, st, mt, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   };
   auto transpose_p = [&](f32x4 (*raw)[MCW], f32x4 (*pa)[MCW]) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         float* patch = pp[wv][(st * MCW + mi) & 1];
-        lds_put_T<TP>(patch, lane, raw[st][mi]);
+        lds_put_T<TP>(patch, lane, blk_val(raw[st][mi], st < SP ? PMODE : 0, st));
         __builtin_amdgcn_wave_barrier();
         pa[st][mi] = lds_get_R<TP>(patch, lane);
         __builtin_amdgcn_wave_barrier();
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) {
           bf16x4 t0[SPL], t1[SPL];
-          terms(blk_val(raw_[2 * sp][mi], (PKM & 4) != 0 && 2 * sp < SP, 2 * sp), t0);
-          if (2 * sp + 1 < S) terms(blk_val(raw_[2 * sp + 1][mi], (PKM & 4) != 0 && 2 * sp + 1 < SP, 2 * sp + 1), t1);
+          terms(blk_val(raw_[2 * sp][mi], 2 * sp < SP ? PMODE : 0, 2 * sp), t0);
+          if (2 * sp + 1 < S) terms(blk_val(raw_[2 * sp + 1][mi], 2 * sp + 1 < SP ? PMODE : 0, 2 * sp + 1), t1);
 #pragma unroll
           for (int k = 0; k < SPL; ++k) pa8[k][sp][mi] = cat8(t0[k], 2 * sp + 1 < S ? t1[k] : zero4);
         }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] += wgt * blk_val(raw_[1 + d][mi], (PKM & 4) != 0, 1 + d);
+        for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] += wgt * blk_val(raw_[1 + d][mi], PMODE, 1 + d);
     }
   };
   if (tile < a.ntiles) {
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 // a private 2.5 KB patch with wave-local barriers only, and 3-4 waves per SIMD overlap each other's latencies.  The
 // four waves of a block are summed through LDS before the atomics.
 // ------------------------------------------------------------------------------------------------------------
-// PKW (bf16 mode): 1 = Q (the layer input's pre-activations) is a PACKED layer buffer, 2 = P (the adjoint) as well; the
+// PKW (bf16 mode): 1 = Q (the layer input's pre-activations) is a packed STASH, 2 = P is a packed ADJOINT buffer; the
 // contraction over the rows then runs on v_mfma_f32_16x16x16_bf16 (BFM): the four fp32 k-steps of a transposed block pair
 // are one bf16 MFMA on the rounded blocks (same (lane group, element) -> row map on both operands, so the sum is the same).
 // The raw-input columns (exact skip operand) stay on the fp32 MFMA.
@@ -582,18 +583,18 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) {
           const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
-          raw[st][mi] = ld_blk_raw(a.P, (PKW & 2) != 0, tile, S, MT, st, mt, lane);
+          raw[st][mi] = ld_blk_raw(a.P, (PKW & 2) ? 2 : 0, tile, S, MT, st, mt, lane);
         }
 #pragma unroll
       for (int st = 0; st < S; ++st)
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(blk_val(raw[st][mi], (PKW & 2) != 0, st));
+        for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(blk_val(raw[st][mi], (PKW & 2) ? 2 : 0, st));
     }
 #pragma unroll
     for (int ki = 0; ki < KTT; ++ki) {
       f32x4 pre[S], H[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKW & 1) != 0, tile, S, KTT, st, ki, lane);
+      for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKW & 1) ? 1 : 0, tile, S, KTT, st, ki, lane);
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) {
@@ -716,6 +717,7 @@ static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
 template <int S1, int S2, int MODE, int ACT, int KC>
 static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   WgradArgs a = a0;
+  if (a.KT == 0 && a.pk == 4 && a.bf16 == 1) a.pk = 5;      // raw-input layer: no Q operand, the mask bit of Q is free
   a.gy = (a.MT + 2 * KC - 1) / (2 * KC);    // groups of 2*KC output tiles
   const int ngr = (a.KT + XT + 7) / 8;      // k-groups (ring = 8 k-tiles)
   const int nhid = a.KT / 8;                // groups made of hidden tiles only
@@ -762,6 +764,18 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
         else
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, true>), grid, dim3(512), 0, stream, a);
       }
+    } else if (a.pk) {
+      // bf16 mode: the value-stream weight gradient of the raw-input layer reads its adjoint as bf16 blocks (fp32 MFMA)
+      if constexpr (S1 == 0 && S2 == 0 && MODE == 0 && KC == 8) {
+        if (a.pk == 4 && part != 0) {
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, false, 1, 4>), grid, dim3(512), 0, stream, a);
+          int rc = stpde_check_launch("k_wgrad_coop");
+          if (rc) return rc;
+          continue;
+        }
+      }
+      stpde_set_error("packed layer buffers: combination %d not compiled for the fp32 weight-gradient kernels", a.pk);
+      return STPDE_E_UNSUPPORTED;
     } else if (part == 0) {
       STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false>), grid, dim3(512), 0, stream, a);
     } else {

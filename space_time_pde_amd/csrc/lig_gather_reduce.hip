@@ -413,8 +413,32 @@ __global__ __launch_bounds__(256) void k_xbar(XbarArgs a) {
     const int MT = a.d.MT[l], SP = a.d.SP[l];
     const float* ab = a.abar[l] + lo;  // stream 0 of tile t starts at (size_t)t * SP * MT * 256
     const float* w = a.wsl[l] + lo;
-    // floats between the value streams of consecutive tiles (packed buffers: value stream first, common.h)
-    const size_t tstride = a.d.packed[l] ? packed_tile_bytes(a.d.S[l], MT) / 4 : (size_t)SP * MT * 256;
+    if (a.d.packed[l]) {
+      // packed ADJOINT buffer (bf16 mode, common.h): bf16 blocks, stream 0 first -- two blocks are one K = 32 bf16 MFMA
+      // against the weight blocks of the same two output tiles, rounded here
+      const char* ab16 = reinterpret_cast<const char*>(a.abar[l]) + lane * 8;
+      const size_t tb = blk_tile_bytes(2, a.d.S[l], MT);
+      const bf16x4 z4 = to_bf4(f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int mt = 0; mt < MT; mt += 2) {
+        const bool two = mt + 1 < MT;
+        bf16x8 B8[XR];
+#pragma unroll
+        for (int t = 0; t < XR; ++t) {
+          const char* bp = ab16 + tl[t] * tb + (size_t)mt * 512;
+          B8[t] = cat8(*reinterpret_cast<const bf16x4*>(bp), two ? *reinterpret_cast<const bf16x4*>(bp + 512) : z4);
+        }
+#pragma unroll
+        for (int xl = 0; xl < XL; ++xl) {
+          const f32x4 w0 = ld4(w + ((size_t)mt * XL + xl) * 256);
+          const f32x4 w1 = two ? ld4(w + ((size_t)(mt + 1) * XL + xl) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const bf16x8 A8 = cat8(to_bf4(w0), to_bf4(w1));
+#pragma unroll
+          for (int t = 0; t < XR; ++t) acc[t][xl] = mfma_bf(A8, B8[t], acc[t][xl]);
+        }
+      }
+      continue;
+    }
+    const size_t tstride = (size_t)SP * MT * 256;     // floats between the value streams of consecutive tiles
     // two output tiles per iteration (MT is even for every hidden layer): their loads are issued together
     for (int mt = 0; mt + 1 < MT; mt += 2) {
       f32x4 B0[XR], B1[XR], w0[XL], w1[XL];

@@ -20,12 +20,12 @@ struct Seq {                       // first error wins, later launches are skipp
   }
 };
 
-bool is_packed(const stpde_imnet_plan* p, int l) { return l >= 1 && ((p->packed_mask >> l) & 1); }
+bool is_packed(const stpde_imnet_plan* p, int l) { return l >= 0 && ((p->packed_mask >> l) & 1); }
 
 // packed flags of a call on layer l (stpde_layer_desc.packed): 1 = its hidden input pre[l-1], 2 = the buffer it writes,
 // 4 = its abar_out; `writes` = index of the layer buffer the call writes (fwd: l, bwd: l - 1), -1 = none
 int packed_flags(const stpde_imnet_plan* p, int l, int writes) {
-  return (is_packed(p, l - 1) ? 1 : 0) | ((writes >= 1 && is_packed(p, writes)) ? 2 : 0) | (is_packed(p, l) ? 4 : 0);
+  return ((l >= 2 && is_packed(p, l - 1)) ? 1 : 0) | ((writes >= 0 && is_packed(p, writes)) ? 2 : 0) | (is_packed(p, l) ? 4 : 0);
 }
 
 stpde_layer_desc layer_desc(int ntiles, const stpde_imnet_plan* p, int l, const stpde_jet_cfg& cfg, int bf16) {
@@ -186,14 +186,22 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   float* z0 = ws->pre[0];
   // value-stream-only layer-0 adjoint: over the z0 stash (each lane reads before it writes), or -- dgrad-first -- into a
   // fresh buffer, because the weight gradient of the first hidden layer still needs z0 afterwards
-  float* abar0 = dfirst ? ws->abar0x : ((split0 || SP0 == 1) ? z0 : ws->abar0);
+  // bf16 mode with packed buffers: the adjoints are packed ADJOINT buffers (every stream bf16), a format of their own, so
+  // none of them goes over the stash it belongs to
+  const bool pkadj = p->packed_mask != 0;
+  if (pkadj && !(tail && ws->abar1x && ws->abar4x && (!is_packed(p, 0) || (split0 && ws->abar0x)))) {
+    stpde_set_error("lig_imnet_jet_bwd: packed layer buffers need the fused tail and workspace.abar1x / abar4x (and abar0x + the tangent row sums with packed_mask bit 0)");
+    return STPDE_E_BADARG;
+  }
+  float* abar0 = (dfirst || is_packed(p, 0)) ? ws->abar0x : ((split0 || SP0 == 1) ? z0 : ws->abar0);
   float* abar[8];
   for (int l = 1; l < NL; ++l) abar[l] = ws->pre[l];      // where the adjoint of layer l's output rows lives once it exists
   if (tail) {
     abar[3] = ws->abar3x;
     abar[2] = ws->abar2x;
   }
-  if (dfirst) abar[1] = ws->abar1x;
+  if (dfirst || pkadj) abar[1] = ws->abar1x;
+  if (pkadj) abar[4] = ws->abar4x;
 
   auto wgrad_l = [&](int l) {
     const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
@@ -206,8 +214,9 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     });
   };
   auto wgrad_0 = [&] {
-    stpde_layer_desc d = layer_desc(nt, p, 0, cfg, 0);
+    stpde_layer_desc d = layer_desc(nt, p, 0, cfg, is_packed(p, 0) ? 1 : 0);    // (bf16 mode: bf16 contraction over the rows)
     d.first_hidden = 0;
+    d.packed = packed_flags(p, 0, -1) & 4;
     float* dw0 = dW_flat + p->dw_off[0];
     if (split0) {
       d.cfg = *cfg_val;       // value stream x raw input (the S = 1 weight-gradient kernels)
@@ -220,7 +229,7 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   auto tail_bwd = [&] {
     const float* WhT[3] = {p->WhT[3], p->WhT[4], p->WhT[5]};
     const float* pre[3] = {ws->pre[2], ws->pre[3], ws->pre[4]};
-    float* outs[3] = {abar[2], abar[3], ws->pre[4]};
+    float* outs[3] = {abar[2], abar[3], abar[4]};
     seq([&] {
       const void* w16[3] = {p->WhT16[3], p->WhT16[4], nullptr};
       const bool pk = is_packed(p, 2);
@@ -258,7 +267,7 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
       xd.MT[l] = p->MT[l];
       xd.SP[l] = l == 0 ? (split0 ? 1 : SP0) : S;
       xd.packed[l] = is_packed(p, l) ? 1 : 0;
-      xd.S[l] = S;
+      xd.S[l] = l == 0 ? 1 : S;
       ab[l] = l == 0 ? abar0 : abar[l];
       wt[l] = p->WsL[l];
     }

@@ -346,10 +346,19 @@ def _buf_floats(meta, l, nt):
     return nt * meta.S * mt * _FRAG
 
 
+def _adj_floats(meta, l, nt):
+    """floats of the adjoint buffer of layer l's output rows: the size of the layer buffer, or -- packed mode -- a packed
+    ADJOINT buffer, every stream bf16 (layer 0: its value stream only)."""
+    mt = meta.plan.layers[l]["MT"]
+    if (meta.packed_mask >> l) & 1:
+        return nt * (meta.S if l else 1) * mt * 128
+    return nt * mt * _FRAG if l == 0 else _buf_floats(meta, l, nt)
+
+
 def _pk(meta, l, writes):
     """stpde_layer_desc.packed of a call on layer l that writes the buffer of layer `writes` (-1: none)."""
     m = meta.packed_mask
-    return (1 if (l >= 2 and (m >> (l - 1)) & 1) else 0) | (2 if (writes >= 1 and (m >> writes) & 1) else 0) | \
+    return (1 if (l >= 2 and (m >> (l - 1)) & 1) else 0) | (2 if (writes >= 0 and (m >> writes) & 1) else 0) | \
         (4 if (m >> l) & 1 else 0)
 
 
@@ -460,7 +469,11 @@ def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None,
 
     MT0 = plan.layers[0]["MT"]
     SP0 = 1 + meta.cfg.S1
-    ws.abar2x, ws.abar3x = buf(saved["bufs"][2].numel()), buf(saved["bufs"][3].numel())
+    ws.abar2x, ws.abar3x = buf(_adj_floats(meta, 2, nt)), buf(_adj_floats(meta, 3, nt))
+    if meta.packed_mask:        # packed ADJOINT buffers are a format of their own: none of them goes over a stash
+        ws.abar1x, ws.abar4x = buf(_adj_floats(meta, 1, nt)), buf(_adj_floats(meta, 4, nt))
+        if meta.packed_mask & 1:
+            ws.abar0x = buf(_adj_floats(meta, 0, nt))
     ws.tan0 = buf(nt * MT0 * 48) if (SP0 == 4 and tan0_rowsum) else None
     ws.abar0 = buf(nt * SP0 * MT0 * _FRAG) if (SP0 == 4 and not tan0_rowsum) else None
     if dlatent is not None and deterministic_dlatent:
@@ -481,7 +494,10 @@ def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None,
                                                  jets_bar.shape[2], ptr(dw_flat), ptr(dlatent), ptr(pbar), fl, stream_ptr()))
 
     if two_phase:
-        ws.abar1x, ws.abar0x = buf(saved["bufs"][1].numel()), buf(nt * MT0 * _FRAG)
+        if not meta.packed_mask:
+            ws.abar1x = buf(saved["bufs"][1].numel())
+        if not meta.packed_mask & 1:
+            ws.abar0x = buf(nt * MT0 * _FRAG)
         call(flags | _lib.F_PHASE_A)
         after_dlatent()
         call(flags | _lib.F_PHASE_B)
@@ -593,6 +609,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
     z0 = saved["z0"]
     # the value-stream-only layer-0 adjoint goes over the z0 stash (same shape; each lane reads before it writes)
     abar0 = z0 if (split0 or SP0 == 1) else torch.empty(nt * SP0 * MT0 * _FRAG, device=dev)
+    if meta.packed_mask & 1:       # bf16 mode: packed ADJOINT buffer (bf16 blocks) of its own
+        abar0 = torch.empty(_adj_floats(meta, 0, nt), device=dev)
     tan0 = torch.empty(nt * MT0 * 48, device=dev) if split0 else None
     # fc5 -> fc4 -> fc3 input gradients in one kernel (adjoints of layers 4 and 3 feed the next GEMM from the registers).
     # Order: wgrad_5 (needs the pre-activations of fc4's output intact), the chain (abar4 in place; abar3 / abar2 into
@@ -600,6 +618,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
     tail = (fused_tail and plan.nf in (16, 32) and (cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
             and (cfg.S2 != 1 or cw is not None))
     abar = {l: bufs[l] for l in range(1, 6)}      # where the adjoint of layer l's output rows lives once it exists
+    if meta.packed_mask:           # packed ADJOINT buffers are a format of their own: none of them goes over a stash
+        abar[1], abar[4] = (torch.empty(_adj_floats(meta, k, nt), device=dev) for k in (1, 4))
     for l in range(5, 0, -1):
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
@@ -616,7 +636,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
                                         ptr(XR), ptr(pv(packs, 0, "tanc")), ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
         if tail and l >= 3:
             if l == 5:
-                abar[3], abar[2] = torch.empty_like(bufs[3]), torch.empty_like(bufs[2])
+                abar[3], abar[2] = (torch.empty(_adj_floats(meta, k, nt), device=dev) for k in (3, 2))
                 arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
                 pk_tail = (meta.packed_mask >> 2) & 1
                 w16s = (C.c_void_p * 3)(meta.packs16[(3, "WhT")].data_ptr(), meta.packs16[(4, "WhT")].data_ptr(), None) \
@@ -627,6 +647,11 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
                                                  arr([bufs[2], bufs[3], bufs[4]]), arr([abar[2], abar[3], abar[4]]),
                                                  ptr(cw), ptr(pbar), 3 if pk_tail else 0, w16s, st))
             continue
+        if l > 1 and abar[l - 1] is not bufs[l - 1]:       # into a fresh buffer: the stash stays intact
+            with _timed("layer%d_dgrad" % l):
+                check(L.stpde_jet_layer_bwd_to(C.byref(d), ptr(abar[l]), ptr(pv(packs, l, "WhT")), ptr(bufs[l - 1]),
+                                               ptr(abar[l - 1]), ptr(cw), ptr(pbar), ptr(w16), st))
+            continue
         with _timed("layer%d_dgrad" % l):
             check(L.stpde_jet_layer_bwd(C.byref(d), ptr(abar[l]), ptr(pv(packs, l, "WhT")),
                                         ptr(bufs[l - 1]) if l > 1 else None, ptr(X), ptr(pv(packs, 0, "Ws")),
@@ -634,7 +659,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
                                         ptr(tan0) if l == 1 else None, ptr(z0) if l == 1 else None, st))
     if meta.need_wgrad:
         lay = plan.layers[0]
-        d = _layer_desc(nt, lay, cfg, False)
+        # (bf16 mode: the adjoint is a packed ADJOINT buffer and the contraction over the rows runs on the bf16 MFMA)
+        d = _layer_desc(nt, lay, cfg, False, meta.packed_mask & 1, _pk(meta, 0, -1) & 4)
         off, mp, ka = plan.dw_off[0]
         with _timed("layer0_wgrad"):
             if split0:
@@ -654,7 +680,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
         for l in range(5):
             xd.MT[l] = plan.layers[l]["MT"]
             xd.SP[l] = (1 if split0 else SP0) if l == 0 else S
-            xd.packed[l], xd.S[l] = (meta.packed_mask >> l) & 1 if l else 0, S
+            xd.packed[l], xd.S[l] = (meta.packed_mask >> l) & 1, (S if l else 1)
             ab[l] = (abar0 if l == 0 else abar[l]).data_ptr()
             wt[l] = pv(packs, l, "WsL").data_ptr()
         if not deterministic_dlatent:
@@ -931,7 +957,9 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     if precision == "bf16" and packed_stash and imnet.nf == 32 and meta.S <= 6:
         tail_ok = fused_tail and meta.cfg.S1 == 3 and (meta.cfg.S2 != 1 or bool(meta.cfg_out.combo))
         # the buffers of fc1 ... fc4's rows (the bf16 kernels are compiled for "every boundary packed" or none)
-        meta.packed_mask = 30 if tail_ok else 0
+        # bits 1-4: the layer buffers of fc1 ... fc4's rows; bit 0: the value-stream adjoint of layer 0 as bf16 blocks (needs
+        # the tangent row sums: value-only adjoint).  The library serves "all of them" or none.
+        meta.packed_mask = 31 if (tail_ok and tan0_rowsum) else 0
     meta.B, meta.N = B, N
     meta.grid_shape = tuple(latent_grid.shape[1:4])
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)
