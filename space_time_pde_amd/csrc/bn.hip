@@ -26,6 +26,7 @@ struct BnArgs {
   float* dr;             // gradient of the residual input or null
   float* dgamma;
   float* dbeta;
+  int il;                // backward kernels: rows dealt to the blocks in interleaved 16 KiB chunks instead of one range per block
 };
 
 // thread -> (channel quad q = 4 consecutive channels, row offset): C / 4 quads, 256 / (C / 4) rows in flight per block; every
@@ -182,9 +183,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(BnArgs a) {
     s1 += dz;
     s2 += dz * (x - mean) * rstd;
   };
-  long row = lo + m.row0;
   const long st = m.rstep;
-  for (; row + 3 * st < hi; row += 4 * st) {          // 8-12 independent 16-byte loads in flight per thread
+  auto four = [&](long row) {                         // 8-12 independent 16-byte loads in flight per thread
     f32x4 dz[4], y[4], x[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -195,11 +195,25 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(BnArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) term(dz[u], y[u], x[u]);
-  }
-  for (; row < hi; row += st) {
+  };
+  auto one_row = [&](long row) {
     const long i = row * C + c;
     const f32x4 dz = ld4(a.dy + i);
     term(dz, relu ? ld4(a.y + i) : dz, ld4(a.x + i));
+  };
+  if (a.il) {
+    // chunk k = rows [4 st k, 4 st (k + 1)): consecutive blocks read consecutive 16 KiB of every array
+    for (long base = (long)blockIdx.x * 4 * st; base < N; base += (long)gridDim.x * 4 * st) {
+      if (base + 4 * st <= N) {
+        four(base + m.row0);
+      } else {
+        for (long row = base + m.row0; row < N; row += st) one_row(row);
+      }
+    }
+  } else {
+    long row = lo + m.row0;
+    for (; row + 3 * st < hi; row += 4 * st) four(row);
+    for (; row < hi; row += st) one_row(row);
   }
   s1 = bn_block_sum(s1, sh, m);
   s2 = bn_block_sum(s2, sh, m);
@@ -231,17 +245,46 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnArgs a) {
   const f32x4 one = f32x4{1.f, 1.f, 1.f, 1.f}, zero = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 g = a.gamma ? ld4(a.gamma + c) : one;
   const f32x4 k1 = a.d.training ? sdz / (float)N : zero, k2 = a.d.training ? sdzx / (float)N : zero;
-  for (long row = lo + m.row0; row < hi; row += m.rstep) {
-    const long i = row * C + c;
-    f32x4 dz = ld4(a.dy + i);
-    if (a.d.relu) {
-      const f32x4 y = ld4(a.y + i);
+  const long st = m.rstep;
+  const bool relu = a.d.relu != 0;
+  auto finish = [&](long i, f32x4 dz, f32x4 y, f32x4 x) {
+    if (relu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (!(y[k] > 0.f)) dz[k] = 0.f;
     }
     if (a.dr) st4(a.dr + i, dz);
-    if (a.dx) st4(a.dx + i, g * rstd * (dz - k1 - (ld4(a.x + i) - mean) * rstd * k2));
+    if (a.dx) st4(a.dx + i, g * rstd * (dz - k1 - (x - mean) * rstd * k2));
+  };
+  auto four = [&](long row) {
+    f32x4 dz[4], y[4], x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = (row + u * st) * C + c;
+      dz[u] = ld4(a.dy + i);
+      y[u] = relu ? ld4(a.y + i) : dz[u];
+      x[u] = a.dx ? ld4(a.x + i) : dz[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) finish((row + u * st) * C + c, dz[u], y[u], x[u]);
+  };
+  auto one_row = [&](long row) {
+    const long i = row * C + c;
+    const f32x4 dz = ld4(a.dy + i);
+    finish(i, dz, relu ? ld4(a.y + i) : dz, a.dx ? ld4(a.x + i) : dz);
+  };
+  if (a.il) {
+    for (long base = (long)blockIdx.x * 4 * st; base < N; base += (long)gridDim.x * 4 * st) {
+      if (base + 4 * st <= N) {
+        four(base + m.row0);
+      } else {
+        for (long row = base + m.row0; row < N; row += st) one_row(row);
+      }
+    }
+  } else {
+    long row = lo + m.row0;
+    for (; row + 3 * st < hi; row += 4 * st) four(row);
+    for (; row < hi; row += st) one_row(row);
   }
 }
 
@@ -315,9 +358,12 @@ extern "C" int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float*
   a.dr = dresidual;
   a.dgamma = dgamma;
   a.dbeta = dbeta;
+  static const int il_env = getenv("STPDE_BN_IL") ? atoi(getenv("STPDE_BN_IL")) : 1;      // (-5 ... -8 % on the 4.2 M-voxel levels)
+  static const int rg_env = getenv("STPDE_BN_RGRID") ? atoi(getenv("STPDE_BN_RGRID")) : 1024;
+  a.il = il_env;
   const unsigned grid = bn_grid(d);
   if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, (size_t)STPDE_BN_REP * 2 * d->C * sizeof(float), (hipStream_t)stream);
-  STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, (hipStream_t)stream, a);
+  STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid > (unsigned)rg_env ? (unsigned)rg_env : grid), dim3(256), 0, (hipStream_t)stream, a);
   rc = stpde_check_launch("k_bn_bwd_reduce");
   if (rc) return rc;
   STPDE_LAUNCH(k_bn_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -267,6 +267,110 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
       }
 }
 
+// Weight gradient of the 3x3x3 convolutions of the full-resolution U-Net levels (16 / 32 channels, millions of voxels) from
+// LDS tiles (round 3).  The per-wave kernel above loads every MFMA operand element with its own dword load and re-reads the
+// activations once per tap group from L1 / L2: 32-48 TFLOP/s.  Here a workgroup of 8 waves owns a 2 x 4 x 32 block of output
+// voxels at a time (persistent, grid-stride): the activations of the block WITH its one-voxel halo (4 x 6 x 34 voxels,
+// zero outside the volume) and the output gradients of the block go to LDS once, as coalesced 16-byte loads, and all 27 taps
+// read their operand fragments from there -- one ds_read_b32 per lane and k-step (lane 16k+i: voxel 4s+k of the 16-voxel
+// tile, channel i), the tap being a constant offset into the halo tile.  The 27 taps are dealt to the 8 waves (4 4 4 3 3 3 3 3:
+// the two waves of a SIMD carry 7 7 7 6 taps), every wave keeps the accumulators of its taps for the whole launch and adds them
+// with one set of fp32 atomics at the end.  32-channel tiles: the two 16-channel halves of a voxel are swapped on odd voxels,
+// so that the two voxels a half-wave reads in one ds_read_b32 land in different banks.
+template <int CIT, int COT>
+__global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
+  constexpr int TT = 2, TZ = 4, TX = 32, HT = TT + 2, HZ = TZ + 2, HX = TX + 2;
+  constexpr int Ci = 16 * CIT, Co = 16 * COT, NH = HT * HZ * HX, NV = TT * TZ * TX;
+  __shared__ __attribute__((aligned(16))) float xs[NH * Ci];
+  __shared__ __attribute__((aligned(16))) float ys[NV * Co];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int ntap_w = wv < 3 ? 4 : 3;
+  const int tap0 = wv < 3 ? 4 * wv : 12 + 3 * (wv - 3);
+  f32x4 acc[4][COT][CIT];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int co = 0; co < COT; ++co)
+#pragma unroll
+      for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int T = a.d.T, Z = a.d.Z, X = a.d.X;
+  const int nbx = X / TX, nbz = Z / TZ, nbt = T / TT;
+  const int nblk = a.d.B * nbt * nbz * nbx;
+#pragma unroll 1
+  for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+    int r = bi;
+    const int x0 = (r % nbx) * TX;
+    r /= nbx;
+    const int z0 = (r % nbz) * TZ;
+    r /= nbz;
+    const int t0 = (r % nbt) * TT;
+    const int b = r / nbt;
+    __syncthreads();                                   // the readers of the previous block are done
+    for (int idx = threadIdx.x; idx < NH * (Ci / 4); idx += 512) {
+      const int q = idx % (Ci / 4), hv = idx / (Ci / 4);
+      const int hx = hv % HX, hz = (hv / HX) % HZ, ht = hv / (HX * HZ);
+      const int t = t0 + ht - 1, z = z0 + hz - 1, x = x0 + hx - 1;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t >= 0 && t < T && z >= 0 && z < Z && x >= 0 && x < X)
+        v = ld4(a.x + ((((size_t)b * T + t) * Z + z) * X + x) * Ci + 4 * q);
+      const int qs = CIT == 2 ? (q ^ ((hv & 1) << 2)) : q;
+      st4(xs + hv * Ci + 4 * qs, v);
+    }
+    for (int idx = threadIdx.x; idx < NV * (Co / 4); idx += 512) {
+      const int q = idx % (Co / 4), vv = idx / (Co / 4);
+      const int xx = vv % TX, zz = (vv / TX) % TZ, tt = vv / (TX * TZ);
+      const f32x4 v = ld4(a.ybar + ((((size_t)b * T + t0 + tt) * Z + z0 + zz) * X + x0 + xx) * Co + 4 * q);
+      const int qs = COT == 2 ? (q ^ ((vv & 1) << 2)) : q;
+      st4(ys + vv * Co + 4 * qs, v);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int vt = 0; vt < NV / 16; ++vt) {             // 16-voxel tiles along x: (tt, zz, half of the 32-voxel row)
+      const int xh = vt & 1, zz = (vt >> 1) & 3, tt = vt >> 3;
+      const int vv = (tt * TZ + zz) * TX + 16 * xh + g;           // this lane's voxel of k-step 0 (k-step s: + 4 s)
+      float pa[COT][4];
+#pragma unroll
+      for (int co = 0; co < COT; ++co)
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk)
+          pa[co][sk] = ys[(vv + 4 * sk) * Co + 16 * (COT == 2 ? (co ^ (vv & 1)) : co) + j];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        if (ti < ntap_w) {                             // wave-uniform
+          const int tap = tap0 + ti;
+          const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+          const int hv = ((tt + 1 + dt) * HZ + (zz + 1 + dz)) * HX + 16 * xh + 1 + dx + g;
+          float qb[CIT][4];
+#pragma unroll
+          for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk)
+              qb[ci][sk] = xs[(hv + 4 * sk) * Ci + 16 * (CIT == 2 ? (ci ^ (hv & 1)) : ci) + j];
+#pragma unroll
+          for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+            for (int co = 0; co < COT; ++co)
+#pragma unroll
+              for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = mfma4(pa[co][sk], qb[ci][sk], acc[ti][co][ci]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    if (ti >= ntap_w) continue;
+#pragma unroll
+    for (int co = 0; co < COT; ++co)
+#pragma unroll
+      for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          atomicAdd(a.dW + ((size_t)(tap0 + ti) * Co + 16 * co + 4 * g + rr) * Ci + 16 * ci + j, acc[ti][co][ci][rr]);
+  }
+}
+
 static int check_conv(const stpde_conv3d_desc* d) {
   if (!d || d->B < 1 || d->T < 1 || d->Z < 1 || d->X < 1 || d->Ci < 16 || d->Co < 16 || (d->Ci & 15) || (d->Co & 15) ||
       (d->ksize != 1 && d->ksize != 3)) {
@@ -355,6 +459,23 @@ extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, co
     if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
     return gx < 1 ? 1 : gx;
   };
+  // full-resolution levels (16 / 32 channels, volume made of whole 2 x 4 x 32 blocks, enough of them): the LDS-tile kernel
+  static const int lds_env = getenv("STPDE_CONV_WGRAD_LDS") ? atoi(getenv("STPDE_CONV_WGRAD_LDS")) : 1;
+  const int nblk = d->B * (d->T / 2) * (d->Z / 4) * (d->X / 32);
+  if (lds_env && d->ksize == 3 && KT <= 2 && MT <= 2 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 32 == 0 && nblk >= 256) {
+    const int wide = (KT == 2 || MT == 2);
+    int gx = wide ? 256 : 512;               // persistent workgroups: one (137 KB of LDS) or two (68 KB) per CU
+    if (gx > nblk) gx = nblk;
+    if (KT == 1 && MT == 1)
+      STPDE_LAUNCH((k_conv3d_wgrad_lds<1, 1>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
+    else if (KT == 2 && MT == 2)
+      STPDE_LAUNCH((k_conv3d_wgrad_lds<2, 2>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
+    else if (KT == 1)
+      STPDE_LAUNCH((k_conv3d_wgrad_lds<1, 2>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
+    else
+      STPDE_LAUNCH((k_conv3d_wgrad_lds<2, 1>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
+    return stpde_check_launch("k_conv3d_wgrad_lds");
+  }
   if (d->ksize == 3 && KT == 1 && MT == 1) {
     STPDE_LAUNCH((k_conv3d_wgrad<1, 1, 9>), dim3(stripes(3), 3), dim3(256), 0, (hipStream_t)stream, a);
   } else if (d->ksize == 3) {

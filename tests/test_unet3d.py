@@ -170,7 +170,8 @@ def test_conv3d_at_bench_volume_vs_torch_fp64(hiplib, ci, co, k):
         torch.cuda.synchronize()
     mt = co // 16
     assert tr.has("k_conv3d_fwd<%d, 4>" % min(mt, 4)), "\n".join(tr.kernels)     # forward: 4 voxel tiles per wave
-    assert tr.has("k_conv3d_wgrad"), "\n".join(tr.kernels)
+    # weight gradient: the LDS-tile kernel for the 3x3x3 convolutions of these levels, the per-wave kernel otherwise
+    assert tr.has("k_conv3d_wgrad_lds" if (k == 3 and ci >= 16) else "k_conv3d_wgrad<"), "\n".join(tr.kernels)
     c64 = torch.nn.Conv3d(ci, co, k, padding=(k - 1) // 2).double()
     c64.load_state_dict({kk: v.double().cpu() for kk, v in cd.state_dict().items()})
     x64 = x.double().requires_grad_(True)
@@ -185,6 +186,34 @@ def test_conv3d_at_bench_volume_vs_torch_fp64(hiplib, ci, co, k):
     # 524,288-term fp32 sums (block partial sums + atomics): error grows with sqrt(n) relative to the terms' size
     assert rel(cd.weight.grad, c64.weight.grad) < 2e-4
     assert rel(cd.bias.grad, c64.bias.grad) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci,co", [(16, 32), (32, 16), (32, 32), (16, 16)])
+def test_conv3d_wgrad_lds_tiles_two_samples_vs_torch_fp64(hiplib, ci, co):
+    """The LDS-tile weight-gradient kernel (csrc/conv3d.hip, k_conv3d_wgrad_lds) on a batch of TWO samples (the halo of a
+    block must stop at the sample boundary) and on every channel-tile combination it is compiled for."""
+    from space_time_pde_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 + ci + 2 * co)
+    shape = (2, 16, 32, 128)
+    conv = torch.nn.Conv3d(ci, co, 3, padding=1)
+    x = torch.randn(*shape, ci, generator=g)
+    cot = torch.randn(*shape, co, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    cd = conv.to(dev)
+    with _lib.dispatch_trace() as tr:
+        y = unet3d._conv_cl(xd, cd)
+        (y * cot.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+    assert tr.has("k_conv3d_wgrad_lds<%d, %d>" % (ci // 16, co // 16)), "\n".join(tr.kernels)
+    c64 = torch.nn.Conv3d(ci, co, 3, padding=1).double()
+    c64.load_state_dict({kk: v.double().cpu() for kk, v in cd.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    y64 = c64(x64.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+    (y64 * cot.double()).sum().backward()
+    err = (cd.weight.grad.double().cpu() - c64.weight.grad).abs().max().item() / c64.weight.grad.abs().max().item()
+    assert err < 1e-4, err
 
 
 @pytest.mark.gpu
