@@ -355,6 +355,11 @@ int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_
                      void* stream);
 /* dW[tap][Co][Ci] += sum_voxels ybar[v][co] * x[v + offset(tap)][ci]  (fp32 atomics; caller zero-fills dW). */
 int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, void* stream);
+/* The same + the bias gradient: dbias[Co] += sum over the voxels of ybar (fp32 atomics; caller zero-fills), taken from the
+ * ybar fragments the kernel loads anyway -- replaces a separate reduction pass over ybar (the reference computes it inside
+ * its convolution backward, torch.nn.Conv3d). */
+int stpde_conv3d_wgrad_bias(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias,
+                            void* stream);
 
 /* ---- a10: BatchNorm3d (+ residual add) (+ ReLU) of the ResBlock3D chain (src/unet3d.py:39-56) -------------
  * Channels-last x [N][C], N = B*T*Z*X, C a power of two in [16, 512].

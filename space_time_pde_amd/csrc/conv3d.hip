@@ -17,6 +17,7 @@ struct ConvArgs {
   float* y;
   const float* ybar;
   float* dW;
+  float* dbias;      // weight-gradient kernels: sum over the voxels of ybar, added with atomics (nullable)
   int nvox, gx;
 };
 
@@ -195,6 +196,12 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
   int toff[TG];
 #pragma unroll
   for (int tg = 0; tg < TG; ++tg) tap_uniform(a.d, tap0 + tg, tmask[tg], toff[tg]);
+  // bias gradient = column sums of ybar: taken from the ybar fragments by the blocks of tap group 0 / ci block 0 (every
+  // element of ybar passes through exactly one of them) -- saves the separate reduction pass over ybar
+  const bool dob = a.dbias && kb == 0 && tap0 == 0;
+  float bs[MCW];
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi) bs[mi] = 0.f;
   auto load = [&](int tile, Frag& f) {
     // coordinates of this lane's voxel of k-step 0 by division, of the following k-steps (+4 voxels each) by carry
     const int v0 = tile * 16 + kk;
@@ -248,6 +255,20 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
         for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
           for (int ki = 0; ki < KCW; ++ki) acc[tg][mi][ki] = mfma4(cur.pa[s][mi], cur.qb[s][tg][ki], acc[tg][mi][ki]);
+    if (dob) {
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) bs[mi] += (cur.pa[0][mi] + cur.pa[1][mi]) + (cur.pa[2][mi] + cur.pa[3][mi]);
+    }
+  }
+  if (dob) {
+#pragma unroll
+    for (int mi = 0; mi < MCW; ++mi) {
+      float v = bs[mi];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int mt = mb * MCW + mi;
+      if (kk == 0 && mt < MT) atomicAdd(a.dbias + 16 * mt + i, v);
+    }
   }
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -298,6 +319,9 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
   const int T = a.d.T, Z = a.d.Z, X = a.d.X;
   const int nbx = X / TX, nbz = Z / TZ, nbt = T / TT;
   const int nblk = a.d.B * nbt * nbz * nbx;
+  // bias gradient (column sums of ybar) from the staged block: thread -> (channel, every (512 / Co)-th voxel)
+  const int bc = threadIdx.x % Co, bv0 = threadIdx.x / Co;
+  float bsum = 0.f;
 #pragma unroll 1
   for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
     int r = bi;
@@ -326,6 +350,9 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       st4(ys + vv * Co + 4 * qs, v);
     }
     __syncthreads();
+    if (a.dbias) {
+      for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (COT == 2 ? (bc ^ ((vv & 1) << 4)) : bc)];
+    }
 #pragma unroll 1
     for (int vt = 0; vt < NV / 16; ++vt) {             // 16-voxel tiles along x: (tt, zz, half of the 32-voxel row)
       const int xh = vt & 1, zz = (vt >> 1) & 3, tt = vt >> 3;
@@ -358,6 +385,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       }
     }
   }
+  if (a.dbias) atomicAdd(a.dbias + bc, bsum);
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
     if (ti >= ntap_w) continue;
@@ -435,8 +463,18 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
   return stpde_check_launch("k_conv3d_fwd");
 }
 
+static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias, void* stream);
+
 extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW,
                                   void* stream) {
+  return conv3d_wgrad(d, x, ybar, dW, nullptr, stream);
+}
+extern "C" int stpde_conv3d_wgrad_bias(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias,
+                                       void* stream) {
+  return conv3d_wgrad(d, x, ybar, dW, dbias, stream);
+}
+
+static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias, void* stream) {
   int rc = check_conv(d);
   if (rc) return rc;
   if (!x || !ybar || !dW) {
@@ -448,6 +486,7 @@ extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, co
   a.x = x;
   a.ybar = ybar;
   a.dW = dW;
+  a.dbias = dbias;
   a.nvox = d->B * d->T * d->Z * d->X;
   const int ntiles = (a.nvox + 15) / 16;
   const int KT = d->Ci / 16, MT = d->Co / 16;

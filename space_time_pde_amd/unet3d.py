@@ -203,12 +203,15 @@ class _Conv3dHip(torch.autograd.Function):
             defer.keep.append((gy, xin))
             defer.side.wait_event(ready)          # not the input-gradient kernel just queued: the two run side by side
             with torch.cuda.stream(defer.side):
+                want_b = has_bias and ctx.needs_input_grad[2]
                 if ctx.needs_input_grad[1]:
+                    # (the bias gradient = column sums of gy comes out of the same kernel: dball is zero-filled per step)
                     dwt, ctx.dwbuf = ctx.dwbuf, None
                     d = _desc(xin, cip, co, k)
-                    _lib.check(L.stpde_conv3d_wgrad(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt),
-                                                    _lib.stream_ptr()))
-                if has_bias and ctx.needs_input_grad[2]:
+                    _lib.check(L.stpde_conv3d_wgrad_bias(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt),
+                                                         _lib.ptr(defer.bias_slice(idx)) if want_b else None,
+                                                         _lib.stream_ptr()))
+                elif want_b:
                     torch.sum(gy.reshape(-1, co), 0, out=defer.bias_slice(idx))
             defer.enqueue(idx)
             return dx, None, None, None
@@ -218,9 +221,12 @@ class _Conv3dHip(torch.autograd.Function):
             if dwt is None:
                 dwt = torch.zeros(ntap, co, cip, device=gy.device, dtype=torch.float32)
             d = _desc(xin, cip, co, k)
-            _lib.check(L.stpde_conv3d_wgrad(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt), _lib.stream_ptr()))
+            if has_bias and ctx.needs_input_grad[2]:
+                db = torch.zeros(co, device=gy.device, dtype=torch.float32)     # column sums of gy, from the same kernel
+            _lib.check(L.stpde_conv3d_wgrad_bias(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt), _lib.ptr(db),
+                                                 _lib.stream_ptr()))
             dw = dwt[:, :, :ci].permute(1, 2, 0).reshape(co, ci, k, k, k)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and db is None:
             db = gy.reshape(-1, co).sum(0)
         return dx, dw, db, None
 
