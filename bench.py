@@ -55,12 +55,23 @@ def algorithmic_macs(nf=32, cin=32, cout=4, n_first=3, n_second=2):
     return macs, M, T
 
 
-def algorithmic_bytes(S, smooth_sp0=4, nf=32, cin=32, cout=4):
-    """Per CORNER ROW HBM bytes each layer kernel has to move (fp32 stash of S streams; X = augmented raw input):
-    used as the roofline numerator when the kernels are HBM-bound (bf16-MFMA mode)."""
+def algorithmic_bytes(S, smooth_sp0=4, nf=32, cin=32, cout=4, packed=False):
+    """Per CORNER ROW HBM bytes each layer kernel has to move (X = augmented raw input): the roofline numerator of a kernel
+    that is HBM-bound.  fp32 stash of S streams, or -- packed=True, the bf16 mode's layer buffers -- a
+    packed STASH per feature 4 + 2 (S - 1) bytes (value stream fp32, derivative streams bf16) and a packed ADJOINT 2 S bytes;
+    the layer-0 adjoint is its value stream only (bf16), the z0 stash fp32."""
     widths = [16 * nf, 8 * nf, 4 * nf, 2 * nf, nf, 16]     # fc5 output padded to one 16-feature tile
     xb = 3 * 16 * 4
     by = {}
+    if packed:
+        stash = lambda l: (4 + 2 * (S - 1)) * widths[l] if l < 5 else 4 * S * widths[l]
+        adj = lambda l: 2 * S * widths[l] if l < 5 else 4 * S * widths[l]
+        for l in range(1, 6):
+            by["layer%d_fwd" % l] = (stash(l - 1) if l > 1 else 0) + xb + stash(l) + (4 * widths[0] if l == 1 else 0)
+            by["layer%d_dgrad" % l] = adj(l) + ((stash(l - 1) + adj(l - 1)) if l > 1 else xb + (4 + 2) * widths[0])
+            by["layer%d_wgrad" % l] = adj(l) + (stash(l - 1) if l > 1 else 0) + 2 * xb
+        by["layer0_wgrad"] = 2 * widths[0] + xb
+        return by
     for l in range(1, 6):
         out_b, in_b = 4 * S * widths[l], (4 * S * widths[l - 1] if l > 1 else 0)
         by["layer%d_fwd" % l] = in_b + xb + out_b
@@ -158,6 +169,10 @@ def main(argv=None):
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
     args = ap.parse_args(argv)
+    if args.mlp_precision == "bf16" and args.traffic_json == ap.get_default("traffic_json"):
+        # the bf16-operand kernels have their own counter passes (taken on configs[3]; the IM-NET launches are the same on
+        # either latent grid: 2^20 points, same kernels)
+        args.traffic_json = os.path.join(ROOT, "profiles", "pmc_traffic_c4_bf16.json")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_spawn(args.gpus, list(sys.argv[1:] if argv is None else argv))
 
@@ -346,7 +361,7 @@ def main(argv=None):
                 # so the bytes of a launch scale with its number of tiles
                 scale = min(args.chunk, n_local) / float(tj["chunk"])
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"] * scale
-                traffic_src = tj.get("source") + ("" if scale == 1 else "; measured on a %d-point launch, scaled x%g to "
+                traffic_src = tj.get("source").replace("r3_pmc_", "r3_c4_pmc_" if args.mlp_precision == "bf16" else "r3_pmc_") + ("" if scale == 1 else "; measured on a %d-point launch, scaled x%g to "
                                                   "this launch's tile count" % (tj["chunk"], scale))
         except (OSError, ValueError, KeyError):
             pass
@@ -382,19 +397,34 @@ def main(argv=None):
             roofline["side_figures"] = side
         bf16 = args.mlp_precision == "bf16"
         if bf16:
-            # bf16 operands make the layer kernels HBM-bound on the fp32 stash: price them against HBM instead
-            by = algorithmic_bytes(1 + 3 + (1 if smooth else 0)).get(dom)
+            # bf16 operands: the layer kernels are priced against BOTH roofs -- HBM on the bytes of the packed layer buffers
+            # (what the kernel has to move) and the dense bf16 MFMA peak on the executed products -- and the line carries the
+            # one the dominant kernel sits closer to; the other is kept as a secondary figure
+            from space_time_pde_amd import lig_jet as _lj
+            pk = bool(getattr(_lj, "packed_stash", False))
+            by = algorithmic_bytes(1 + 3 + (1 if smooth else 0), packed=pk).get(dom)
             if by:
                 gbs = by * rows_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e9
-                roofline.update(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
-                                note="bf16-MFMA mode: achieved = algorithmic stash bytes of the dominant kernel / launch "
-                                     "time; traffic = its measured HBM bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same "
-                                     "configuration) when committed; MFMA-side figures (executed_tflops vs the 2500 TFLOP/s "
-                                     "bf16 peak) for reference",
-                                executed_frac=round(exe / 2500.0, 4), bytes_per_launch=by * rows_per_launch)
+                hbm = dict(achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
+                           bytes_per_launch=by * rows_per_launch,
+                           bytes_note="algorithmic bytes of the dominant kernel in the %s layer-buffer format"
+                                      % ("packed (value fp32 / derivative streams bf16; adjoints bf16)" if pk else "fp32"))
                 if traffic:
-                    roofline["measured_GBps"] = round(traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e9, 1)
-                    roofline["measured_frac"] = round(traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / 8000.0, 4)
+                    hbm["measured_GBps"] = round(traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e9, 1)
+                    hbm["measured_frac"] = round(traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / 8000.0, 4)
+                mfma = dict(achieved=round(exe, 2), peak=2500.0, unit="TFLOP/s", frac=round(exe / 2500.0, 4))
+                if mfma["frac"] >= hbm["frac"]:
+                    roofline.update(bound="mfma", hbm_side=hbm, **mfma)
+                else:
+                    roofline.update(bound="hbm", mfma_side=mfma, **{k: hbm[k] for k in ("achieved", "peak", "unit", "frac")})
+                    roofline["hbm_side"] = hbm
+                roofline.update(note="bf16-MFMA mode: the dominant kernel against the dense bf16 MFMA peak (executed products: "
+                                     "combined second-order stream) and against HBM (algorithmic bytes of its packed layer "
+                                     "buffers / launch time; measured_* = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same "
+                                     "configuration when committed); `bound` names the roof it is closer to -- it reaches "
+                                     "neither: the first-layer kernels of this mode are bound by VALU work (activation jets) "
+                                     "and latency, DESIGN 5a",
+                                executed_frac=round(exe / 2500.0, 4))
                 roofline.pop("step_frac_per_gpu", None)
         if args.mlp_precision == "fp32x3":
             # exact-split mode: the wide layers issue SIX bf16 MFMA products per fp32 product, so the pipe that bounds them is

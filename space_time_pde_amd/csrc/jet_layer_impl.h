@@ -398,8 +398,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
       for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
     // first hidden layer's input gradient: the z0 blocks its epilogue takes the adjoint against, fetched now
-    f32x4 z0p[EPI == EPI_ADJ_L0 ? MCg : 1];
-    if constexpr (EPI == EPI_ADJ_L0) {
+    constexpr bool Z0P = EPI == EPI_ADJ_L0 && SPL == 1;      // (not in the three-term split mode: register pressure)
+    f32x4 z0p[Z0P ? MCg : 1];
+    if constexpr (Z0P) {
 #pragma unroll
       for (int mi = 0; mi < MCg; ++mi) z0p[mi] = ld4(a.Z0 + ((size_t)tile * MT + mt0 + mi) * 256 + lo);
     }
@@ -420,7 +421,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
     for (int gi = 0; gi < ngroups; ++gi) {
       const int buf = gi & 1;
       const int gnext = gi + 1 < ngroups ? gi + 1 : gi;
-      constexpr bool EARLY = PRO == PRO_NONE;     // B blocks are plain loads from the stash: issue them now
+      // B blocks are plain loads from the stash: issue them now (not in the three-term split mode: the registers the
+      // early blocks occupy cost that mode more than the hidden latency gives, fp32x3 dgrad 64.5 -> 71.3 ms)
+      constexpr bool EARLY = PRO == PRO_NONE && SPL == 1;
       constexpr bool EARLY0 = PRO == PRO_L0 && !VT && STPDE_EARLY_L0;   // layer 0 on the fly: its weight / tangent fragments
       f32x4 rawn[EARLY ? PK : 1][S];
       if constexpr (EARLY) {
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
       }
       // branch-free (the last group re-produces one of its own blocks): one basic block per group, so the
       // produce stage's loads / regeneration / activation VALU interleave with the MFMAs above
-      if constexpr (PRO == PRO_NONE) {
+      if constexpr (EARLY) {
 #pragma unroll
         for (int k = 0; k < PK; ++k) store_block(rawn[k], buf ^ 1, NW * k + wv);
       } else if constexpr (EARLY0) {
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_layer_coop(LayerArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
       layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc,
-                                              EPI == EPI_ADJ_L0 ? &z0p[mi] : nullptr);
+                                              Z0P ? &z0p[mi] : nullptr);
     STAMP(13);
   }
   flush_pbar<EPI, ACT>(a, pacc, lane);

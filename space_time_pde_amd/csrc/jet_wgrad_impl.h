@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     float cqq[6];
     // bf16-pipe modes: likewise the next tile's activated-input source blocks (first-layer weight gradient 29.3 -> 27.0 ms
     // per step; with fp32 operands the early loads cost 1.5 %, so the fp32 kernels keep them behind the MFMAs)
-    constexpr bool EARLYQ = BF;
+    constexpr bool EARLYQ = BF && SPL == 1;     // (three-term split mode: 77.9 -> 93.2 ms with the early loads)
     if (EARLYQ && NBUF == 2 && STPDE_ABLATE_W != 3) load_q(nx, preq, cqq);
     f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (XB) {

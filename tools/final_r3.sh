@@ -2,6 +2,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 bash $R/tools/profile_r3.sh > $O/profile_r3.log 2>&1
+bash $R/tools/micro/pmc_bf16.sh > $O/pmc_bf16.log 2>&1
 cd $R
 python tools/make_traffic_json.py $O/prof_r3/r3_pmc_FETCH_SIZE.txt $O/prof_r3/r3_pmc_WRITE_SIZE.txt 1048576 softplus $O/prof_r3/pmc_traffic.json
 python tools/make_traffic_json.py $O/prof_r3/r3_c4_pmc_FETCH_SIZE.txt $O/prof_r3/r3_c4_pmc_WRITE_SIZE.txt 1048576 softplus $O/prof_r3/pmc_traffic_c4_bf16.json bf16
@@ -14,6 +15,8 @@ for p in 524288 262144 131072; do python bench.py --points $p --steps 8 --warmup
 STPDE_BENCH_ONE_DEVICE=1 STPDE_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline > $O/r3_bench_2rank_gloo.json 2> /dev/null
 python tools/bench_inference.py > $O/r3_inference.json 2> /dev/null
 python tools/bench_next_rows.py > $O/r3_next_rows.json 2> /dev/null
+python tools/unet_profile.py 64 256 256 > $O/r3_unet_profile_c4.txt 2> /dev/null
+python tools/unet_profile.py 32 128 128 > $O/r3_unet_profile_c2.txt 2> /dev/null
 for f in r3_bench r3_bench_leakyrelu r3_bench_fp32x3 r3_bench_bf16_mode_c2grid r3_bench_config4_bf16 r3_proxy_524288 r3_proxy_262144 r3_proxy_131072 r3_bench_2rank_gloo; do python - <<PY
 import json
 try:

@@ -36,7 +36,7 @@ def bench_name(sym):
     m = re.match(r"k_layer_coop2<(\d+),(\d+),(\d+),(\d+),(-?\d+)>", sym)
     if m:
         return {2: "layer1_dgrad", 1: "layer2_dgrad"}.get(int(m.group(4)))
-    m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+?)(?:,(\w+))?(?:,\d+)?>", sym)
+    m = re.match(r"k_wgrad_coop<(\d+),(\d+),(\d+),(-?\d+),(\d+),(\w+?)(?:,(\w+?))?(?:,[\d,]+)?>", sym)
     if m and int(m.group(3)) == 1 and m.group(6) == "false" and (m.group(7) in (None, "false") or BF16):
         return "layer1_wgrad"
     if m and int(m.group(3)) == 0 and int(m.group(5)) == 4 and m.group(6) == "false" and (m.group(7) in (None, "false") or BF16):
