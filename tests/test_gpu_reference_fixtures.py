@@ -212,11 +212,13 @@ def test_recompute_mode_gives_bit_identical_gradients(hiplib, monkeypatch):
         assert (a - b).abs().max().item() <= 5e-6 * a.abs().max().item()   # fp32-atomic summation order
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("act", ["softplus", "leakyrelu"])
-def test_one_call_per_direction_equals_the_per_kernel_path(hiplib, act, monkeypatch):
+def test_one_call_per_direction_equals_the_per_kernel_path(hiplib, act, prec, monkeypatch):
     """stpde_lig_imnet_jet_fwd / _bwd (one C call per direction, cell sort on the device) against the per-layer entry points
     sequenced from Python: the same kernels in the same order -> identical jets and d latent bit for bit, weight gradients
-    to fp32-atomic rounding.  Several chunks, an odd point count, many points per cell."""
+    to fp32-atomic rounding.  Several chunks, an odd point count, many points per cell.  "bf16": the mode with packed layer
+    buffers (stash / adjoint formats, separate adjoint buffers) -- both hosts of it must lay the buffers out the same way."""
     from space_time_pde_amd import _lib, implicit_net, lig_jet, nonlinearities
     g = torch.Generator().manual_seed(51)
     lat = 0.5 * torch.randn(2, 3, 4, 5, 32, generator=g)
@@ -232,12 +234,14 @@ def test_one_call_per_direction_equals_the_per_kernel_path(hiplib, act, monkeypa
             p.grad = None
         latd = lat.to(DEV).requires_grad_(True)
         with _lib.dispatch_trace() as tr:
-            jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=1024, combo=combo)
+            jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=1024, combo=combo,
+                                       precision=prec)
             if cot is None:
                 cot = torch.randn(jets.shape, generator=g).to(DEV)
             (jets * cot).sum().backward()
             torch.cuda.synchronize()
         assert tr.has("k_dlat_reduce") and tr.has("k_gather") and tr.has("k_tail_bwd"), "\n".join(tr.kernels)
+        assert tr.has("k_tail_bwd_bf") == (prec == "bf16"), "\n".join(tr.kernels)
         out.append((jets.detach().clone(), latd.grad.clone(), [p.grad.clone() for p in net.parameters()]))
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
@@ -245,8 +249,9 @@ def test_one_call_per_direction_equals_the_per_kernel_path(hiplib, act, monkeypa
         assert (a - b).abs().max().item() <= 5e-6 * a.abs().max().item()   # fp32-atomic summation order
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("act", ["softplus", "leakyrelu", "swish"])
-def test_dgrad_first_two_phase_backward_equals_one_call(hiplib, act):
+def test_dgrad_first_two_phase_backward_equals_one_call(hiplib, act, prec):
     """The order the point-sharded step uses (train_step.sharded_step -> lig_jet.sync_hooks): phase A = the whole
     input-gradient chain into fresh adjoint buffers + d latent, then the collective hook, then phase B = the weight gradients
     (stpde_lig_imnet_jet_bwd with STPDE_F_PHASE_A / _B, stpde_jet_layer_bwd_to).  With no-op hooks on one rank the result must
@@ -265,7 +270,7 @@ def test_dgrad_first_two_phase_backward_equals_one_call(hiplib, act):
         for p in net.parameters():
             p.grad = None
         latd = lat.to(DEV).requires_grad_(True)
-        jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=512, combo=combo)
+        jets, _ = lig_jet.lig_jets(net, latd, pts.to(DEV), 0., 1., True, (), chunk_points=512, combo=combo, precision=prec)
         if cot is None:
             cot = torch.randn(jets.shape, generator=g).to(DEV)
         if two_phase:
