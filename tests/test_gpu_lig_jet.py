@@ -419,3 +419,49 @@ def test_fewer_latent_channels(hiplib, cin, nf):
     for k in range(6):
         assert _relerr(net.fc[k].weight.grad, p64[k][0].grad) < 2e-4, "dW%d" % k
         assert _relerr(net.fc[k].bias.grad, p64[k][1].grad) < 2e-4, "db%d" % k
+
+
+def test_bf16_mode_packed_buffers_on_the_side_paths(hiplib, monkeypatch):
+    """bf16 mode (packed stash / adjoint buffers) through the paths next to the plain step: chunk-wise recomputation of the
+    stash in the backward, a second backward after retain_graph, a forward without gradients, the atomic d-latent scatter,
+    and the value-only query (which keeps the fp32 fc3 -> fc5 kernels: agreement to the two-term products' 2^-16)."""
+    from space_time_pde_amd import lig_jet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    lat = 0.5 * torch.randn(2, 4, 5, 6, 32, generator=g)
+    pts = torch.rand(2, 777, 3, generator=g)
+    net = _net("softplus", nf=32, seed=1).to(dev)
+    combo = {(1, 1): 1.0, (2, 2): 0.25}
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        latd = lat.to(dev).requires_grad_(True)
+        jets, _ = lig_jet.lig_jets(net, latd, pts.to(dev), 0., 1., True, (), chunk_points=512, combo=combo, precision="bf16")
+        cot = torch.randn(jets.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        return jets, latd, cot
+
+    jets, latd, cot = run()
+    (jets * cot).sum().backward(retain_graph=True)
+    j0, g0, w0 = jets.detach().clone(), latd.grad.clone(), [p.grad.clone() for p in net.parameters()]
+    latd.grad = None
+    (jets * cot).sum().backward()                      # second backward: the stash is rebuilt by the forward kernels
+    assert torch.equal(latd.grad, g0)
+    n0 = lig_jet.stats["recompute_steps"]
+    monkeypatch.setattr(lig_jet, "force_recompute", True)
+    jets, latd, cot = run()
+    (jets * cot).sum().backward()
+    monkeypatch.setattr(lig_jet, "force_recompute", False)
+    assert lig_jet.stats["recompute_steps"] == n0 + 1
+    assert torch.equal(jets.detach(), j0) and torch.equal(latd.grad, g0)
+    for a, b in zip(w0, [p.grad for p in net.parameters()]):
+        assert (a - b).abs().max().item() <= 5e-6 * a.abs().max().item()       # fp32-atomic summation order
+    with torch.no_grad():
+        j2, _ = lig_jet.lig_jets(net, lat.to(dev), pts.to(dev), 0., 1., True, (), chunk_points=512, combo=combo, precision="bf16")
+        j3, _ = lig_jet.lig_jets(net, lat.to(dev), pts.to(dev), 0., 1., False, (), chunk_points=512, precision="bf16")
+    assert torch.equal(j2, j0)
+    assert _relerr(j3[0], j0[0].double().cpu()) < 5e-5
+    monkeypatch.setattr(lig_jet, "deterministic_dlatent", False)
+    jets, latd, cot = run()
+    (jets * cot).sum().backward()
+    assert _relerr(latd.grad, g0.double().cpu()) < 5e-6
