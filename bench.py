@@ -69,14 +69,14 @@ def algorithmic_bytes(S, smooth_sp0=4, nf=32, cin=32, cout=4, packed=False):
         for l in range(1, 6):
             by["layer%d_fwd" % l] = (stash(l - 1) if l > 1 else 0) + xb + stash(l) + (4 * widths[0] if l == 1 else 0)
             by["layer%d_dgrad" % l] = adj(l) + ((stash(l - 1) + adj(l - 1)) if l > 1 else xb + (4 + 2) * widths[0])
-            by["layer%d_wgrad" % l] = adj(l) + (stash(l - 1) if l > 1 else 0) + 2 * xb
+            by["layer%d_wgrad" % l] = adj(l) + (stash(l - 1) if l > 1 else 4 * widths[0]) + 2 * xb     # (l = 1: the z0 stash)
         by["layer0_wgrad"] = 2 * widths[0] + xb
         return by
     for l in range(1, 6):
         out_b, in_b = 4 * S * widths[l], (4 * S * widths[l - 1] if l > 1 else 0)
         by["layer%d_fwd" % l] = in_b + xb + out_b
         by["layer%d_dgrad" % l] = out_b + (2 * in_b if l > 1 else xb + 4 * smooth_sp0 * widths[0])
-        by["layer%d_wgrad" % l] = out_b + in_b + 2 * xb
+        by["layer%d_wgrad" % l] = out_b + (in_b if l > 1 else 4 * widths[0]) + 2 * xb       # (l = 1: the z0 stash)
     by["layer0_wgrad"] = 4 * smooth_sp0 * widths[0] + xb
     return by
 
