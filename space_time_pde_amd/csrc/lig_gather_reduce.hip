@@ -148,6 +148,98 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   }
 }
 
+// The same kernel for the reference's 32 latent channels, one WAVE per row tile (round 3): a lane (g, j) fetches channels
+// 8g .. 8g+7 of the grid node of corner row j as two aligned 16-byte loads (the first version: four dword loads per lane,
+// unaligned by the three coordinate features in front of the channels), the 16 x 36 feature rows of the tile go through an
+// LDS patch, and BOTH fragment images of the three input tiles leave as coalesced 16-byte stores (the row-major image used
+// to be four strided dword stores per lane).  Same expressions for the cell index / relative coordinates, bit for bit.
+__global__ __launch_bounds__(256) void k_gather_tile(GatherArgs a) {
+  constexpr int RS = 36;                       // floats per row: features 0..35 = rel(3), 32 channels, the ones column
+  __shared__ __attribute__((aligned(16))) float rows[4][16 * RS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntiles = a.d.P / 2;
+  const int tile = blockIdx.x * 4 + wv;
+  const bool live = tile < ntiles;
+  const int g = lane >> 4, j = lane & 15;
+  float* rw = rows[wv];
+  if (live) {
+    const int p = tile * 2 + (j >> 3);
+    const int corner = j & 7;
+    const int bit[3] = {(corner >> 2) & 1, (corner >> 1) & 1, corner & 1};
+    const int n[3] = {a.d.n0, a.d.n1, a.d.n2};
+    float pt[3] = {a.pts[(size_t)p * 3], a.pts[(size_t)p * 3 + 1], a.pts[(size_t)p * 3 + 2]};
+    float q[3];
+    int i0[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) i0[d] = cell_index_1d(pt[d], a.d.lo_c[d], a.d.hi_c[d], a.d.cube[d], n[d], q[d]);
+    int b = (a.d.p_base + p) / a.d.N;
+    b = b > a.d.B - 1 ? a.d.B - 1 : b;
+    const size_t node0 = (((size_t)b * n[0] + i0[0]) * n[1] + i0[1]) * n[2] + i0[2];
+    const size_t node = node0 + ((size_t)bit[0] * n[1] + bit[1]) * n[2] + bit[2];
+    const f32x4 c0 = ld4(a.latent + node * 32 + 8 * g), c1 = ld4(a.latent + node * 32 + 8 * g + 4);
+    float* rj = rw + j * RS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rj[3 + 8 * g + k] = c0[k];
+      rj[3 + 8 * g + 4 + k] = c1[k];
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        // relative coordinate of this corner along dimension f: (q - pos) / cube, pos = (i0 + bit) * cube (reference :69-76)
+        const float cs = a.d.cube[f];
+        const float i0f = (float)i0[f];
+        const float pos = bit[f] ? (i0f + 1.f) * cs : i0f * cs;
+        rj[f] = (q[f] - pos) / cs;
+      }
+      rj[35] = 1.f;                            // bias column
+      if (corner == 0) {
+        const PointGeom gm = point_geom(pt, a.d.lo_c, a.d.hi_c, a.d.cube, n);
+        float* cf = a.coef + (size_t)p * 16;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          cf[d] = gm.om[0][d];
+          cf[3 + d] = gm.om[1][d];
+          cf[6 + d] = gm.dom[0][d];
+          cf[9 + d] = gm.dom[1][d];
+          cf[12 + d] = gm.kap[d];
+        }
+        cf[15] = 0.f;
+        a.cell[p] = (int)node0;
+        if (a.cw) {  // weights of the combined second-order stream: alpha_k * kappa_a * kappa_b over the canonical pairs
+          float* cwp = a.cw + (size_t)p * 8;
+          const float k0 = gm.kap[0], k1 = gm.kap[1], k2 = gm.kap[2];
+          cwp[0] = a.d.alpha[0] * k0 * k0;
+          cwp[1] = a.d.alpha[1] * k0 * k1;
+          cwp[2] = a.d.alpha[2] * k0 * k2;
+          cwp[3] = a.d.alpha[3] * k1 * k1;
+          cwp[4] = a.d.alpha[4] * k1 * k2;
+          cwp[5] = a.d.alpha[5] * k2 * k2;
+          cwp[6] = 0.f;
+          cwp[7] = 0.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  float* xo = a.X + (size_t)tile * XT * 256 + lane * 4;
+  // column-major images: lane (g, j) = features 4g..4g+3 of row j; tile 2 is sparse (register 0: feature 32 + g)
+  st4(xo, ld4(rw + j * RS + 4 * g));
+  st4(xo + 256, ld4(rw + j * RS + 16 + 4 * g));
+  st4(xo + 512, f32x4{rw[j * RS + 32 + g], 0.f, 0.f, 0.f});
+  if (a.XR) {
+    // row-major images: lane (g, c) = rows 4g..4g+3 of slot c
+    float* ro = a.XR + (size_t)tile * XT * 256 + lane * 4;
+    const float* r0 = rw + 4 * g * RS;
+    st4(ro, f32x4{r0[j], r0[RS + j], r0[2 * RS + j], r0[3 * RS + j]});
+    st4(ro + 256, f32x4{r0[16 + j], r0[RS + 16 + j], r0[2 * RS + 16 + j], r0[3 * RS + 16 + j]});
+    const int fs = 32 + (j >> 2);
+    const bool has = (j & 3) == 0;
+    st4(ro + 512, has ? f32x4{r0[fs], r0[RS + fs], r0[2 * RS + fs], r0[3 * RS + fs]} : f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
 extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X,
                                 float* XR, float* coef, int* cell, float* cw, void* stream) {
   if (!d || d->P <= 0 || (d->P & 1) || d->N <= 0 || d->p_base < 0 || d->B <= 0 || d->n0 < 2 || d->n1 < 2 || d->n2 < 2 || d->C < 1 ||
@@ -160,6 +252,11 @@ extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, co
     return STPDE_E_BADARG;
   }
   GatherArgs a{*d, pts, latent, X, XR, coef, cell, cw};
+  static const int tile_env = getenv("STPDE_GATHER_TILE") ? atoi(getenv("STPDE_GATHER_TILE")) : 1;
+  if (d->C == 32 && tile_env) {       // the reference's latent width: one wave per row tile, 16-byte loads and stores
+    STPDE_LAUNCH(k_gather_tile, dim3((unsigned)((d->P / 2 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return stpde_check_launch("k_gather_tile");
+  }
   const size_t nthreads = (size_t)(d->P / 2) * XT * 64;
   STPDE_LAUNCH(k_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_gather");

@@ -19,7 +19,7 @@ def parse(path):
 
 
 def bench_name(sym):
-    if sym.startswith("k_gather("):
+    if sym.startswith("k_gather(") or sym.startswith("k_gather_tile("):
         return "gather"
     if sym.startswith("k_fc1_fwd_spec<3,"):
         return "layer1_fwd"
