@@ -366,20 +366,22 @@ __global__ __launch_bounds__(256) void k_reduce_fwd(ReduceArgs a) {
     if (s < S) a.dst[((size_t)s * a.n_out + ch) * a.ldp + p] = y[s];
 }
 
-// one thread per (point, corner, feature 0..15): writes the S stream values of abar_out (zeros for ch >= n_out)
+// one thread per (row tile, lane of its fragment block): lane (g, j) holds output features 4g..4g+3 of corner row j and
+// writes ONE 16-byte store per stream (zeros for features >= n_out) -- the first version had one thread per feature and
+// 4-byte stores scattered over the block (1.5 ms per 2^20-point launch for 2.7 GB)
 __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)a.P * 128) return;
-  const int ch = gid & 15, corner = (gid >> 4) & 7, p = gid >> 7;
+  if (gid >= (size_t)a.P * 32) return;
+  const int lane = gid & 63;
+  const int tile = gid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int p = tile * 2 + (j >> 3), corner = j & 7;
   const int S1 = a.cfg.S1, S2 = a.cfg.S2, S = 1 + S1 + S2;
-  const int tile = p >> 1;
-  const int j = ((p & 1) << 3) | corner;
-  const int lane = ((ch >> 2) << 4) | j;
-  float* base = a.dst + (size_t)tile * a.S_mlp * 256 + lane * 4 + (ch & 3);
-  float fb[10];
+  float* base = a.dst + (size_t)tile * a.S_mlp * 256 + lane * 4;
+  f32x4 fbv[10];
 #pragma unroll
-  for (int s = 0; s < 10; ++s) fb[s] = 0.f;
-  if (ch < a.n_out) {
+  for (int s = 0; s < 10; ++s) fbv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (4 * g < a.n_out) {
     float cf[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -390,47 +392,57 @@ __global__ __launch_bounds__(256) void k_reduce_bwd(ReduceArgs a) {
       cf[4 * i + 3] = v[3];
     }
     const float* kap = cf + 12;
-    float yb[10];
+    const CornerW c = corner_weights(cf, corner);
 #pragma unroll
-    for (int s = 0; s < 10; ++s) yb[s] = s < S ? a.src[((size_t)s * a.n_out + ch) * a.ldp + p] : 0.f;
-    CornerW c = corner_weights(cf, corner);
-    fb[0] = c.w * yb[0];
-    if (S1 == 3) {
+    for (int r = 0; r < 4; ++r) {
+      const int ch = 4 * g + r;
+      if (ch >= a.n_out) continue;
+      float fb[10];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        fb[0] += c.dw[d] * yb[1 + d];
-        fb[1 + d] = c.w * kap[d] * yb[1 + d];
-      }
-      if (a.cfg.combo) {
-        const float* al = a.cfg.alpha;
-        const float g = yb[4];
-        fb[0] += (al[1] * c.ddw[0] + al[2] * c.ddw[1] + al[4] * c.ddw[2]) * g;
-        fb[1] += (2.f * al[0] * c.dw[0] * kap[0] + al[1] * c.dw[1] * kap[0] + al[2] * c.dw[2] * kap[0]) * g;
-        fb[2] += (2.f * al[3] * c.dw[1] * kap[1] + al[1] * c.dw[0] * kap[1] + al[4] * c.dw[2] * kap[1]) * g;
-        fb[3] += (2.f * al[5] * c.dw[2] * kap[2] + al[2] * c.dw[0] * kap[2] + al[4] * c.dw[1] * kap[2]) * g;
-        fb[4] = c.w * g;
-      }
+      for (int s = 0; s < 10; ++s) fb[s] = 0.f;
+      float yb[10];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        if (k < S2 && !a.cfg.combo) {
-          const int d = a.cfg.pair0[k], e = a.cfg.pair1[k];
-          const float kd = sel3(d, kap[0], kap[1], kap[2]), ke = sel3(e, kap[0], kap[1], kap[2]);
-          const float dwd = sel3(d, c.dw[0], c.dw[1], c.dw[2]), dwe = sel3(e, c.dw[0], c.dw[1], c.dw[2]);
-          const float g = yb[4 + k];
-          fb[0] += pair_ddw(c, d, e) * g;
-          const float te = dwd * ke * g;  // -> f_{1+e}
-          const float td = dwe * kd * g;  // -> f_{1+d}
-          fb[1] += (e == 0 ? te : 0.f) + (d == 0 ? td : 0.f);
-          fb[2] += (e == 1 ? te : 0.f) + (d == 1 ? td : 0.f);
-          fb[3] += (e == 2 ? te : 0.f) + (d == 2 ? td : 0.f);
-          fb[4 + k] = c.w * kd * ke * g;
+      for (int s = 0; s < 10; ++s) yb[s] = s < S ? a.src[((size_t)s * a.n_out + ch) * a.ldp + p] : 0.f;
+      fb[0] = c.w * yb[0];
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          fb[0] += c.dw[d] * yb[1 + d];
+          fb[1 + d] = c.w * kap[d] * yb[1 + d];
+        }
+        if (a.cfg.combo) {
+          const float* al = a.cfg.alpha;
+          const float gg = yb[4];
+          fb[0] += (al[1] * c.ddw[0] + al[2] * c.ddw[1] + al[4] * c.ddw[2]) * gg;
+          fb[1] += (2.f * al[0] * c.dw[0] * kap[0] + al[1] * c.dw[1] * kap[0] + al[2] * c.dw[2] * kap[0]) * gg;
+          fb[2] += (2.f * al[3] * c.dw[1] * kap[1] + al[1] * c.dw[0] * kap[1] + al[4] * c.dw[2] * kap[1]) * gg;
+          fb[3] += (2.f * al[5] * c.dw[2] * kap[2] + al[2] * c.dw[0] * kap[2] + al[4] * c.dw[1] * kap[2]) * gg;
+          fb[4] = c.w * gg;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          if (k < S2 && !a.cfg.combo) {
+            const int d = a.cfg.pair0[k], e = a.cfg.pair1[k];
+            const float kd = sel3(d, kap[0], kap[1], kap[2]), ke = sel3(e, kap[0], kap[1], kap[2]);
+            const float dwd = sel3(d, c.dw[0], c.dw[1], c.dw[2]), dwe = sel3(e, c.dw[0], c.dw[1], c.dw[2]);
+            const float gg = yb[4 + k];
+            fb[0] += pair_ddw(c, d, e) * gg;
+            const float te = dwd * ke * gg;  // -> f_{1+e}
+            const float td = dwe * kd * gg;  // -> f_{1+d}
+            fb[1] += (e == 0 ? te : 0.f) + (d == 0 ? td : 0.f);
+            fb[2] += (e == 1 ? te : 0.f) + (d == 1 ? td : 0.f);
+            fb[3] += (e == 2 ? te : 0.f) + (d == 2 ? td : 0.f);
+            fb[4 + k] = c.w * kd * ke * gg;
+          }
         }
       }
+#pragma unroll
+      for (int s = 0; s < 10; ++s) fbv[s][r] = fb[s];
     }
   }
 #pragma unroll
   for (int s = 0; s < 10; ++s)
-    if (s < a.S_mlp) base[(size_t)s * 256] = fb[s];
+    if (s < a.S_mlp) st4(base + (size_t)s * 256, fbv[s]);
 }
 
 static int check_reduce(const stpde_jet_cfg* cfg, int P, int n_out, const void* a, const void* b, const void* c) {
@@ -465,7 +477,7 @@ extern "C" int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int S_mlp, int P, 
     return STPDE_E_BADARG;
   }
   ReduceArgs a{*cfg, P, n_out, S_mlp, ldp, jets_bar, coef, abar_out};
-  const size_t n = (size_t)P * 128;
+  const size_t n = (size_t)P * 32;      // one thread per (row tile, lane): P / 2 tiles x 64 lanes
   STPDE_LAUNCH(k_reduce_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_reduce_bwd");
 }
