@@ -664,6 +664,131 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
   }
 }
 
+// fc3 of the reference width (4 output tiles, 8 hidden k-tiles + the raw-input tiles) with the four waves of a workgroup
+// on ONE row tile (round 3).  The per-wave kernel above needs the accumulators of all 4 x 11 output blocks in one wave
+// (368 - 480 registers: one wave per SIMD, every load latency in the open: 9.6 ms fp32 / 7.1 ms bf16 per step for 32 / 19 GB).
+// Here wave w transposes the adjoint blocks of output tile w into a patch all four waves read, and owns hidden k-tiles
+// 2w, 2w+1 and raw-input tile w (wave 3: the tangent column sums instead): 12 accumulator blocks and ~130 registers per
+// wave, three workgroups per CU.  Every wave adds its own columns of dW with atomics at the end (no cross-wave reduction).
+template <int S1, int S2, int ACT, int PKW, bool BFM>
+__global__ __launch_bounds__(256, 3) void k_wgrad_quad(WgradArgs a) {
+  constexpr int S = 1 + S1 + S2, KTT = 8, MCW = 4, KW = 2;
+  constexpr int TP = 24, TBLK = 16 * TP;
+  __shared__ __attribute__((aligned(16))) float pshare[S][MCW][TBLK];    // transposed adjoint blocks of the row tile
+  __shared__ __attribute__((aligned(16))) float ppriv[4][2][TBLK];       // private patches (activated-input blocks)
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lo = lane * 4;
+  const int g = lane >> 4, c = lane & 15;
+  constexpr int PM = (PKW & 2) ? 2 : 0, QM = (PKW & 1) ? 1 : 0;
+
+  f32x4 acc[MCW][KW + 1];
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+    for (int k = 0; k <= KW; ++k) acc[mi][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float acct[3][MCW];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int mi = 0; mi < MCW; ++mi) acct[d][mi] = 0.f;
+  int flip = 0;
+  auto transpose = [&](f32x4 v) -> f32x4 {
+    float* patch = ppriv[wv][flip];
+    flip ^= 1;
+    lds_put_T<TP>(patch, lane, v);
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 r = lds_get_R<TP>(patch, lane);
+    __builtin_amdgcn_wave_barrier();
+    return r;
+  };
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    float cq[6];
+    load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
+    f32x4 praw[S], qraw[KW][S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) praw[st] = ld_blk_raw(a.P, PM, tile, S, MCW, st, wv, lane);
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int st = 0; st < S; ++st) qraw[k][st] = ld_blk_raw(a.Q, QM, tile, S, KTT, st, KW * wv + k, lane);
+    f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wv < XT) xr = ld4(a.XR + ((size_t)tile * XT + wv) * 256 + lo);      // already the row-major image
+#pragma unroll
+    for (int st = 0; st < S; ++st) lds_put_T<TP>(&pshare[st][wv][0], lane, blk_val(praw[st], PM, st));
+    __syncthreads();
+    // (the transposed adjoint blocks are read from the shared patch where they are used: 4 instead of 20 blocks in registers)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      f32x4 pre[S], H[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) pre[st] = blk_val(qraw[k][st], QM, st);
+      act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        const f32x4 hr = transpose(H[st]);
+        f32x4 pa[MCW];
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) pa[mi] = lds_get_R<TP>(&pshare[st][mi][0], lane);
+        if constexpr (BFM) {
+          const bf16x4 h16 = to_bf4(hr);
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi) acc[mi][k] = mfma_bf16k(to_bf4(pa[mi]), h16, acc[mi][k]);
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][k] = mfma4(pa[mi][r], hr[r], acc[mi][k]);
+        }
+      }
+    }
+    if (wv < XT) {
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) {
+        const f32x4 p0 = lds_get_R<TP>(&pshare[0][mi][0], lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][KW] = mfma4(p0[r], xr[r], acc[mi][KW]);
+      }
+    } else if (S1 == 3) {
+      // tangent stream d of a skip connection sees the unit vector e_d: column d of the raw-input block gets the sum over the
+      // rows of the adjoint (per-lane partial sums, folded once at the end)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) {
+          const f32x4 pd = lds_get_R<TP>(&pshare[1 + d][mi][0], lane);
+          acct[d][mi] += (pd[0] + pd[1]) + (pd[2] + pd[3]);
+        }
+    }
+    __syncthreads();        // every wave is done with pshare before the next tile's blocks go in
+  }
+  const int ldw = 16 * (KTT + XT);
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi) {
+#pragma unroll
+    for (int k = 0; k <= KW; ++k) {
+      if (k == KW && wv >= XT) continue;
+      const int col = k < KW ? 16 * (KW * wv + k) : 16 * (KTT + wv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r]);
+    }
+  }
+  if (S1 == 3 && wv == XT) {
+    // lane (g, c): partial row sums (rows 4g..4g+3 of every tile) of output feature c; fold the four lane groups
+#pragma unroll
+    for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float v = acct[d][mi];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) atomicAdd(a.dW + (size_t)(16 * mi + c) * ldw + 16 * KTT + d, v);
+      }
+  }
+}
+
 template <int S1, int S2, int ACT, int MCW, int KTT>
 static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
   const int gy = (a.MT + MCW - 1) / MCW;
@@ -705,6 +830,18 @@ static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
       // fc3 of the reference net (4 output tiles, 8 hidden k-tiles): all four output tiles in ONE pass halves the stash reads
       // of this HBM-bound kernel (the two-pass grid reads abar3 / pre2 twice: 11.4 -> 9.6 ms per step, 368 registers = one wave
       // per SIMD); STPDE_WGRAD_MCW4=0: two passes
+      static const int quad = getenv("STPDE_WGRAD_QUAD") ? atoi(getenv("STPDE_WGRAD_QUAD")) : 1;
+      if constexpr (S1 == 3) {
+        if (a.KT == 8 && a.MT == 4 && quad && XT == 3 && (a.pk == 0 || a.pk == 5)) {
+          int gx = 768;                        // three workgroups per CU, persistent
+          if (gx > a.ntiles) gx = a.ntiles;
+          if (a.pk)
+            STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 3, true>), dim3(gx), dim3(256), 0, stream, a);
+          else
+            STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 0, false>), dim3(gx), dim3(256), 0, stream, a);
+          return stpde_check_launch("k_wgrad_quad");
+        }
+      }
       static const int mcw4 = getenv("STPDE_WGRAD_MCW4") ? atoi(getenv("STPDE_WGRAD_MCW4")) : 1;
       static const int mcw4_bf = getenv("STPDE_WGRAD_MCW4_BF") ? atoi(getenv("STPDE_WGRAD_MCW4_BF")) : 1;
       if (a.KT == 8 && a.MT == 4 && (a.pk ? mcw4_bf : mcw4)) return launch_wgrad_wave<S1, S2, ACT, 4, 8>(a, stream);
