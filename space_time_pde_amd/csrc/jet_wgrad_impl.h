@@ -670,12 +670,15 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
 // Here wave w transposes the adjoint blocks of output tile w into a patch all four waves read, and owns hidden k-tiles
 // 2w, 2w+1 and raw-input tile w (wave 3: the tangent column sums instead): 12 accumulator blocks and ~130 registers per
 // wave, three workgroups per CU.  Every wave adds its own columns of dW with atomics at the end (no cross-wave reduction).
-template <int S1, int S2, int ACT, int PKW, bool BFM>
-__global__ __launch_bounds__(256, 3) void k_wgrad_quad(WgradArgs a) {
-  constexpr int S = 1 + S1 + S2, KTT = 8, MCW = 4, KW = 2;
+// NWV = 8 (round 3): the same scheme for the second hidden layer of the reference width (8 output tiles, 16 hidden k-tiles):
+// 24 accumulator blocks per wave, one workgroup of 8 waves per CU; the adjoint blocks of a row tile are transposed ONCE (the
+// ring kernel k_wgrad_coop does it once per k-group) and the waves meet at two barriers per row tile.
+template <int S1, int S2, int ACT, int PKW, bool BFM, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(WgradArgs a) {
+  constexpr int S = 1 + S1 + S2, KTT = 2 * NWV, MCW = NWV, KW = 2;
   constexpr int TP = 24, TBLK = 16 * TP;
   __shared__ __attribute__((aligned(16))) float pshare[S][MCW][TBLK];    // transposed adjoint blocks of the row tile
-  __shared__ __attribute__((aligned(16))) float ppriv[4][2][TBLK];       // private patches (activated-input blocks)
+  __shared__ __attribute__((aligned(16))) float ppriv[NWV][2][TBLK];     // private patches (activated-input blocks)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lo = lane * 4;
@@ -703,21 +706,39 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_quad(WgradArgs a) {
     return r;
   };
 
+  // the blocks of a row tile are requested one iteration ahead, into the registers the current tile has just released: the
+  // adjoint blocks right after they went into the patch, the input blocks of k-tile k after its activation jets
+  f32x4 praw[S], qraw[KW][S];
+  f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_p = [&](int t) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) praw[st] = ld_blk_raw(a.P, PM, t, S, MCW, st, wv, lane);
+    if (wv < XT) xr = ld4(a.XR + ((size_t)t * XT + wv) * 256 + lo);        // already the row-major image
+  };
+  auto load_qk = [&](int t, int k) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) qraw[k][st] = ld_blk_raw(a.Q, QM, t, S, KTT, st, KW * wv + k, lane);
+  };
+  constexpr bool PF = NWV == 8;       // (the 4-wave variant runs three workgroups per CU on a 168-register budget: no room)
+  if (PF && (int)blockIdx.x < a.ntiles) {
+    load_p(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) load_qk(blockIdx.x, k);
+  }
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tnext = tile + (int)gridDim.x < a.ntiles ? tile + (int)gridDim.x : tile;     // (last one: re-read, unused)
     float cq[6];
     load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
-    f32x4 praw[S], qraw[KW][S];
+    if (!PF) {
+      load_p(tile);
 #pragma unroll
-    for (int st = 0; st < S; ++st) praw[st] = ld_blk_raw(a.P, PM, tile, S, MCW, st, wv, lane);
-#pragma unroll
-    for (int k = 0; k < KW; ++k)
-#pragma unroll
-      for (int st = 0; st < S; ++st) qraw[k][st] = ld_blk_raw(a.Q, QM, tile, S, KTT, st, KW * wv + k, lane);
-    f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (wv < XT) xr = ld4(a.XR + ((size_t)tile * XT + wv) * 256 + lo);      // already the row-major image
+      for (int k = 0; k < KW; ++k) load_qk(tile, k);
+    }
 #pragma unroll
     for (int st = 0; st < S; ++st) lds_put_T<TP>(&pshare[st][wv][0], lane, blk_val(praw[st], PM, st));
+    const f32x4 xcur = xr;
+    if (PF) load_p(tnext);
     __syncthreads();
     // (the transposed adjoint blocks are read from the shared patch where they are used: 4 instead of 20 blocks in registers)
 #pragma unroll
@@ -725,6 +746,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_quad(WgradArgs a) {
       f32x4 pre[S], H[S];
 #pragma unroll
       for (int st = 0; st < S; ++st) pre[st] = blk_val(qraw[k][st], QM, st);
+      if (PF) load_qk(tnext, k);
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) {
@@ -749,7 +771,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_quad(WgradArgs a) {
       for (int mi = 0; mi < MCW; ++mi) {
         const f32x4 p0 = lds_get_R<TP>(&pshare[0][mi][0], lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mi][KW] = mfma4(p0[r], xr[r], acc[mi][KW]);
+        for (int r = 0; r < 4; ++r) acc[mi][KW] = mfma4(p0[r], xcur[r], acc[mi][KW]);
       }
     } else if (S1 == 3) {
       // tangent stream d of a skip connection sees the unit vector e_d: column d of the raw-input block gets the sum over the
@@ -929,6 +951,21 @@ static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
   if constexpr (MODE == 0) {
     const int rc = try_wgrad_wave<S1, S2, ACT>(a, stream);
     if (rc >= 0) return rc;
+    // second hidden layer of the reference width: eight waves on one row tile (k_wgrad_quad<..., 8>); exact-fp32 operands, or
+    // bf16 operands with packed buffers (the three-term split mode keeps the ring kernel)
+    static const int oct = getenv("STPDE_WGRAD_OCT") ? atoi(getenv("STPDE_WGRAD_OCT")) : 1;
+    if constexpr (S1 == 3 && S1 + S2 <= 5) {
+      if (oct && a.KT == 16 && a.MT == 8 && XT == 3 && a.SP == 1 + S1 + S2 && a.XR &&
+          ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5))) {
+        int gx = 256;                          // one workgroup per CU, persistent
+        if (gx > a.ntiles) gx = a.ntiles;
+        if (a.pk)
+          STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 3, true, 8>), dim3(gx), dim3(512), 0, stream, a);
+        else
+          STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 0, false, 8>), dim3(gx), dim3(512), 0, stream, a);
+        return stpde_check_launch("k_wgrad_quad");
+      }
+    }
   }
   if (a.MT >= 16) return launch_wgrad_kc<S1, S2, MODE, ACT, 8>(a, stream);
   if constexpr (MODE == 1) {

@@ -46,12 +46,13 @@ def _assert_benchmarked_kernels(tr, act):
     assert tr.has("k_layer_coop", "1, true>)", cfg, "MCg = 4", "PRO = 0", "EPI = 1"), dump
     # layer-2 forward (activation-jet prologue)
     assert tr.has("k_layer_coop", cfg, "PRO = 1", "EPI = 0"), dump
-    # weight gradients: first hidden layer (MODE = 1, KC = 8) and layer 2 (MODE 0, KC 4): ONE launch each -- the raw-input
-    # k-tiles are folded into the hidden k-groups (no HASX = true launch for this stream set any more; the value-stream
-    # launch of layer 0, S1 = S2 = 0, is the only raw-input-only one left)
+    # weight gradients: first hidden layer (ring kernel, MODE = 1, KC = 8: ONE launch -- the raw-input k-tiles are folded into
+    # the hidden k-groups, no HASX = true launch for this stream set; the value-stream launch of layer 0, S1 = S2 = 0, is the
+    # only raw-input-only one left), layer 2 (eight waves on one row tile) and fc3 (four waves on one row tile), fc4 / fc5
     assert tr.has("k_wgrad_coop", "false>)", cfg, "MODE = 1", "KC = 8"), dump
     assert not tr.has("k_wgrad_coop", "true>)", cfg), dump
-    assert tr.has("k_wgrad_coop", cfg, "MODE = 0", "KC = 4"), dump
+    assert tr.has("k_wgrad_quad", "false, 8>)", cfg), dump
+    assert tr.has("k_wgrad_quad", "false>)", cfg), dump
     assert tr.has("k_wgrad_wave", cfg), dump
     assert tr.has("k_gather") and tr.has("k_xbar") and tr.has("k_reduce_bwd"), dump
 
@@ -127,7 +128,8 @@ def _assert_bf16_kernels(tr, cfg, dump):
     # bf16 weight gradients with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
     # (the packed-stash instantiations carry two more template arguments: ..., false, true, 1, PKA>)
     assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1", "KC = 8"), dump
-    assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 0", "KC = 4"), dump
+    assert tr.has("k_wgrad_quad", "true, 8>)", cfg), dump          # layer 2: eight waves on one row tile, bf16 contraction
+    assert tr.has("k_wgrad_quad", "true>)", cfg), dump             # fc3: four waves
     assert not tr.has("k_wgrad_coop", "KC, true, true", cfg), dump
 
 
