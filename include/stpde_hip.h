@@ -204,7 +204,10 @@ int stpde_jet_layer_bwd_to(const stpde_layer_desc* d, const float* abar_out, con
  * columns tanc0 [3][KT][256] = W0[:, d] in the column-major image, the second-order streams are zero) -- call it before
  * stpde_jet_layer_bwd(first_hidden) writes the layer-0 adjoint over the stash.  XR = row-major augmented input from
  * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug.  d->mfma_bf16: layers with MT >= 8 contract with
- * bf16-rounded operands (two derivative streams per v_mfma_f32_16x16x32_bf16), fp32 accumulation. */
+ * bf16-rounded operands (two derivative streams per v_mfma_f32_16x16x32_bf16), fp32 accumulation.  d->packed (bf16 mode,
+ * bits 1 = in_pre is a packed stash, 4 = abar_out is a packed adjoint buffer): the narrow layers (MT < 8) and the raw-input
+ * layer (KT = 0, mfma_bf16 = 1, packed = 4) then contract over the rows with bf16 MFMAs as well; the raw-input columns of
+ * the hidden layers stay fp32. */
 int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* XR,
                     const float* tanc0, float* dW_aug, const float* cw, void* stream);
 
