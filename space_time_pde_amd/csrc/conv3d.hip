@@ -504,6 +504,13 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
   if (lds_env && d->ksize == 3 && KT <= 2 && MT <= 2 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 32 == 0 && nblk >= 256) {
     const int wide = (KT == 2 || MT == 2);
     int gx = wide ? 256 : 512;               // persistent workgroups: one (137 KB of LDS) or two (68 KB) per CU
+    // Volumes below ~2 M voxels: the training step runs this kernel on a side stream next to the input-gradient chain
+    // (unet3d._DeferredGrads), which at that size is a chain of short launches -- a grid that fills every CU with persistent
+    // MFMA-bound workgroups stretches that chain by more than the weight gradients shrink (2^17-point step 63.2 -> 64.6 ms);
+    // on half of the CUs it is neutral there and still 2x the per-wave kernel when it runs alone.  STPDE_CONV_WGRAD_LDS_GX
+    // overrides.
+    static const int gx_env = getenv("STPDE_CONV_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_GX")) : 128;
+    if (gx_env > 0 && nblk < 8192) gx = gx_env;
     if (gx > nblk) gx = nblk;
     if (KT == 1 && MT == 1)
       STPDE_LAUNCH((k_conv3d_wgrad_lds<1, 1>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
