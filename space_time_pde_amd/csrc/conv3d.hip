@@ -509,8 +509,11 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
     // MFMA-bound workgroups stretches that chain by more than the weight gradients shrink (2^17-point step 63.2 -> 64.6 ms);
     // on half of the CUs it is neutral there and still 2x the per-wave kernel when it runs alone.  STPDE_CONV_WGRAD_LDS_GX
     // overrides.
-    static const int gx_env = getenv("STPDE_CONV_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_GX")) : 128;
-    if (gx_env > 0 && nblk < 8192) gx = gx_env;
+    static const int gx_env = getenv("STPDE_CONV_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_GX")) : 0;
+    if (gx_env > 0)
+      gx = gx_env;
+    else if (nblk < 8192)
+      gx = 128;
     if (gx > nblk) gx = nblk;
     if (KT == 1 && MT == 1)
       STPDE_LAUNCH((k_conv3d_wgrad_lds<1, 1>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
