@@ -717,12 +717,42 @@ def _free_bytes(device):
 
 
 def _per_point_bytes(meta):
-    """(forward stash, backward scratch) bytes per query point of the jet path (tile = 2 points, block = 1 KiB)."""
-    mt = [lay["MT"] for lay in meta.plan.layers]
-    cp = (meta.plan.cin + 3) // 4 * 4
-    fwd = (meta.S * sum(mt[1:]) + mt[0] + 2 * XT) * 512 + 64 + 32 + 4
-    bwd = meta.S * (mt[2] + mt[3]) * 512 + mt[0] * 96 + 8 * cp * 4 + 16
+    """(forward stash, backward scratch) bytes per query point of the jet path, from the SAME size functions the chunk
+    allocators use (``_buf_floats`` / ``_adj_floats``: fp32 blocks or the packed formats of the bf16 mode), plus the
+    fragment images of the augmented input (X, XR), the interpolation coefficients, the per-row weights of a combined
+    second-order stream and the cell index.  Tile = 2 points."""
+    plan = meta.plan
+    mt0 = plan.layers[0]["MT"]
+    cp = (plan.cin + 3) // 4 * 4
+    fwd_tile = 4 * (sum(_buf_floats(meta, l, 1) for l in range(1, 6)) + mt0 * _FRAG + 2 * XT * _FRAG)
+    fwd = fwd_tile // 2 + 4 * 16 + (4 * 8 if meta.cfg_out.combo else 0) + 4
+    bwd_tile = 4 * (_adj_floats(meta, 2, 1) + _adj_floats(meta, 3, 1) + mt0 * 48)
+    if meta.packed_mask:
+        bwd_tile += 4 * (_adj_floats(meta, 1, 1) + _adj_floats(meta, 4, 1) + _adj_floats(meta, 0, 1))
+    if sync_hooks:          # dgrad-first order of the point-sharded step: two more adjoint buffers
+        bwd_tile += 4 * ((0 if meta.packed_mask else _buf_floats(meta, 1, 1)) + (0 if meta.packed_mask & 1 else mt0 * _FRAG))
+    bwd = bwd_tile // 2 + 8 * cp * 4 + 4 + 24          # per-row latent adjoints, permutation, radix-sort scratch
     return fwd, bwd
+
+
+# Device-memory budget of ONE jet call in bytes (None = whatever the device has free): a call whose forward stash + backward
+# scratch would exceed it keeps no stash and rebuilds it chunk by chunk in the backward (+1 forward of compute), with the
+# chunk sized so that one chunk's stash + scratch fits half of the budget.  ``STPDE_MEM_BUDGET_GB`` / ``set_memory_budget``
+# / ``lig_jets(..., memory_budget=bytes)``: how a rank with less than the 142 GB the default 2^20-point step peaks at
+# (DESIGN 4) runs the same configuration.
+memory_budget = (lambda v: int(float(v) * 2 ** 30) if v else None)(os.environ.get("STPDE_MEM_BUDGET_GB"))
+
+
+def set_memory_budget(nbytes):
+    """Budget in bytes for the stash + scratch of one jet call (None: the free device memory); returns the previous one."""
+    global memory_budget
+    prev, memory_budget = memory_budget, (None if nbytes is None else int(nbytes))
+    return prev
+
+
+def _avail_bytes(meta, device):
+    free = _free_bytes(device)
+    return free if meta.budget is None else min(free, meta.budget)
 
 
 def _stash_bytes(meta, P):
@@ -731,16 +761,23 @@ def _stash_bytes(meta, P):
 
 
 def _recompute_chunk(meta, device):
-    """Largest power-of-two chunk whose stash + backward scratch takes at most half of the free memory."""
+    """Largest power-of-two chunk whose stash + backward scratch takes at most half of the available memory."""
     fwd, bwd = _per_point_bytes(meta)
-    n = max(1, int(0.5 * _free_bytes(device) / (fwd + bwd)))
+    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd)))
     c = 1 << (n.bit_length() - 1)
     mult = 8 if meta.S == 1 else 2
     return max(mult, min(c, DEFAULT_CHUNK))
 
 
 class LigJetFunction(torch.autograd.Function):
-    """jets[S, n_out, P] of the LIG+IM-NET composite; differentiable w.r.t. latent grid and IM-NET parameters."""
+    """jets[S, n_out, P] of the LIG+IM-NET composite; differentiable w.r.t. latent grid and IM-NET parameters.
+
+    Reproducibility.  Run to run on the same inputs: the forward (jets, and therefore a stash rebuilt by recomputation) and
+    ``d latent`` (``deterministic_dlatent``, the default: per-node gather in a fixed order) are bit-identical.  The IM-NET
+    WEIGHT gradients are NOT: every weight-gradient kernel (k_wgrad_coop / k_wgrad_quad / k_wgrad_wave, csrc/jet_wgrad_impl.h)
+    finishes with fp32 atomic adds of its workgroups' partial sums into the flat dW buffer, whose order varies -- they agree to
+    fp32 summation-order rounding (a few 1e-6 relative; the tolerance of the second-backward / host-equality tests).  The same
+    holds for the convolution weight gradients of the U-Net (csrc/conv3d.hip).  There is no deterministic switch for them."""
 
     @staticmethod
     @_lib.guarded
@@ -758,10 +795,11 @@ class LigJetFunction(torch.autograd.Function):
         # would not fit the free device memory (or an allocation fails half way), the forward keeps NO stash and the
         # backward re-runs the forward kernels chunk by chunk right before each chunk's backward (the same kernels on the
         # same inputs rebuild the same stash bit for bit): +1 forward of compute, memory bounded by one chunk.
-        recompute = need_grad and (meta.recompute or _stash_bytes(meta, P) > 0.85 * _free_bytes(pts.device))
+        recompute = need_grad and (meta.recompute or _stash_bytes(meta, P) > 0.85 * _avail_bytes(meta, pts.device))
         if recompute:
             chunk = meta.chunk = min(chunk, _recompute_chunk(meta, pts.device))
         saved = []
+        oom = False
         try:
             for p0 in range(0, P, chunk):
                 s = _forward_chunk(meta, packs, latent, pts[p0:p0 + chunk], jets, p0, need_grad and not recompute)
@@ -770,7 +808,14 @@ class LigJetFunction(torch.autograd.Function):
         except torch.OutOfMemoryError:
             if not need_grad or recompute:
                 raise
+            oom = True
+        if oom:
+            # OUTSIDE the except block: while it runs, the exception's traceback pins the failed _forward_chunk
+            # frame and its half-allocated buffers, so empty_cache() could not release them and the retry was sized against
+            # less memory than there is
             saved, s = [], None
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
             recompute = True
             chunk = meta.chunk = min(chunk, _recompute_chunk(meta, pts.device))
@@ -814,7 +859,7 @@ class LigJetFunction(torch.autograd.Function):
         def start_dlatent_sync():
             if hooks and need_lat and hooks.get("dlatent"):
                 works.append(hooks["dlatent"](dlatent))
-                hooks["dlatent_done"] = True
+                hooks["dlatent_done"] = dlatent      # WHICH tensor is summed over ranks (train_step._SumGradAcrossRanks)
 
         if rebuild:
             latent, pts = ctx.inputs
@@ -903,7 +948,7 @@ def set_mlp_precision(precision):
 
 
 def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), chunk_points=None, combo=None,
-             precision=None):
+             precision=None, memory_budget=None):
     """HIP evaluation of y and its coordinate derivatives.
 
     imnet: implicit_net.ImNet (dim=3); latent_grid [b, n0, n1, n2, c]; query_pts [b, p, 3].
@@ -912,6 +957,8 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     combo = {(a, b): alpha}: instead of one stream per pair, ONE combined second-order stream
     sum alpha_ab d2y/dq_a dq_b is carried through the network (S = 5); returned pairs = ["combo"].
     precision: "fp32" | "bf16" MFMA operands of the wide layers (None = module setting ``mlp_precision``).
+    memory_budget: bytes the stash + backward scratch of this call may take (None = module setting ``memory_budget``, whose
+    None means the free device memory); above it the backward recomputes the forward chunk by chunk (``_recompute_chunk``).
     """
     if not (latent_grid.is_cuda and query_pts.is_cuda):
         raise RuntimeError("the HIP jet path needs CUDA/HIP tensors (no CPU fallback)")
@@ -965,6 +1012,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.lo_c, meta.hi_c, meta.cube = cached_box_constants(meta.grid_shape, xmin, xmax)
     meta.need_wgrad = True
     meta.recompute = force_recompute
+    meta.budget = memory_budget if memory_budget is not None else globals()["memory_budget"]
     meta.cfg_val = make_cfg(act, prm, False, [])[0]
     P = B * N
     if P == 0:   # empty query set: nothing to launch (the reference returns an empty [b, 0, o] tensor as well)

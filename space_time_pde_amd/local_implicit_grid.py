@@ -78,8 +78,12 @@ def _query_data_parallel(dp, latent_grid, query_pts, xmin, xmax, req):
     the rows of the decoder input are scattered over ``dp.device_ids``.  Here the QUERY POINTS are: every device gets a
     replica of the IM-NET (``torch.nn.parallel.replicate``: gradients flow back to the wrapped module, summed), a copy of the
     latent grid and its share of the points, and runs the HIP jet path on them; the jets are gathered on the first device.
-    One process drives all devices, as nn.DataParallel does (``train_step.sharded_step`` -- one process per GPU over RCCL --
-    is the scalable route)."""
+    One process drives all devices, as nn.DataParallel does.  Costs that come with that mechanism, per CALL: the module is
+    re-replicated, the full latent grid is copied to every device and the devices are driven one after another from this
+    thread -- it exists so that a reference script with several ``device_ids`` keeps the HIP path instead of dropping to the
+    composed formulation, not for speed.  ``train_step.sharded_step`` (one process per GPU, collectives over RCCL) is the
+    supported multi-GPU route.  Hardware coverage: on the 1-GPU test box both "devices" are ``cuda:0``
+    (tests/test_gpu_lig_jet.py); with two real devices the path has not been run by the builder."""
     devs = list(dp.device_ids)
     B, N = query_pts.shape[0], query_pts.shape[1]
     chunks = [c for c in torch.chunk(query_pts, len(devs), dim=1) if c.shape[1] > 0]

@@ -32,7 +32,13 @@ class FusedClipAdam(torch.optim.Optimizer):
     The per-parameter state keeps torch.optim.Adam's names and shapes; ``state_dict()`` returns plain (cloned) tensors,
     so checkpoints interoperate with the reference's Adam both ways.
     A group falls back to the multi-tensor pointer-table kernel for a step in which some parameter has no gradient or the
-    step counts differ (torch's Adam skips such parameters; a flat pass could not)."""
+    step counts differ (torch's Adam skips such parameters; a flat pass could not).
+
+    Aliasing: building the flat buffers (first ``step()`` / ``gather_grads()`` after construction, ``load_state_dict`` or
+    ``add_param_group``) RE-POINTS every ``p.data`` into the new buffer.  The values are preserved, the storage is not: an
+    alias of the old storage taken before that (an EMA copy made with ``p.data`` views, a captured hipGraph, a
+    ``DistributedDataParallel`` bucket view) keeps pointing at memory the optimizer no longer updates.  Take such aliases
+    after the first step, or construct with ``flat=False`` (pointer-table kernel, storages untouched)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0, flat=True):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
@@ -52,6 +58,9 @@ class FusedClipAdam(torch.optim.Optimizer):
             if group.get("amsgrad") or group.get("maximize"):
                 raise ValueError("FusedClipAdam does not implement amsgrad / maximize")
         self._flat = {}          # loaded state tensors are fresh allocations: rebuild the flat views on the next step
+        # Optimizer.__getstate__ serialises defaults / state / param_groups only: an instance that comes back from
+        # copy.deepcopy or pickle has no ``_use_flat`` yet (flat mode is the default of __init__)
+        self._use_flat = bool(getattr(self, "_use_flat", True))
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

@@ -30,11 +30,20 @@ class _SumGradAcrossRanks(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         hooks = lig_jet.sync_hooks
-        if hooks and hooks.get("dlatent_done"):
-            return g          # already summed over ranks inside the HIP backward (behind the IM-NET weight gradients)
-        g = g.contiguous()
-        dist.all_reduce(g)
-        return g
+        done = hooks.get("dlatent_done") if hooks else None
+        if done is None:
+            g = g.contiguous()
+            dist.all_reduce(g)
+            return g
+        # ``done`` is the tensor the HIP backward has already summed over ranks (behind the IM-NET weight gradients).  With
+        # ONE consumer of the latent grid in the graph -- what sharded_step builds -- the incoming gradient IS that tensor
+        # and passes through.  A second consumer (another query, a value query next to a jet query, a partial generic
+        # fallback) makes autograd hand over reduced + local contributions: only the local remainder still has to be summed.
+        if g.data_ptr() == done.data_ptr() and g.shape == done.shape and g.stride() == done.stride():
+            return g
+        rest = (g - done.view_as(g)).contiguous()
+        dist.all_reduce(rest)
+        return rest + done.view_as(g)
 
 
 _LOSS_SUMS = {

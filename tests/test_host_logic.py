@@ -193,3 +193,19 @@ def test_tensor_bounds_cache_survives_repeated_lookups():
     assert lig_jet.cached_box_constants((4, 8, 8), a, b)[2][0] == pytest.approx(2.0 / 3.0)
     with pytest.raises(ValueError):
         lig_jet.cached_box_constants((4, 8, 8), torch.full((3,), 0.5), b)
+
+
+def test_fused_clip_adam_survives_deepcopy_and_pickle():
+    """Optimizer.__getstate__ serialises defaults / state / param_groups only, so a copied FusedClipAdam came
+    back without ``_use_flat`` and step() raised AttributeError.  (Host logic only: no launch on this machine.)"""
+    import copy
+    import pickle
+    import torch
+    from space_time_pde_amd.optim import FusedClipAdam
+    p = torch.nn.Parameter(torch.zeros(8))
+    for flat in (True, False):
+        opt = FusedClipAdam([p], lr=1e-3, clip_grad=0.5, flat=flat)
+        for clone in (copy.deepcopy(opt), pickle.loads(pickle.dumps(opt))):
+            assert clone._use_flat in (True, flat) and clone._flat == {}
+            assert clone.param_groups[0]["clip_grad"] == 0.5
+            clone.step()          # no gradients anywhere: nothing to launch, but every attribute step() reads must exist
