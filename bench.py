@@ -30,6 +30,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BASELINE configs[4] / SURVEY 8(d) C5: 3 inputs (x, y, t), 5 outputs (c, u, v, w, p), user strings.  The first is SURVEY's
+# advection-diffusion string with k = 0.01; together the four are the set pinned against the imported reference by fixture
+# G9 (tests/golden/make_golden.py: g9_generic) -- every channel appears, second derivatives xx, yy, xy, tt.
+C5_VARS = ("x, y, t", "c, u, v, w, p")
+C5_EQS = {
+    "adv_diff": "dif(c,t)+u*dif(c,x)+v*dif(c,y)-0.01*(dif(dif(c,x),x)+dif(dif(c,y),y))",
+    "prod_rule": "dif(u*c,x)+dif(v*c,y)",
+    "mixed": "dif(dif(c,x),y)-w*p",
+    "explicit_x": "x*dif(p,x)+t*dif(dif(p,t),t)",
+}
 MEAN, STD = (0.01, 0.0, 0.02, -0.01), (0.05, 0.3, 0.15, 0.12)
 RB2 = dict(mean=MEAN, std=STD, t_crop=2., z_crop=1., x_crop=1., use_continuity=True)
 ALPHA_REG, ALPHA_PDE = 1.0, 0.0125
@@ -81,12 +91,19 @@ def algorithmic_bytes(S, smooth_sp0=4, nf=32, cin=32, cout=4, packed=False):
     return by
 
 
-def make_inputs(n_pts, dev, seed=0, igres=(32, 128, 128)):
+def make_inputs(n_pts, dev, seed=0, igres=(32, 128, 128), n_out=4):
     g = torch.Generator().manual_seed(seed)
     crop = torch.randn(1, 4, *igres, generator=g).to(dev)
     pts = torch.rand(1, n_pts, 3, generator=g).to(dev)
-    tgt = torch.randn(1, n_pts, 4, generator=g).to(dev)
+    tgt = torch.randn(1, n_pts, n_out, generator=g).to(dev)
     return crop, pts, tgt
+
+
+def c5_layer(pde_module):
+    layer = pde_module.PDELayer(*C5_VARS)
+    for name, eq in C5_EQS.items():
+        layer.add_equation(eq, name)
+    return layer
 
 
 def cpu_baseline(act, chunk=1024, nchunks=16):
@@ -165,6 +182,13 @@ def main(argv=None):
                          "wide IM-NET layers, fp32 accumulation (NOT the headline metric)")
     ap.add_argument("--igres", type=int, nargs=3, default=[32, 128, 128], metavar=("T", "Z", "X"),
                     help="latent grid; 64 256 256 = BASELINE configs[3]")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                    help="c2 = BASELINE configs[1] (RB2 + continuity, 4 outputs; with --igres 64 256 256 --mlp-precision bf16: "
+                         "configs[3]); c5 = BASELINE configs[4]: 5-output user-string advection-diffusion equation set "
+                         "(the strings pinned by fixture G9: products, a mixed second derivative, explicit coordinates)")
+    ap.add_argument("--mem-budget-gb", type=float, default=None,
+                    help="device-memory budget of the jet call's stash + scratch (lig_jet.set_memory_budget): above it the "
+                         "backward recomputes the forward chunk by chunk; the line reports peak_GB either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
@@ -205,8 +229,12 @@ def main(argv=None):
     from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
 
     torch.manual_seed(1)
-    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+    c5 = args.workload == "c5"
+    n_out = 5 if c5 else 4
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=n_out, nf=32,
                              activation=nonlinearities.NONLINEARITIES[args.act]).to(dev)
+    if args.mem_budget_gb is not None:
+        lig_jet.set_memory_budget(int(args.mem_budget_gb * 2 ** 30))
     igres = tuple(args.igres)
     lig_jet.set_mlp_precision(args.mlp_precision)
     unet = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256).to(dev)
@@ -216,12 +244,16 @@ def main(argv=None):
     if world > 1:
         for p in params + uparams:
             dist.broadcast(p.data, 0)
-    crop, pts_all, tgt_all = make_inputs(args.points, dev, igres=igres)
+    crop, pts_all, tgt_all = make_inputs(args.points, dev, igres=igres, n_out=n_out)
     n_local = args.points // world
     pts = pts_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
     tgt = tgt_all[:, rank * n_local:(rank + 1) * n_local].contiguous()
     del pts_all, tgt_all
-    layer = physics.get_rb2_pde_layer(**RB2)
+    if c5:
+        from space_time_pde_amd import pde as pde_module
+        layer = c5_layer(pde_module)
+    else:
+        layer = physics.get_rb2_pde_layer(**RB2)
     lig_jet.DEFAULT_CHUNK = args.chunk
     from space_time_pde_amd.train_step import sharded_step
     uev = []
@@ -265,6 +297,50 @@ def main(argv=None):
     step_ms_seq = [a.elapsed_time(b) for a, b in sev]
     step_ms = sorted(step_ms_seq)
     step_ms_median = step_ms[len(step_ms) // 2]
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30      # warm-up + timed steps (allocated, not reserved)
+    recompute_steps = lig_jet.stats["recompute_steps"]
+    # Per-rank diagnosis of a multi-GPU line (outside the timed region, VERDICT r3 #3c): what THIS rank's step costs with no
+    # collective in it (same shard, same kernels, same overlap of the U-Net backward with the IM-NET weight gradients) and what
+    # its replicated U-Net costs alone; rank 0 prints the per-rank lists and ms_per_step - max(compute_ms) as the exposed
+    # communication (+ load imbalance) of the timed steps.
+    def local_step():
+        for p in params + uparams:
+            p.grad = None
+        sharded_step(unet, net, layer, crop, pts, tgt, args.points, ALPHA_REG, ALPHA_PDE, "l1", distributed=False)
+
+    local_step()
+    ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ce[0].record()
+    for _ in range(2):
+        local_step()
+    ce[1].record()
+    torch.cuda.synchronize()
+    compute_ms = ce[0].elapsed_time(ce[1]) / 2
+    gcot = torch.randn(1, *igres, 32, device=dev).permute(0, 4, 1, 2, 3)
+    ue = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    uf, ub = [], []
+    for it in range(3):
+        for p in uparams:
+            p.grad = None
+        ue[0].record()
+        y = unet(crop)
+        ue[1].record()
+        y.backward(gcot)
+        ue[2].record()
+        torch.cuda.synchronize()
+        if it:
+            uf.append(ue[0].elapsed_time(ue[1]))
+            ub.append(ue[1].elapsed_time(ue[2]))
+    del y, gcot
+    per_rank = torch.tensor([compute_ms, sum(uf) / len(uf), sum(ub) / len(ub), peak_gb], device=dev, dtype=torch.float64)
+    if world > 1:
+        allr = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+        per_rank = torch.stack(allr)
+    else:
+        per_rank = per_rank[None]
+    per_rank = per_rank.cpu().tolist()
     # per-kernel HIP-event timings: a SECOND pass outside the timed region (the event pairs around ~70 launches per
     # step would otherwise sit inside it)
     lig_jet.profile = {}
@@ -314,7 +390,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         side = dict(inference_value_only_points_per_s=round(3 * args.points / (ev[0].elapsed_time(ev[1]) * 1e-3)),
                     lig_only_step_points_per_s=round(2 * args.points / (ev[2].elapsed_time(ev[3]) * 1e-3)))
-        if args.mlp_precision == "fp32":
+        if args.mlp_precision == "fp32" and not c5:
             # second figure: the SAME full step with the wide layers' products as exact-split bf16 MFMAs
             # ("fp32x3": fp32 tolerances incl. the 1e-5 loss bound hold, tests/test_gpu_reference_fixtures.py); the headline
             # `value` above stays the exact-fp32 MFMA path
@@ -336,9 +412,12 @@ def main(argv=None):
 
     if rank == 0:
         smooth = args.act not in ("relu", "leakyrelu")
-        # piecewise-linear activations have identically zero second-order MLP jets
-        macs, M, T = algorithmic_macs(n_second=2 if smooth else 0)
-        fwd_flop_pt = 2 * 8 * (M + (5 if smooth else 3) * T)
+        # piecewise-linear activations have identically zero second-order MLP jets.  c5: the equation set needs
+        # 4 second-order jets (xx, yy, xy, tt); SURVEY: "replace 32*4 by 32*5 in M and T"
+        n2_alg = (4 if c5 else 2) if smooth else 0
+        n2_exe = (6 if c5 else 1) if smooth else 0       # c5: four pairs padded to the compiled (3,6) stream set
+        macs, M, T = algorithmic_macs(n_second=n2_alg, cout=n_out)
+        fwd_flop_pt = 2 * 8 * (M + (3 + n2_alg) * T)
         step_flop_pt = 3 * fwd_flop_pt
         kern = {}
         prof["unet_fwd"] = uev[-nprof:]
@@ -346,12 +425,17 @@ def main(argv=None):
             ms = [a.elapsed_time(b) for a, b in evs]
             kern[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
         dom = max(kern, key=lambda k: kern[k]["total_ms"])
-        rows_per_launch = 8 * min(args.chunk, n_local)
+        # A kernel may take several launches per step (launch chunks; with the U-Net backward overlapped, a separate last
+        # chunk of lig_jet.tail_chunk points): achieved = its algorithmic FLOPs per STEP / its time per step, which is also
+        # FLOPs per launch / average launch duration with both averaged over the same launches -- the figure a rocprofv3
+        # --stats summary of this command gives
+        lps = kern[dom]["launches"] / float(nprof)
+        rows_per_launch = 8 * n_local / lps
         flop_launch = 2.0 * macs.get(dom, 0) * rows_per_launch
         ach = flop_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
         # what the kernels actually execute: the RB2 equations use d_xx and d_zz only through one common combination,
         # so the network carries ONE second-order stream (none at all for piecewise-linear activations)
-        macs_x, _, _ = algorithmic_macs(n_second=1 if smooth else 0)
+        macs_x, _, _ = algorithmic_macs(n_second=n2_exe, cout=n_out)
         exe = 2.0 * macs_x.get(dom, 0) * rows_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (same chunk size)
@@ -359,7 +443,7 @@ def main(argv=None):
             if tj.get("act") == args.act and dom in tj["kernels"]:
                 # the counter passes were taken on a 2^18-point launch; these kernels stream every row tile exactly once,
                 # so the bytes of a launch scale with its number of tiles
-                scale = min(args.chunk, n_local) / float(tj["chunk"])
+                scale = rows_per_launch / 8.0 / float(tj["chunk"])
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"] * scale
                 traffic_src = tj.get("source").replace("r3_pmc_", "r3_c4_pmc_" if args.mlp_precision == "bf16" else "r3_pmc_") + ("" if scale == 1 else "; measured on a %d-point launch, scaled x%g to "
                                                   "this launch's tile count" % (tj["chunk"], scale))
@@ -370,7 +454,7 @@ def main(argv=None):
                         note="achieved = SURVEY 8(d) algorithmic FLOPs (value + 3 first + 2 second-order streams) / "
                              "launch time; executed_* = the MFMA work actually issued (combined second-order stream)",
                         executed_tflops=round(exe, 2), executed_frac=round(exe / PEAK_F32_TFLOPS, 4),
-                        flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3),
+                        flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3), launches_per_step=lps,
                         step_algorithmic_tflops=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world, 2),
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
                                                 / PEAK_F32_TFLOPS, 4),
@@ -379,7 +463,8 @@ def main(argv=None):
                         kernels={k: round(v["total_ms"] / nprof, 2) for k, v in sorted(kern.items())})
         if "gather" in kern:   # the gather stage in isolation is HBM-bound: algorithmic 1036 B per point
             g_ms = kern["gather"]["avg_ms"]
-            gs = dict(bound="hbm", achieved=round(1036.0 * min(args.chunk, n_local) / (g_ms * 1e-3) / 1e9, 1),
+            g_pts = n_local * nprof / float(kern["gather"]["launches"])        # points per launch, averaged like g_ms
+            gs = dict(bound="hbm", achieved=round(1036.0 * g_pts / (g_ms * 1e-3) / 1e9, 1),
                       peak=8000.0, unit="GB/s", avg_launch_ms=round(g_ms, 3),
                       note="achieved = algorithmic 12 B coords + 8 x 32 x 4 B corner latents per point / launch time; the kernel "
                            "also writes the fragment images of the MLP input (X and, for training, XR: 6 KiB per point); "
@@ -387,7 +472,7 @@ def main(argv=None):
             try:
                 tj = json.load(open(args.traffic_json))
                 if "gather" in tj["kernels"]:
-                    mb = tj["kernels"]["gather"]["hbm_bytes_per_launch"] * min(args.chunk, n_local) / float(tj["chunk"])
+                    mb = tj["kernels"]["gather"]["hbm_bytes_per_launch"] * g_pts / float(tj["chunk"])
                     gs.update(measured_bytes_per_launch=mb, measured_GBps=round(mb / (g_ms * 1e-3) / 1e9, 1),
                               measured_frac=round(mb / (g_ms * 1e-3) / 1e9 / 8000.0, 4))
             except (OSError, ValueError, KeyError):
@@ -439,7 +524,8 @@ def main(argv=None):
             roofline.pop("executed_frac", None)
             roofline["step_frac_note"] = "step_frac_per_gpu is the algorithmic fp32 FLOP rate of the step over the fp32-MFMA peak (157.3): a speed-up figure in this mode, not a utilisation"
         out = {
-            "metric": "query-points/sec (fwd+PDE-residual bwd), rb2d 128^3 latent",
+            "metric": ("query-points/sec (fwd+PDE-residual bwd), user-string 5-channel equations, 128^3 latent" if c5 else
+                       "query-points/sec (fwd+PDE-residual bwd), rb2d 128^3 latent"),
             "value": args.points * args.steps / dt,
             "unit": "query-points/s",
             "n_gpus": world,
@@ -451,6 +537,16 @@ def main(argv=None):
             "ms_per_step_hip_event_median": round(step_ms_median, 3),
             "ms_per_step_hip_event_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
             "ms_per_step_hip_event_sequence": [round(v, 2) for v in step_ms_seq],
+            "peak_GB": round(max(r[3] for r in per_rank), 2),
+            "recompute_steps": recompute_steps,
+            "per_rank": {"compute_ms": [round(r[0], 2) for r in per_rank],
+                         "unet_fwd_ms": [round(r[1], 2) for r in per_rank], "unet_bwd_ms": [round(r[2], 2) for r in per_rank],
+                         "peak_GB": [round(r[3], 2) for r in per_rank],
+                         "exposed_comm_ms": round(1e3 * dt / args.steps - max(r[0] for r in per_rank), 2),
+                         "note": "compute_ms = this rank's step on its shard with no collective in it (2 steps after the timed "
+                                 "region); unet_*_ms = its replicated U-Net alone, eager launches with their gaps (inside the "
+                                 "step the backward runs beside the IM-NET weight gradients); exposed_comm_ms = ms_per_step - "
+                                 "max(compute_ms): exchange + load imbalance not hidden behind compute"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -459,7 +555,11 @@ def main(argv=None):
                       "onto the bf16 MFMA pipe, 6 products, fp32-accurate; everything else exact fp32)"
                       if args.mlp_precision == "fp32x3" else "f32"),
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: latent [1,%d,%d,%d,32], 2^%d query points, RB2 "
+            "config": {"workload": ("BASELINE configs[4]: latent [1,%d,%d,%d,32], 2^%d query points, 5-output user-string "
+                                    "equations %s (3 inputs x, y, t; second derivatives xx, yy, xy, tt -> the (3,6) stream set), "
+                                    "ImNet nf=32 out_features=5 %s, L1 losses, backward to ImNet + UNet3d parameters"
+                                    % (igres + (args.points.bit_length() - 1, json.dumps(C5_EQS), args.act))) if c5 else
+                                   "BASELINE configs[%d]: latent [1,%d,%d,%d,32], 2^%d query points, RB2 "
                                    "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + UNet3d parameters"
                                    % ((3 if (bf16 and igres == (64, 256, 256)) else 1,) + igres + (args.points.bit_length() - 1, args.act)),
                        "points": args.points, "parallelism": "points sharded x%d" % world,

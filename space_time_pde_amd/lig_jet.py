@@ -450,12 +450,16 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return s
 
 
-def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None):
+def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None, side_stream=None):
     """_backward_chunk through ONE library call (+ allocation of its scratch).
 
     after_dlatent (callable or None): "dgrad-first" order in TWO calls -- phase A runs the whole input-gradient chain into
     fresh adjoint buffers and finishes d latent, after_dlatent() is called (the point-sharded step starts the all-reduce of
-    d latent there), phase B computes the remaining weight gradients while that all-reduce is in flight."""
+    d latent there), phase B computes the remaining weight gradients while that all-reduce is in flight.
+    side_stream: phase B is launched on THAT stream (after an event behind phase A) instead of the current one, so that
+    whatever the caller queues on the current stream next -- the U-Net backward -- runs beside the weight gradients.  Returns
+    the scratch tensors phase B works on (the caller keeps them alive until it has joined the streams), or None when phase B
+    ran on the current stream."""
     plan, S = meta.plan, meta.S
     Pc, ws, gd = saved["Pc"], saved["ws"], saved["gd"]
     nt = Pc // 2
@@ -500,11 +504,17 @@ def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None,
             ws.abar0x = buf(nt * MT0 * _FRAG)
         call(flags | _lib.F_PHASE_A)
         after_dlatent()
+        if side_stream is not None and meta.need_wgrad:
+            side_stream.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side_stream):
+                call(flags | _lib.F_PHASE_B)
+            return keep
         call(flags | _lib.F_PHASE_B)
     else:
         call(flags)
         if after_dlatent is not None:
             after_dlatent()
+    return None
 
 
 def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
@@ -583,11 +593,11 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw, z0=z0)
 
 
-def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None):
+def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None, side_stream=None):
     """reduce_bwd -> for l = 5..1: wgrad_l (reads abar_l and the still intact pre-activations of layer l-1), then
     dgrad_l (overwrites them with abar_{l-1}) -> wgrad_0 -> xbar/scatter."""
     if "ws" in saved:
-        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar, after_dlatent)
+        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar, after_dlatent, side_stream)
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()
@@ -701,11 +711,41 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
                                                  plan.cin, ptr(xrows), ptr(perm), ptr(start), ptr(dlatent), st))
     if after_dlatent is not None:      # per-kernel (profiling) path: weight gradients first, nothing left to overlap
         after_dlatent()
+    return None
 
 
-# {"dlatent": f(tensor) -> work | None, "dw": f(tensor) -> work | None}: collectives of the point-sharded step, started from
-# inside the backward (set / cleared by train_step.sharded_step; the first LigJetFunction.backward of the step consumes them)
+# {"dlatent": f(tensor) -> work | None, "dw": f(tensor) -> work | None, "defer_wgrad": bool}: collectives of the point-sharded
+# step, started from inside the backward (set / cleared by train_step.sharded_step; the first LigJetFunction.backward of the
+# step consumes them).  "defer_wgrad": the weight gradients of the LAST chunk (phase B of the dgrad-first order) run on a side
+# stream and the IM-NET ``.grad`` are assigned by a callback when the whole backward pass is over, so that the U-Net backward
+# -- a chain of short launches that leaves most of the chip idle -- runs BESIDE them instead of after them.  Only
+# ``loss.backward()`` sees gradients delivered that way (not ``torch.autograd.grad``): opt-in, set by sharded_step.
 sync_hooks = None
+
+# Points of the LAST launch chunk of a differentiable call (0 = no separate tail).  With "defer_wgrad" the weight gradients
+# of that chunk are what the U-Net backward runs beside: 2^17 points = ~18 ms of weight-gradient kernels in exact fp32
+# against ~6 ms of U-Net backward, for +7 GB of dgrad-first adjoint buffers (a whole 2^20-point chunk would take +58 GB).
+tail_chunk = 0
+
+_wgrad_streams = {}
+
+
+def _wgrad_stream(device):
+    key = (device.type, device.index)
+    if key not in _wgrad_streams:
+        _wgrad_streams[key] = torch.cuda.Stream(device=device)
+    return _wgrad_streams[key]
+
+
+def _chunk_ranges(meta, P):
+    """[(first point, points)] of the launch chunks: ``meta.chunk`` points each, plus -- for a call with ``meta.tail`` -- a
+    separate last chunk of that many points."""
+    tail = meta.tail if (meta.tail and P >= 2 * meta.tail and meta.tail < meta.chunk) else 0
+    body = P - tail
+    out = [(p0, min(meta.chunk, body - p0)) for p0 in range(0, body, meta.chunk)]
+    if tail:
+        out.append((body, tail))
+    return out
 
 stats = {"recompute_steps": 0}     # calls whose backward rebuilt the stash chunk by chunk (memory plan below)
 
@@ -729,10 +769,14 @@ def _per_point_bytes(meta):
     bwd_tile = 4 * (_adj_floats(meta, 2, 1) + _adj_floats(meta, 3, 1) + mt0 * 48)
     if meta.packed_mask:
         bwd_tile += 4 * (_adj_floats(meta, 1, 1) + _adj_floats(meta, 4, 1) + _adj_floats(meta, 0, 1))
-    if sync_hooks:          # dgrad-first order of the point-sharded step: two more adjoint buffers
-        bwd_tile += 4 * ((0 if meta.packed_mask else _buf_floats(meta, 1, 1)) + (0 if meta.packed_mask & 1 else mt0 * _FRAG))
     bwd = bwd_tile // 2 + 8 * cp * 4 + 4 + 24          # per-row latent adjoints, permutation, radix-sort scratch
     return fwd, bwd
+
+
+def _two_phase_bytes(meta):
+    """extra bytes per point of the dgrad-first order (last chunk of a sharded_step backward): two more adjoint buffers"""
+    mt0 = meta.plan.layers[0]["MT"]
+    return 2 * ((0 if meta.packed_mask else _buf_floats(meta, 1, 1)) + (0 if meta.packed_mask & 1 else mt0 * _FRAG))
 
 
 # Device-memory budget of ONE jet call in bytes (None = whatever the device has free): a call whose forward stash + backward
@@ -757,13 +801,14 @@ def _avail_bytes(meta, device):
 
 def _stash_bytes(meta, P):
     fwd, bwd = _per_point_bytes(meta)
-    return P * fwd + min(P, meta.chunk) * bwd
+    last = _chunk_ranges(meta, P)[-1][1]
+    return P * fwd + min(P, meta.chunk) * bwd + last * _two_phase_bytes(meta)
 
 
 def _recompute_chunk(meta, device):
     """Largest power-of-two chunk whose stash + backward scratch takes at most half of the available memory."""
     fwd, bwd = _per_point_bytes(meta)
-    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd)))
+    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd + _two_phase_bytes(meta))))
     c = 1 << (n.bit_length() - 1)
     mult = 8 if meta.S == 1 else 2
     return max(mult, min(c, DEFAULT_CHUNK))
@@ -800,9 +845,11 @@ class LigJetFunction(torch.autograd.Function):
             chunk = meta.chunk = min(chunk, _recompute_chunk(meta, pts.device))
         saved = []
         oom = False
+        if not need_grad:
+            meta.tail = 0
         try:
-            for p0 in range(0, P, chunk):
-                s = _forward_chunk(meta, packs, latent, pts[p0:p0 + chunk], jets, p0, need_grad and not recompute)
+            for p0, n in _chunk_ranges(meta, P):
+                s = _forward_chunk(meta, packs, latent, pts[p0:p0 + n], jets, p0, need_grad and not recompute)
                 if need_grad and not recompute:
                     saved.append(s)
         except torch.OutOfMemoryError:
@@ -819,8 +866,8 @@ class LigJetFunction(torch.autograd.Function):
             torch.cuda.empty_cache()
             recompute = True
             chunk = meta.chunk = min(chunk, _recompute_chunk(meta, pts.device))
-            for p0 in range(0, P, chunk):
-                _forward_chunk(meta, packs, latent, pts[p0:p0 + chunk], jets, p0, False)
+            for p0, n in _chunk_ranges(meta, P):
+                _forward_chunk(meta, packs, latent, pts[p0:p0 + n], jets, p0, False)
         stats["recompute_steps"] += int(recompute)
         ctx.recompute = recompute
         ctx.meta, ctx.packs, ctx.saved = meta, packs, saved
@@ -855,39 +902,73 @@ class LigJetFunction(torch.autograd.Function):
         # the IM-NET gradients are all-reduced in place in their flat buffer before they are unpacked.
         hooks = sync_hooks if (sync_hooks and not sync_hooks.get("used")) else None
         works = []
+        side = _wgrad_stream(dev) if (hooks and hooks.get("defer_wgrad") and meta.need_wgrad) else None
 
         def start_dlatent_sync():
             if hooks and need_lat and hooks.get("dlatent"):
                 works.append(hooks["dlatent"](dlatent))
                 hooks["dlatent_done"] = dlatent      # WHICH tensor is summed over ranks (train_step._SumGradAcrossRanks)
 
+        held = None        # scratch of a phase B that runs on the side stream
         if rebuild:
             latent, pts = ctx.inputs
             scratch = torch.empty(meta.S_out, meta.plan.cout, pts.shape[0], device=pts.device)
-            starts = list(range(0, pts.shape[0], meta.chunk))
-            for p0 in starts:
-                s = _forward_chunk(meta, ctx.packs, latent, pts[p0:p0 + meta.chunk], scratch, p0, True)
-                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
-                                start_dlatent_sync if (hooks and p0 == starts[-1]) else None)
+            ranges = _chunk_ranges(meta, pts.shape[0])
+            for p0, n in ranges:
+                last = hooks and p0 == ranges[-1][0]
+                s = _forward_chunk(meta, ctx.packs, latent, pts[p0:p0 + n], scratch, p0, True)
+                held = _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
+                                       start_dlatent_sync if last else None, side if last else None)
+                if held is not None:
+                    held.append(s)
                 s = None
         else:
             for k, s in enumerate(ctx.saved):
-                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
-                                start_dlatent_sync if (hooks and k == len(ctx.saved) - 1) else None)
+                last = hooks and k == len(ctx.saved) - 1
+                held = _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
+                                       start_dlatent_sync if last else None, side if last else None)
+                if held is not None:
+                    held.append(dict(s))             # the stash phase B still reads
                 s["bufs"] = s["z0"] = None  # release the stash chunk by chunk
         ctx.saved = []
+        grads = [None] * ctx.n_params
+        deferred = held is not None
         if hooks:
             hooks["used"] = True
-            if meta.need_wgrad and hooks.get("dw"):
-                works.append(hooks["dw"](dw_flat))
-                if pbar is not None:                      # adjoint of the learnable swish beta: same treatment
-                    works.append(hooks["dw"](pbar))
-                hooks["dw_done"] = True
-            for wk in works:
-                if wk is not None:
-                    wk.wait()
-        grads = [None] * ctx.n_params
-        if meta.need_wgrad:
+        if deferred:
+            # the weight gradients of the last chunk are still running on the side stream: the collective on the flat IM-NET
+            # gradient and its unpacking follow them THERE; ``.grad`` is assigned when the whole backward pass is over
+            with torch.cuda.stream(side):
+                if hooks.get("dw"):
+                    wk = hooks["dw"](dw_flat)
+                    if wk is not None:
+                        wk.wait()                    # (a stream-level wait: the side stream waits for the collective)
+                    hooks["dw_done"] = True
+                g = meta.plan.unpack_grads(dw_flat, ctx.params)
+            done = side.record_event()
+            held += [dw_flat, ctx.packs]
+            params, needs = ctx.params, ctx.needs_input_grad[4:]
+
+            def assign_grads():
+                with torch.cuda.device(dev):
+                    torch.cuda.current_stream().wait_event(done)
+                for p, gi, need in zip(params, g, needs):
+                    if need:
+                        p.grad = gi if p.grad is None else p.grad + gi
+                held.clear()     # operands of the side-stream kernels: free for reuse on the main stream from here on
+
+            torch.autograd.Variable._execution_engine.queue_callback(assign_grads)
+            if pbar is not None and hooks.get("dw"):
+                works.append(hooks["dw"](pbar))
+        elif hooks and meta.need_wgrad and hooks.get("dw"):
+            works.append(hooks["dw"](dw_flat))
+            if pbar is not None:                      # adjoint of the learnable swish beta: same treatment
+                works.append(hooks["dw"](pbar))
+            hooks["dw_done"] = True
+        for wk in works:
+            if wk is not None:
+                wk.wait()
+        if meta.need_wgrad and not deferred:
             g = meta.plan.unpack_grads(dw_flat, ctx.params)
             grads = [gi if need else None for gi, need in zip(g, ctx.needs_input_grad[4:])]
         dprm = pbar.sum().reshape(ctx.prm_shape) if pbar is not None else None
@@ -1013,6 +1094,7 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.need_wgrad = True
     meta.recompute = force_recompute
     meta.budget = memory_budget if memory_budget is not None else globals()["memory_budget"]
+    meta.tail = int(tail_chunk) // 2 * 2
     meta.cfg_val = make_cfg(act, prm, False, [])[0]
     P = B * N
     if P == 0:   # empty query set: nothing to launch (the reference returns an empty [b, 0, o] tensor as well)

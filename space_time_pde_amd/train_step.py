@@ -124,7 +124,16 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)
     pde_layer.update_forward_method(lambda pts: query_local_implicit_grid(imnet, latent_grid, pts, xmin, xmax))
-    pred, residues = pde_layer(point_coord, return_residue=True)    # train.py:66-67
+    # U-Net backward BESIDE the IM-NET weight gradients (lig_jet.sync_hooks["defer_wgrad"]): the last launch chunk of the
+    # query -- ``tail_chunk`` points -- runs its input-gradient chain first and its weight gradients on a side stream
+    overlap_unet = latent_grid.is_cuda and os.environ.get("STPDE_OVERLAP_UNET_BWD", "1") != "0"
+    prev_tail = lig_jet.tail_chunk
+    if overlap_unet:
+        lig_jet.tail_chunk = int(os.environ.get("STPDE_TAIL_CHUNK", 1 << 17))
+    try:
+        pred, residues = pde_layer(point_coord, return_residue=True)    # train.py:66-67
+    finally:
+        lig_jet.tail_chunk = prev_tail
     b = point_coord.shape[0]
     reg = loss_sum(pred, point_value, loss_type) / (b * n_points_global * pred.shape[-1])
     res = list(residues.values())
@@ -133,11 +142,14 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
     stack = base if (base is not None and base.numel() == sum(r.numel() for r in res)) else torch.stack(res, dim=0)
     pde = loss_sum(stack, None, loss_type) / (len(res) * b * n_points_global)
     loss = alpha_reg * reg + alpha_pde * pde
-    hooks = None
+    hooks = {}
     if distributed and os.environ.get("STPDE_OVERLAP_SYNC", "1") != "0":
         # collectives issued from inside the HIP backward: d latent asynchronously behind the IM-NET weight gradients, the
         # IM-NET gradients in place in their flat buffer (no cat / copy-back); both are waited for before backward returns
-        hooks = dict(dlatent=lambda t: dist.all_reduce(t, async_op=True), dw=lambda t: dist.all_reduce(t, async_op=True))
+        hooks.update(dlatent=lambda t: dist.all_reduce(t, async_op=True), dw=lambda t: dist.all_reduce(t, async_op=True))
+    if overlap_unet:
+        hooks["defer_wgrad"] = True
+    hooks = hooks or None
     lig_jet.sync_hooks = hooks
     try:
         loss.backward()

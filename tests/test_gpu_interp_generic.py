@@ -145,10 +145,12 @@ def test_large_size_properties(hiplib):
     assert torch.isfinite(a).all()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "bf16"])
-def test_full_size_step_subset_vs_oracle_and_additivity(hiplib, prec, monkeypatch):
+@pytest.mark.parametrize("prec,grid", [("fp32", (32, 128, 128)), ("fp32x3", (32, 128, 128)), ("bf16", (32, 128, 128)),
+                                       ("bf16", (64, 256, 256))])
+def test_full_size_step_subset_vs_oracle_and_additivity(hiplib, prec, grid, monkeypatch):
     """(parametrised over the three MFMA operand modes, VERDICT r2 #3b: fp32x3 with the fp32 tolerances, bf16 with the
-    mode's 3e-2 Frobenius bound.)  BASELINE configs[1] size (latent [1,32,128,128,32], 2^20 points, RB2 + continuity, softplus):
+    mode's 3e-2 Frobenius bound; VERDICT r3 #1b: the bf16 mode also on BASELINE configs[3]'s OWN latent grid
+    [1,64,256,256,32] = 512 MiB.)  BASELINE configs[1] / [3] size (2^20 points, RB2 + continuity, softplus):
     (a) points are independent, so pred / residuals of a random subset must equal the CPU oracle run on just that subset;
     (b) gradients are additive over points: grads(all points) == grads(first half) + grads(second half)."""
     from oracle import cpu_ref
@@ -156,7 +158,7 @@ def test_full_size_step_subset_vs_oracle_and_additivity(hiplib, prec, monkeypatc
     monkeypatch.setattr(lig_jet, "mlp_precision", prec)
     g = torch.Generator().manual_seed(0)
     N = 1 << 20
-    lat0 = (0.5 * torch.randn(1, 32, 128, 128, 32, generator=g))
+    lat0 = (0.5 * torch.randn(1, *grid, 32, generator=g))
     pts = torch.rand(1, N, 3, generator=g)
     torch.manual_seed(0)
     net = implicit_net.ImNet(nf=32, activation=torch.nn.Softplus).to(DEV)
@@ -198,6 +200,74 @@ def test_full_size_step_subset_vs_oracle_and_additivity(hiplib, prec, monkeypatc
         err = (res[k][:, sel].cpu() - v).abs() / v.abs().max()
         assert err.median().item() < 1e-5 and err.max().item() < 1e-3, (k, err.max().item())
     # (b) additivity of the gradients over the two halves
+    _, _, gl1, gp1 = run(slice(0, N // 2))
+    _, _, gl2, gp2 = run(slice(N // 2, N))
+    assert (gl - (gl1 + gl2)).abs().max().item() < 1e-4 * gl.abs().max().item()
+    for a, b, c in zip(gp, gp1, gp2):
+        assert (a - (b + c)).abs().max().item() < 2e-4 * a.abs().max().item()
+
+
+def test_config5_full_size_properties(hiplib):
+    """VERDICT r3 #1c -- BASELINE configs[4] at ITS size: the 5-output user-string equation set (bench.py C5_EQS = the strings
+    of fixture G9: products, a mixed second derivative, explicit coordinates -> stream set (3,6), S = 10) on 2^20 points over
+    the [1,32,128,128,32] grid, ImNet nf = 32, through whichever of stash / recomputation the memory plan picks:
+    (a) a random subset of the points equals the oracle's reverse-sweep autograd on just that subset;
+    (b) chunk invariance: one 2^20-point launch chunk and 2^18-point chunks give bit-identical jets;
+    (c) gradients are additive over the points: grads(all) == grads(first half) + grads(second half)."""
+    import bench
+    from oracle import cpu_ref as O
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, local_implicit_grid as lig, pde
+    g = torch.Generator().manual_seed(5)
+    N = 1 << 20
+    lat0 = 0.5 * torch.randn(1, 32, 128, 128, 32, generator=g)
+    pts = torch.rand(1, N, 3, generator=g)
+    torch.manual_seed(5)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=5, nf=32, activation=torch.nn.Softplus).to(DEV)
+    layer = bench.c5_layer(pde)
+    latd, ptsd = lat0.to(DEV), pts.to(DEV)
+    cot = torch.randn(1, N, 5, generator=g).to(DEV)
+
+    def run(sl, trace=False):
+        lat = latd.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        layer.update_forward_method(lambda q: lig.query_local_implicit_grid(net, lat, q, 0., 1.))
+        n0 = lig.stats["hip_jet_calls"]
+        pred, res = layer(ptsd[:, sl].contiguous())
+        assert lig.stats["hip_jet_calls"] == n0 + 1
+        loss = (pred * cot[:, sl]).sum() / N + 0.0125 * torch.stack(list(res.values()), 0).abs().sum() / N
+        loss.backward()
+        torch.cuda.synchronize()
+        return pred.detach(), {k: v.detach() for k, v in res.items()}, lat.grad, [p.grad.clone() for p in net.parameters()]
+
+    r0 = lig_jet.stats["recompute_steps"]
+    with _lib.dispatch_trace() as tr:
+        pred, res, gl, gp = run(slice(0, N))
+    assert tr.has("S1 = 3, S2 = 6") and tr.has("k_residual_bwd"), "\n".join(sorted(set(tr.kernels)))
+    print("config5 full size: recompute path taken =", lig_jet.stats["recompute_steps"] > r0)
+    assert all(torch.isfinite(v).all() for v in [pred, gl] + gp + list(res.values()))
+    # (a) subset vs the oracle (reference formulation: one reverse sweep per dif, fp32 like the reference)
+    sel = torch.randperm(N, generator=g)[:512]
+    params = [(net.fc[k].weight.detach().cpu(), net.fc[k].bias.detach().cpu()) for k in range(6)]
+    orc = O.PDEOracle(*bench.C5_VARS)
+    for name, eq in bench.C5_EQS.items():
+        orc.add_equation(eq, name)
+    act = O.activation_fn("softplus")
+    orc.forward_method = lambda q: O.query_lig(lambda x: O.imnet_forward(params, x, act), lat0, q, 0., 1.)
+    y_ref, r_ref = orc(pts[:, sel].clone())
+    assert (pred[:, sel].cpu() - y_ref.detach()).abs().max().item() < 2e-5 * y_ref.abs().max().item()
+    for k, v in r_ref.items():
+        # second derivatives carry 1/cubesize^2 = 127^2 (the fp32 reference itself: max-rel ~2e-4 per point, SURVEY a-Q8)
+        err = (res[k][:, sel].cpu() - v.detach()).abs() / v.detach().abs().max()
+        assert err.median().item() < 1e-5 and err.max().item() < 1e-3, (k, err.max().item())
+    # (b) chunk invariance of the forward (all ten streams)
+    pairs = ((0, 0), (0, 1), (1, 1), (2, 2))
+    with torch.no_grad():
+        a, _ = lig_jet.lig_jets(net, latd, ptsd, 0., 1., True, pairs, chunk_points=1 << 20)
+        b, _ = lig_jet.lig_jets(net, latd, ptsd, 0., 1., True, pairs, chunk_points=1 << 18)
+    assert a.shape[0] == 10 and torch.equal(a, b)
+    del a, b
+    # (c) additivity over the two halves of the points
     _, _, gl1, gp1 = run(slice(0, N // 2))
     _, _, gl2, gp2 = run(slice(N // 2, N))
     assert (gl - (gl1 + gl2)).abs().max().item() < 1e-4 * gl.abs().max().item()
