@@ -840,7 +840,20 @@ class LigJetFunction(torch.autograd.Function):
         # would not fit the free device memory (or an allocation fails half way), the forward keeps NO stash and the
         # backward re-runs the forward kernels chunk by chunk right before each chunk's backward (the same kernels on the
         # same inputs rebuild the same stash bit for bit): +1 forward of compute, memory bounded by one chunk.
-        recompute = need_grad and (meta.recompute or _stash_bytes(meta, P) > 0.85 * _avail_bytes(meta, pts.device))
+        limit = 0.85 * _avail_bytes(meta, pts.device)
+        if need_grad and not meta.recompute and _stash_bytes(meta, P) > limit:
+            # the stash of all chunks is what it is, the backward scratch is per launch chunk: smaller chunks (down to 2^16
+            # points: below that the launches get short) before giving up the stash (configs[4], S = 10 at 2^20 points: 187 GB
+            # of stash + 69 GB of scratch per 2^20-point chunk, 17 GB per 2^18-point chunk)
+            c = chunk
+            while c > (1 << 16) and _stash_bytes(meta, P) > limit:
+                c //= 2
+                meta.chunk = c
+            if _stash_bytes(meta, P) <= limit:
+                chunk = c
+            else:
+                meta.chunk = chunk
+        recompute = need_grad and (meta.recompute or _stash_bytes(meta, P) > limit)
         if recompute:
             chunk = meta.chunk = min(chunk, _recompute_chunk(meta, pts.device))
         saved = []

@@ -125,8 +125,14 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)
     pde_layer.update_forward_method(lambda pts: query_local_implicit_grid(imnet, latent_grid, pts, xmin, xmax))
     # U-Net backward BESIDE the IM-NET weight gradients (lig_jet.sync_hooks["defer_wgrad"]): the last launch chunk of the
-    # query -- ``tail_chunk`` points -- runs its input-gradient chain first and its weight gradients on a side stream
-    overlap_unet = latent_grid.is_cuda and os.environ.get("STPDE_OVERLAP_UNET_BWD", "1") != "0"
+    # query -- ``tail_chunk`` points -- runs its input-gradient chain first and its weight gradients on a side stream.
+    # OFF by default (STPDE_OVERLAP_UNET_BWD=1 turns it on): measured on MI355X (round 4, profiles/r4_overlap_timeline.txt) the
+    # two streams do run side by side, but the first / second hidden layer's weight-gradient kernels hold every VGPR of every
+    # CU (254 registers x 8 waves, 147 KB of LDS), so a U-Net kernel dispatched beside them waits for a whole workgroup to
+    # retire (a 15 us convolution took 6.1 ms) and the chain of ~350 short launches advances by three kernels per heavy
+    # kernel: 63.1 -> 63.7 ms per step at 2^17 points, 422.2 -> 424.7 ms at 2^20 (the dgrad-first order and the extra
+    # launch chunk cost more than the overlap of the light kernels gains).
+    overlap_unet = latent_grid.is_cuda and os.environ.get("STPDE_OVERLAP_UNET_BWD", "0") == "1"
     prev_tail = lig_jet.tail_chunk
     if overlap_unet:
         lig_jet.tail_chunk = int(os.environ.get("STPDE_TAIL_CHUNK", 1 << 17))

@@ -157,7 +157,7 @@ def test_bench_self_spawns_two_ranks(hiplib):
     assert rec["value"] > 0 and rec["config"]["parallelism"] == "points sharded x2"
 
 
-def _nccl_world1_worker(rank, port, out):
+def _nccl_world1_worker(rank, port, out, fixed_latent=False):
     """One rank, backend "nccl" (= RCCL): the point-sharded step with its collectives forced on, three ways."""
     import os
     import torch.distributed as dist
@@ -170,8 +170,25 @@ def _nccl_world1_worker(rank, port, out):
     from space_time_pde_amd import lig_jet
     from space_time_pde_amd.train_step import sharded_step
     unet, net, layer, crop, pts, tgt = _rccl_build(dev)
+    if fixed_latent:
+        # the U-Net's deep levels accumulate with fp32 atomics (run-to-run rounding differences of the latent grid): a fixed
+        # latent grid in the U-Net's channels-last output layout makes every quantity of the step bit-reproducible
+        class _Fixed(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                g = torch.Generator().manual_seed(3)
+                self.lat = torch.nn.Parameter(0.5 * torch.randn(1, 4, 16, 16, 32, generator=g))
+
+            def forward(self, x):
+                return (self.lat * 1.0).permute(0, 4, 1, 2, 3)
+
+        unet = _Fixed().to(dev)
     seen = {}
-    unet.register_forward_hook(lambda m, i, o: o.register_hook(lambda g: seen.__setitem__("dlat", g.detach().clone())))
+
+    def grab(m, i, o):           # (a forward hook that returns something replaces the module output: return None)
+        o.register_hook(lambda g: seen.__setitem__("dlat", g.detach().clone()))
+
+    unet.register_forward_hook(grab)
     res = {}
     for name, dist_flag, overlap in (("plain", False, "1"), ("hooks", True, "1"), ("blocking", True, "0")):
         os.environ["STPDE_OVERLAP_SYNC"] = overlap
@@ -205,13 +222,17 @@ def _nccl_world1_worker(rank, port, out):
 
 
 @pytest.mark.gpu
-def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_path):
+@pytest.mark.parametrize("fixed_latent", [True, False])
+def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_path, fixed_latent):
     """VERDICT r3 #1a: a process group with backend "nccl" (RCCL) on the 1-GPU box, world size 1, carrying the collectives of
     ``sharded_step(distributed=True)``: RCCL initialisation, ``all_reduce(async_op=True)`` of d latent issued from inside the
     HIP backward between its two phases, the in-place all-reduce of the flat IM-NET gradient, the ``dlatent_done`` /
     ``dw_done`` handshake with ``_SumGradAcrossRanks`` (train_step.py), the loss-statistics all-reduce.  With one rank a sum
     over ranks is the identity, so the result must equal the collective-free step: losses and d latent (deterministic
-    per-node gather) bit for bit, weight gradients to fp32-atomic summation order.  Reference: train_ddp.py:48, 401-406."""
+    per-node gather) bit for bit, weight gradients to fp32-atomic summation order.  Reference: train_ddp.py:48, 401-406.
+    fixed_latent: the encoder replaced by a fixed latent grid -- the bit-for-bit case (the real U-Net's deep levels
+    accumulate with fp32 atomics, so with it the latent grid itself differs run to run in the last bits and the comparison
+    is to rounding)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -219,7 +240,7 @@ def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_pat
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "nccl_w1.pt")
-    mp.spawn(_nccl_world1_worker, args=(port, out), nprocs=1, join=True)
+    mp.spawn(_nccl_world1_worker, args=(port, out, fixed_latent), nprocs=1, join=True)
     r = torch.load(out)
     assert r["backend"] == "nccl" and r["world"] == 1
     plain, hooks, blocking = r["plain"], r["hooks"], r["blocking"]
@@ -235,9 +256,14 @@ def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_pat
     bc = blocking["collectives"]
     assert bc[0] == (n_lat, False, True) and bc[1] == (sum(g.numel() for g in plain["g_im"]), False, True) and len(bc) == 3, bc
     for other in (hooks, blocking):
-        for k in ("loss", "reg", "pde"):
-            assert torch.equal(other[k], plain[k]), k
-        assert torch.equal(other["dlat"], plain["dlat"])
+        if fixed_latent:
+            for k in ("loss", "reg", "pde"):
+                assert torch.equal(other[k], plain[k]), k
+            assert torch.equal(other["dlat"], plain["dlat"])
+        else:
+            for k in ("loss", "reg", "pde"):
+                assert abs(float(other[k]) - float(plain[k])) <= 1e-6 * abs(float(plain[k])), k
+            assert (other["dlat"] - plain["dlat"]).abs().max().item() <= 1e-4 * plain["dlat"].abs().max().item()
         for a, b in zip(other["g_im"], plain["g_im"]):
             assert (a - b).abs().max().item() <= 5e-6 * b.abs().max().item() + 1e-12
         for a, b in zip(other["g_un"], plain["g_un"]):
