@@ -551,8 +551,9 @@ def main(argv=None):
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": ("bf16 MFMA operands (wide IM-NET layers) / f32 accumulate, stash, epilogues, UNet" if bf16 else
-                      "f32 (GEMMs of the wide IM-NET layers -- forward, input gradient, weight gradient: fp32 operands split 3-way "
-                      "onto the bf16 MFMA pipe, 6 products, fp32-accurate; everything else exact fp32)"
+                      "f32 via 3xbf16 split, f32 accumulate (hidden-to-hidden GEMMs of the two wide IM-NET layers -- forward, input "
+                      "gradient, weight gradient: every fp32 operand split exactly into three bf16 terms, six partial products on "
+                      "the bf16 MFMA pipe; everything else exact f32)"
                       if args.mlp_precision == "fp32x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4]: latent [1,%d,%d,%d,32], 2^%d query points, 5-output user-string "

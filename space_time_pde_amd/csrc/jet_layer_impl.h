@@ -35,6 +35,9 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #ifndef STPDE_EARLY_L0
 #define STPDE_EARLY_L0 1
 #endif
+#ifndef STPDE_EPI_PF
+#define STPDE_EPI_PF 1
+#endif
 #if STPDE_STAMP
 #define STPDE_STAMP_B0 8192
 static __device__ unsigned long long g_stamp[256 * 8 * 16];
@@ -96,7 +99,7 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 template <int S1, int S2, int EPI, int ACT, int PKM = 0>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
                                                const f32x4 (*xbv)[XT], const float* cq, float& pacc,
-                                               const f32x4* z0pre = nullptr) {
+                                               const f32x4* z0pre = nullptr, const f32x4* prepf = nullptr) {
   constexpr int S = 1 + S1 + S2;
   constexpr bool VT = S1 == 0 && S2 > 0;     // value-tile mode: every stream is the value stream of its own row tile
   const int lo = lane * 4;
@@ -121,7 +124,8 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
       f32x4 pre[S], ab[S];
       if (EPI == EPI_ADJ) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Pre, (PKM & 4) ? 1 : 0, tile, S, MT, st, mt, lane);
+        for (int st = 0; st < S; ++st)
+          pre[st] = prepf ? prepf[st] : ld_blk(a.Pre, (PKM & 4) ? 1 : 0, tile, S, MT, st, mt, lane);
       } else {
         pre[0] = z0pre ? *z0pre : ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {
@@ -563,10 +567,31 @@ __global__ __launch_bounds__(64 * NW, (!BF && PRO == PRO_ACT && EPI == EPI_FWD &
       if (sum[0] == 12345.678f) st4(a.Out + lo, sum);
       continue;
     }
+    // exact-fp32 input-gradient kernels of the hidden layers (round 4): the stashed pre-activation blocks of output tile
+    // mi + 1 are requested before the adjoint of tile mi is computed (they were loaded tile by tile right in front of their
+    // use: MCg exposed HBM round trips per pass with one co-resident workgroup to cover them).  STPDE_EPI_PF=0: as before.
+    constexpr bool EPF = EPI == EPI_ADJ && !BF && MCg > 1 && STPDE_EPI_PF;
+    if constexpr (EPF) {
+      f32x4 prc[S], prn[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) prc[st] = ld_blk(a.Pre, 0, tile, S, MT, st, mt0, lane);
+#pragma unroll
+      for (int mi = 0; mi < MCg; ++mi) {
+        if (mi + 1 < MCg) {
+#pragma unroll
+          for (int st = 0; st < S; ++st) prn[st] = ld_blk(a.Pre, 0, tile, S, MT, st, mt0 + mi + 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, nullptr, prc);
+#pragma unroll
+        for (int st = 0; st < S; ++st) prc[st] = prn[st];
+      }
+    } else {
 #pragma unroll
     for (int mi = 0; mi < MCg; ++mi)
       layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc,
                                               Z0P ? &z0p[mi] : nullptr);
+    }
     STAMP(13);
   }
   flush_pbar<EPI, ACT>(a, pacc, lane);
@@ -584,6 +609,13 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     if (a.Wp16 && a.nsplit == 1 && spec_env && a.MT == 16 && (a.KT == 32 || a.KT == 16))
       return launch_fc1_fwd_spec<S1, S2, ACT>(a, stream);
   }
+  // ... and its input gradient with packed buffers and the tangent row sums (round 4): k_fc1_dgrad_spec; STPDE_BF_SPEC_DGRAD=0
+  // keeps the cooperative kernel
+  if constexpr (PRO == PRO_NONE && EPI == EPI_ADJ_L0 && NW == 4 && MCg == 4 && S1 == 3 && S2 <= 1) {
+    static const int dspec_env = getenv("STPDE_BF_SPEC_DGRAD") ? atoi(getenv("STPDE_BF_SPEC_DGRAD")) : 1;
+    if (a.Wp16 && a.nsplit == 1 && dspec_env && a.pk == 3 && a.MT == 32 && a.KT == 16 && a.Tan0 && a.Z0)
+      return launch_fc1_dgrad_spec<S1, S2, ACT>(a, stream);
+  }
   const int npass = a.MT / (NW * MCg);
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
   a.split = (PRO != PRO_L0 && npass > 1) ? npass : 0;
@@ -592,13 +624,12 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     stpde_set_error("packed layer buffers are a bf16-operand mode (stpde_layer_desc.mfma_bf16 == 1)");
     return STPDE_E_UNSUPPORTED;
   }
+  // "fp32x3" is a contract on accuracy (fp32), not on the pipe: the split kernels are compiled for the wide-layer shapes of the
+  // training stream sets; every other stream set / workgroup shape takes the exact-fp32 kernels (round 4; used to be refused)
+  if (a.Wp16 && a.nsplit == 3 && !(S1 + S2 <= 4 && NW == 4)) a.Wp16 = nullptr;
   if (a.Wp16 && a.nsplit == 3) {
-    if constexpr (S1 + S2 <= 4 && NW == 4)     // split mode: compiled for the wide-layer shapes of the training stream sets
+    if constexpr (S1 + S2 <= 4 && NW == 4)
       STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, true, 1, false, 3>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
-    else {
-      stpde_set_error("bf16x3 split mode is not compiled for this stream set / workgroup shape");
-      return STPDE_E_UNSUPPORTED;
-    }
   } else if (a.Wp16) {
     // the packed-buffer mask this (PRO, EPI) kind may be launched with (stpde_layer_desc.packed, mapped by jet_layer.hip)
     // (bf16 mode packs the buffers of fc1's AND fc2's rows: fc1 forward writes one, fc2 forward reads one and writes one, ...)

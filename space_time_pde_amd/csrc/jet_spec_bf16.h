@@ -246,6 +246,218 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
   static_assert(NST <= 4 && NST >= 2 && NST % 2 == 0, "ring parity needs an even number of steps per tile");
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Input gradient of the first hidden layer, bf16 operands, packed buffers (round 4): the same idea the other way round.
+// In k_layer_coop<..., EPI_ADJ_L0, BF> every wave alternates between the bf16 MFMAs of its output tiles and their epilogue --
+// the activation-jet adjoint against the z0 stash, the VALU-heavy half of the kernel -- and the two never overlap inside a
+// wave: SQ counters of round 3 (profiles/r3_bf16_pmc_sq_counters.txt) 11.1 ms of VALU issue + 5.2 ms of MFMA for a 22.3 ms kernel.
+// Here the 8 waves of a persistent workgroup (one per CU) have fixed roles, one of each on every SIMD:
+//   waves 0-3 ("M")  the bf16 MFMAs.  The B operand of a row tile -- its S x 16 adjoint blocks, 40 KB at S = 5 -- is read from
+//                    an LDS copy into REGISTERS once per row tile (S x 8 bf16x8 fragments) and reused for the wave's 8 output
+//                    tiles; the weight fragments stream from L2 through a register ring 4 k-tile pairs deep that runs across
+//                    steps and row tiles.  One output tile (S accumulator blocks) per step goes to an LDS hand-off slot.
+//   waves 4-7 ("E")  the epilogue of the tile their partner M-wave finished in the PREVIOUS step: activation-jet adjoint
+//                    against the z0 block (requested one step ahead) and the tangent constants W0[:, d] (this wave's 8 tiles:
+//                    registers, loaded once), layer-0 adjoint value stream as bf16 blocks, tangent streams as DPP row sums;
+//                    and, 4 pieces per step, the copy of the NEXT row tile's adjoint blocks from HBM into the LDS staging
+//                    buffer (requested at the head of a step, written at its end).
+// One barrier per step (8 per row tile).  LDS: 40 KB staging + 4 x 2 x S KB hand-off.  Arithmetic: operand rounding, the
+// accumulation order over the k-tile pairs and the epilogue are those of k_layer_coop<..., BF = true, PKM = 3>.
+// ------------------------------------------------------------------------------------------------------------
+template <int S1, int S2, int ACT>
+__global__ __launch_bounds__(512, 2) void k_fc1_dgrad_spec(LayerArgs a) {
+  constexpr int S = 1 + S1 + S2, MT = 32, KT = 16, KP = KT / 2, NSTEP = MT / 4;
+  __shared__ __attribute__((aligned(16))) float bst[S * KP * 64 * 4];       // [st][kp][lane][2 x 4 bf16] = the MFMA B fragments
+  __shared__ __attribute__((aligned(16))) float ho[4][2][S][256];          // hand-off: accumulator blocks (fp32)
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const bool ewave = wv >= 4;
+  const int w = __builtin_amdgcn_readfirstlane(wv & 3);
+  const int lo = lane * 4;
+  const int G = gridDim.x;
+  const int ntl = a.ntiles > (int)blockIdx.x ? (a.ntiles - (int)blockIdx.x + G - 1) / G : 0;   // row tiles of this workgroup
+  constexpr unsigned TILE_IN = (unsigned)S * KT * 512u;         // packed ADJOINT tile of the layer's output rows (bytes)
+  constexpr int NPIECE = S * KT * 64 / 256;                     // 8-byte pieces of a tile per E-lane (20 at S = 5)
+
+  // E-waves: copy of row tile `tile`'s adjoint blocks into the staging buffer, pieces [p0, p1) of this lane.  Piece i of a
+  // tile = 8 bytes = lane (i & 63) of block (i >> 6) = (st, kt); staged at [st][kt >> 1][lane][kt & 1] so that an M-lane reads
+  // its bf16x8 B fragment of a k-tile pair with one ds_read_b128.
+  auto stage_load = [&](int tile, int p0, int p1, float2* v) {
+    const char* src = reinterpret_cast<const char*>(a.Bin) + (size_t)tile * TILE_IN;
+#pragma unroll
+    for (int p = p0; p < p1; ++p) v[p - p0] = *reinterpret_cast<const float2*>(src + ((size_t)(p * 256 + (wv - 4) * 64 + lane)) * 8);
+  };
+  auto stage_store = [&](int p0, int p1, const float2* v) {
+#pragma unroll
+    for (int p = p0; p < p1; ++p) {
+      const int i = p * 256 + (wv - 4) * 64 + lane, blk = i >> 6, ln = i & 63, st = blk / KT, kt = blk % KT;
+      *reinterpret_cast<float2*>(reinterpret_cast<char*>(bst) + ((size_t)((st * KP + (kt >> 1)) * 64 + ln)) * 16 + (kt & 1) * 8) = v[p - p0];
+    }
+  };
+
+  if (!ewave) {
+    // =========================================== M-waves ===========================================
+    bf16x8 B8[KP][S];
+    f32x4 acc[S];
+    bf16x8 wr[4];
+    const auto wrs = load_rsrc(a.Wp16, (unsigned)KP * MT * 1024u);
+    const int wlane = lane * 16;
+    // weight fragment n of this wave's stream: step n / KP, k-tile pair n % KP, output tile 4 * step + w
+    auto wload = [&](int n) -> bf16x8 {
+      const int step = (n / KP) % NSTEP, kp = n % KP;
+      return __builtin_bit_cast(bf16x8, buf_ld16(wrs, wlane + w * 1024, ((kp * MT + 4 * step) * 64) * 16));
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr[q] = wload(q);
+    __syncthreads();                     // the E-waves have staged the first row tile
+    for (int it = 0; it <= ntl; ++it) {
+      auto step = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+#pragma unroll
+        for (int st = 0; st < S; ++st) acc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+          const int n = s * KP + kp;               // compile-time after unrolling
+#pragma unroll
+          for (int st = 0; st < S; ++st) acc[st] = mfma_bf(wr[n & 3], B8[kp][st], acc[st]);
+          wr[n & 3] = wload(n + 4);                // ring: four pairs ahead (wraps into the next row tile: same weights)
+        }
+#pragma unroll
+        for (int st = 0; st < S; ++st) st4(&ho[w][s & 1][st][lo], acc[st]);
+      };
+      if (it < ntl) {
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+          for (int st = 0; st < S; ++st)
+            B8[kp][st] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(bst) + ((size_t)((st * KP + kp) * 64 + lane)) * 16);
+        step(std::integral_constant<int, 0>{});
+      }
+      __syncthreads();
+      if (it == ntl) break;
+      step(std::integral_constant<int, 1>{});
+      __syncthreads();
+      step(std::integral_constant<int, 2>{});
+      __syncthreads();
+      step(std::integral_constant<int, 3>{});
+      __syncthreads();
+      step(std::integral_constant<int, 4>{});
+      __syncthreads();
+      step(std::integral_constant<int, 5>{});
+      __syncthreads();
+      step(std::integral_constant<int, 6>{});
+      __syncthreads();
+      step(std::integral_constant<int, 7>{});
+      __syncthreads();
+    }
+  } else {
+    // =========================================== E-waves ===========================================
+    f32x4 tc[S1 == 3 ? NSTEP : 1][3];
+    if (S1 == 3) {
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) tc[s][d] = ld4(a.tanc0 + ((size_t)d * MT + 4 * s + w) * 256 + lo);
+    }
+    float cq[6], cqn[6];
+    float pacc = 0.f;
+    f32x4 z0n;
+    // prologue: the whole first tile into the staging buffer, its first z0 block and combination weights requested
+    if (ntl > 0) {
+      float2 v[NPIECE];
+      stage_load(blockIdx.x, 0, NPIECE, v);
+      stage_store(0, NPIECE, v);
+      z0n = ld4(a.Z0 + ((size_t)blockIdx.x * MT + w) * 256 + lo);
+      load_cq<S2>(a.cw, blockIdx.x * 2 + ((lane & 15) >> 3), cqn);
+    }
+    __syncthreads();                     // (matches the M-waves' barrier in front of their loop)
+    // epilogue of output tile mt = 4 * s + w of row tile `tile` out of hand-off slot (s & 1); z0c = its z0 block
+    auto epi = [&](int tile, auto sc, f32x4 z0c) {
+      constexpr int s = decltype(sc)::value;
+      const int mt = 4 * s + w;
+      f32x4 hbar[S], pre[S], ab[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) hbar[st] = ld4(&ho[w][s & 1][st][lo]);
+      pre[0] = z0c;
+      if (S1 == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pre[1 + d] = tc[S1 == 3 ? s : 0][d];
+#pragma unroll
+        for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      act_jet_adj<S1, S2, ACT>(a.cfg, pre, hbar, ab, cq);
+      if (ACT == STPDE_ACT_SWISH && a.pbar) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, hbar, cq);
+      // layer-0 adjoint: value stream as a bf16 block (packed ADJOINT buffer with one stream), tangent streams as row sums
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.Out) + ((size_t)tile * MT + mt) * 512 + lane * 8) = to_bf4(ab[0]);
+      if (S1 == 3) {
+        f32x4 ts[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ts[d][r] = row_sum16(ab[1 + d][r]);
+        if ((lane & 15) == 15) {
+          float* tp = a.Tan0 + ((size_t)tile * MT + mt) * 48 + 4 * (lane >> 4);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) st4(tp + 16 * d, ts[d]);
+        }
+      }
+    };
+    for (int it = 0; it <= ntl; ++it) {
+      const int tile = (int)blockIdx.x + it * G;           // the M-waves' tile; step 0 here finishes tile - G
+      // step 0: last output tile of the previous row tile (its cq are still the current ones)
+      if (it >= 1) {
+        const f32x4 z0c = z0n;
+        if (it < ntl) z0n = ld4(a.Z0 + ((size_t)tile * MT + w) * 256 + lo);          // z0 of (tile, step 0), used in step 1
+        epi(tile - G, std::integral_constant<int, NSTEP - 1>{}, z0c);
+      }
+      if (it < ntl) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cq[i] = cqn[i];
+      }
+      __syncthreads();
+      if (it == ntl) break;
+      const bool more = it + 1 < ntl;
+      // steps 1 .. 7: epilogue of (tile, s - 1); steps 1 .. 5 also copy a fifth of the next row tile into the staging buffer
+      auto step = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int NP5 = (NPIECE + 4) / 5;
+        constexpr int p0 = (s - 1) * NP5, p1 = (p0 + NP5 < NPIECE ? p0 + NP5 : NPIECE);
+        float2 v[NP5];
+        const bool stg = s <= 5 && more && p0 < NPIECE;
+        if (stg) stage_load(tile + G, p0, p1, v);
+        const f32x4 z0c = z0n;
+        // z0 block of output tile 4 s + w, used in the next step (step 7's: at step 0 of the next iteration)
+        z0n = ld4(a.Z0 + ((size_t)tile * MT + 4 * s + w) * 256 + lo);
+        if (s == NSTEP - 1 && more) load_cq<S2>(a.cw, (tile + G) * 2 + ((lane & 15) >> 3), cqn);
+        epi(tile, std::integral_constant<int, s - 1>{}, z0c);
+        if (stg) stage_store(p0, p1, v);
+        __syncthreads();
+      };
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+    }
+    if (ACT == STPDE_ACT_SWISH && a.pbar) {
+      const float v = wave_sum(pacc);
+      if (lane == 0) atomicAdd(a.pbar + (blockIdx.x % STPDE_PBAR_SLOTS), v);
+    }
+  }
+}
+
+template <int S1, int S2, int ACT>
+static int launch_fc1_dgrad_spec(const LayerArgs& a, hipStream_t stream) {
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = ncu < a.ntiles ? ncu : a.ntiles;
+  STPDE_LAUNCH((k_fc1_dgrad_spec<S1, S2, ACT>), dim3(grid), dim3(512), 0, stream, a);
+  return stpde_check_launch("k_fc1_dgrad_spec");
+}
+
 template <int S1, int S2, int ACT>
 static int launch_fc1_fwd_spec(const LayerArgs& a, hipStream_t stream) {
   int dev = 0, ncu = 256;

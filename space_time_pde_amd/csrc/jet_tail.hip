@@ -8,6 +8,10 @@
 // stream sets; every other shape keeps the per-layer kernels (jet_layer_impl.h).
 #include "jet_layer_impl.h"
 
+// nothing may be scheduled across this point: keeps the operand requests of the NEXT stage above the MFMAs of the current one
+// (the machine scheduler of a fully unrolled one-wave-per-tile kernel otherwise sinks every load down to its first use)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 struct TailArgs {
   const float* in2;              // [tile][S][KT3][256] pre-activations of the layer in front (layer 2)
   const float* X;                // [tile][XT][256]
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
       for (int st = 0; st < S; ++st) rawn[st] = ld4(a.in2 + (((size_t)tile * S + st) * KT3 + kn) * 256 + lo);
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi) wn[mi] = ld4(a.Wh[0] + ((size_t)kn * MT3 + mi) * 256 + lo);
+      SCHED_FENCE();
       act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi)
@@ -88,6 +93,19 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MT3; ++mi) w[mi] = wn[mi];
     }
+  }
+  // weights of fc4 and fc5 (L2-resident, MT3 * MT4 + MT4 fragments): requested before fc3's epilogue (round 4; they were
+  // loaded right in front of their MFMAs, one exposed L2 round trip per k-tile with two waves per SIMD to cover it)
+  constexpr bool PFW = !VT && S <= 5;          // (S = 6: the prefetched fragments would cost the second wave per SIMD)
+  f32x4 w4[PFW ? MT3 : 1][PFW ? MT4 : 1], w5[PFW ? MT4 : 1];
+  if constexpr (PFW) {
+#pragma unroll
+    for (int kt = 0; kt < MT3; ++kt)
+#pragma unroll
+      for (int mi = 0; mi < MT4; ++mi) w4[kt][mi] = ld4(a.Wh[1] + ((size_t)kt * MT4 + mi) * 256 + lo);
+#pragma unroll
+    for (int kt = 0; kt < MT4; ++kt) w5[kt] = ld4(a.Wh[2] + ((size_t)kt * MT5) * 256 + lo);
+    SCHED_FENCE();
   }
 #pragma unroll
   for (int mi = 0; mi < MT3; ++mi) finish(0, MT3, mi, acc3[mi]);
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
     act_jet_fwd<S1, S2, ACT>(a.cfg, acc3[kt], B, cq);
 #pragma unroll
     for (int mi = 0; mi < MT4; ++mi) {
-      const f32x4 w = ld4(a.Wh[1] + ((size_t)kt * MT4 + mi) * 256 + lo);
+      const f32x4 w = PFW ? w4[PFW ? kt : 0][PFW ? mi : 0] : ld4(a.Wh[1] + ((size_t)kt * MT4 + mi) * 256 + lo);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
   for (int kt = 0; kt < MT4; ++kt) {
     f32x4 B[S];
     act_jet_fwd<S1, S2, ACT>(a.cfg, acc4[kt], B, cq);
-    const f32x4 w = ld4(a.Wh[2] + ((size_t)kt * MT5) * 256 + lo);
+    const f32x4 w = PFW ? w5[PFW ? kt : 0] : ld4(a.Wh[2] + ((size_t)kt * MT5) * 256 + lo);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -385,8 +403,12 @@ struct TailBwdArgs {
   stpde_jet_cfg cfg;
 };
 
+// Round 4: every stash block and weight fragment is REQUESTED one stage ahead of its use.  The first version loaded the five
+// stash blocks of an output tile right in front of their activation-jet adjoint and every weight fragment right in front of
+// its MFMAs (compiler listing: ~30 `global_load ; s_waitcnt vmcnt(0..1)` pairs per row tile), with two waves per SIMD (252
+// registers) to cover HBM / L2 round trips of 1-2 us each: 0.45 of the fp32 pipe.
 template <int S1, int S2, int ACT, int NFT>
-__global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_tail_bwd(TailBwdArgs a) {
   constexpr int S = 1 + S1 + S2;
   constexpr int T2 = 4 * NFT, T3 = 2 * NFT, T4 = NFT;     // feature tiles of the outputs of layers 2, 3, 4
   const int lane = threadIdx.x & 63;
@@ -398,13 +420,14 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
   float pacc = 0.f;
   const bool swish = (ACT == STPDE_ACT_SWISH) && a.pbar;
 
-  // hbar (accumulator tile) + stored pre-activations -> adjoint, written over the pre-activations and returned in acc
-  auto adjoint = [&](int l, int MT, int mt, f32x4* acc) {
-    const float* buf_in = a.pre[l];
-    float* buf = a.out[l];
-    f32x4 pre[S], ab[S];
+  auto ldpre = [&](int l, int MT, int mt, f32x4* pre) {
 #pragma unroll
-    for (int st = 0; st < S; ++st) pre[st] = ld4(buf_in + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+    for (int st = 0; st < S; ++st) pre[st] = ld4(a.pre[l] + (((size_t)tile * S + st) * MT + mt) * 256 + lo);
+  };
+  // hbar (accumulator tile) + stored pre-activations (already in registers) -> adjoint, written to out[l] and returned in acc
+  auto adjoint = [&](int l, int MT, int mt, const f32x4* pre, f32x4* acc) {
+    float* buf = a.out[l];
+    f32x4 ab[S];
     act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc, ab, cq);
     if (swish) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc, cq);
 #pragma unroll
@@ -414,22 +437,42 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
     }
   };
 
-  // ---- through fc5: abar_5 [1 tile] -> hbar_4 [T4 tiles] -> abar_4
-  f32x4 b5[S];
+  // ---- head: everything the fc5 stage needs, and the fc4 stage's weights + its first stash blocks
+  f32x4 b5[S], p4[T4][S], w5[T4], w4[T4][T3];
+  constexpr int P3 = T3 < 2 ? T3 : 2;          // stash blocks of fc3's output rows: a ring of two output tiles
+  f32x4 p3[P3][S];
 #pragma unroll
   for (int st = 0; st < S; ++st) b5[st] = ld4(a.abar5 + ((size_t)tile * S + st) * 256 + lo);
+#pragma unroll
+  for (int mi = 0; mi < T4; ++mi) {
+    w5[mi] = ld4(a.WhT[2] + ((size_t)mi) * 256 + lo);                  // [MT5 = 1][KT = T4]: block (0, mi)
+    ldpre(2, T4, mi, p4[mi]);
+  }
+#pragma unroll
+  for (int kt = 0; kt < T4; ++kt)
+#pragma unroll
+    for (int mi = 0; mi < T3; ++mi) w4[kt][mi] = ld4(a.WhT[1] + ((size_t)kt * T3 + mi) * 256 + lo);   // [MT4 = T4][KT = T3]
+#pragma unroll
+  for (int e = 0; e < P3; ++e) ldpre(1, T3, e, p3[e]);
+  SCHED_FENCE();      // (the machine scheduler otherwise sinks every request down to its first use)
+
+  // ---- through fc5: abar_5 [1 tile] -> hbar_4 [T4 tiles] -> abar_4
   f32x4 a4[T4][S];
 #pragma unroll
   for (int mi = 0; mi < T4; ++mi) {
-    const f32x4 w = ld4(a.WhT[2] + ((size_t)mi) * 256 + lo);          // [MT5 = 1][KT = T4]: block (0, mi)
 #pragma unroll
     for (int st = 0; st < S; ++st) a4[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int st = 0; st < S; ++st) a4[mi][st] = mfma4(w[r], b5[st][r], a4[mi][st]);
-    adjoint(2, T4, mi, a4[mi]);
+      for (int st = 0; st < S; ++st) a4[mi][st] = mfma4(w5[mi][r], b5[st][r], a4[mi][st]);
+    adjoint(2, T4, mi, p4[mi], a4[mi]);
   }
+  // first weight slab (k-tile 0, output tiles 0 / 1) of the fc3 stage: requested before the fc4 stage's MFMAs
+  f32x4 w3c[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) w3c[e] = ld4(a.WhT[0] + ((size_t)e) * 256 + lo);                          // [MT3 = T3][KT = T2]
+  SCHED_FENCE();
   // ---- through fc4: abar_4 -> hbar_3 [T3 tiles] -> abar_3
   f32x4 a3[T3][S];
 #pragma unroll
@@ -437,37 +480,47 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
 #pragma unroll
     for (int st = 0; st < S; ++st) a3[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < T4; ++kt) {
-      const f32x4 w = ld4(a.WhT[1] + ((size_t)kt * T3 + mi) * 256 + lo);   // [MT4 = T4][KT = T3]
+    for (int kt = 0; kt < T4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int st = 0; st < S; ++st) a3[mi][st] = mfma4(w[r], a4[kt][st][r], a3[mi][st]);
-    }
-    adjoint(1, T3, mi, a3[mi]);
+        for (int st = 0; st < S; ++st) a3[mi][st] = mfma4(w4[kt][mi][r], a4[kt][st][r], a3[mi][st]);
+    adjoint(1, T3, mi, p3[mi % P3], a3[mi]);
+    if (mi + P3 < T3) ldpre(1, T3, mi + P3, p3[mi % P3]);           // ring: the block two tiles ahead
+    SCHED_FENCE();
   }
-  // ---- through fc3: abar_3 -> hbar_2 [T2 tiles] -> abar_2, two output tiles at a time
+  // ---- through fc3: abar_3 -> hbar_2 [T2 tiles] -> abar_2, two output tiles at a time; the stash blocks of a pair are
+  // requested at the head of the pair's MFMAs (2 x T3 x 4 x S of them), the weight slabs one k-tile ahead
 #pragma unroll
   for (int m0 = 0; m0 < T2; m0 += 2) {
-    f32x4 a2[2][S];
+    f32x4 a2[2][S], p2[2][S];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) ldpre(0, T2, m0 + e, p2[e]);
+    SCHED_FENCE();
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int st = 0; st < S; ++st) a2[e][st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < T3; ++kt) {
-      f32x4 w[2];
+      // next slab: k-tile kt + 1 of this pair, or k-tile 0 of the next pair (the last one re-reads its own: harmless)
+      const int ktn = kt + 1 < T3 ? kt + 1 : 0;
+      const int mn = kt + 1 < T3 ? m0 : (m0 + 2 < T2 ? m0 + 2 : m0);
+      f32x4 w3n[2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) w[e] = ld4(a.WhT[0] + ((size_t)kt * T2 + m0 + e) * 256 + lo);   // [MT3 = T3][KT = T2]
+      for (int e = 0; e < 2; ++e) w3n[e] = ld4(a.WhT[0] + ((size_t)ktn * T2 + mn + e) * 256 + lo);
+      SCHED_FENCE();
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int st = 0; st < S; ++st) a2[e][st] = mfma4(w[e][r], a3[kt][st][r], a2[e][st]);
+          for (int st = 0; st < S; ++st) a2[e][st] = mfma4(w3c[e][r], a3[kt][st][r], a2[e][st]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) w3c[e] = w3n[e];
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) adjoint(0, T2, m0 + e, a2[e]);
+    for (int e = 0; e < 2; ++e) adjoint(0, T2, m0 + e, p2[e], a2[e]);
   }
   if (swish) {
     const float v = wave_sum(pacc);

@@ -884,7 +884,11 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   // into the hidden-group launch and the second launch is dropped (STPDE_WGRAD_XFOLD=0: two launches)
   static const int xfold_env = getenv("STPDE_WGRAD_XFOLD") ? atoi(getenv("STPDE_WGRAD_XFOLD")) : 1;
   const int kslots = 8 / KC;                 // k-slots per workgroup (NW / NM)
-  const bool xfold = xfold_env && (!a.bf16 || (a.bf16 == 1 && KC >= 4)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
+  // "fp32x3" (a.bf16 == 3) is a contract on ACCURACY (fp32), not on the pipe: stream sets / widths its split kernels are not
+  // compiled for take the exact-fp32 kernels (round 4; they used to be refused)
+  constexpr bool SPLIT_OK = KC >= 4 && S1 + S2 <= 4;
+  const int bfm = (a.bf16 == 3 && !SPLIT_OK) ? 0 : a.bf16;
+  const bool xfold = xfold_env && (!bfm || (bfm == 1 && KC >= 4)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
   for (int part = 0; part < 2; ++part) {
     a.kz0 = part == 0 ? 0 : nhid;
     a.gz = part == 0 ? nhid : ngr - nhid;
@@ -897,17 +901,14 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
     a.gx = gx;
     constexpr bool HAS_BF = KC >= 4;          // bf16 variant compiled for the wide layers only (MT >= 8)
     const dim3 grid(gx * a.gy * a.gz);
-    if (HAS_BF && a.bf16 == 3) {
-      if constexpr (HAS_BF && S1 + S2 <= 4) {
+    if (HAS_BF && bfm == 3) {
+      if constexpr (SPLIT_OK) {
         if (part == 0)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 3>), grid, dim3(512), 0, stream, a);
         else
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, true, true, 3>), grid, dim3(512), 0, stream, a);
-      } else {
-        stpde_set_error("bf16x3 split mode is not compiled for this stream set / layer width");
-        return STPDE_E_UNSUPPORTED;
       }
-    } else if (HAS_BF && a.bf16) {
+    } else if (HAS_BF && bfm) {
       if constexpr (HAS_BF) {
         constexpr int PKA = MODE == 1 ? 4 : 5;      // first hidden layer: packed abar; layer 2: packed input stash AND packed abar
         if (a.pk != 0 && a.pk != PKA) {

@@ -80,8 +80,12 @@ def test_cell_index_bit_exact_in_gather_kernel(hiplib, golden_dir, tag):
     assert torch.equal(got, want)
 
 
-def test_generic_equations_config5_style(hiplib, golden_dir):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_generic_equations_config5_style(hiplib, golden_dir, prec, monkeypatch):
     """G9: 5-channel user-string PDELayer (products, mixed 2nd derivative, explicit coordinates) on the HIP jet path."""
+    # VERDICT r3 #8(i): the same test, same tolerances, with the wide layers' products as exact-split bf16 MFMAs ("fp32x3")
+    from space_time_pde_amd import lig_jet as _lj
+    monkeypatch.setattr(_lj, "mlp_precision", prec)
     from space_time_pde_amd import implicit_net, local_implicit_grid as lig, pde
     d = _load(golden_dir, "g9_generic.npz")
     net = implicit_net.ImNet(dim=3, in_features=32, out_features=5, nf=16, activation=torch.nn.Softplus).to(DEV)

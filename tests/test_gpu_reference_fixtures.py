@@ -415,8 +415,12 @@ def test_benchmarked_instantiations_backward_vs_fp64_oracle(hiplib, act):
 
 
 @pytest.mark.parametrize("act", ["softplus", "leakyrelu"])
-def test_config0_c1_step_on_hip_matches_reference(hiplib, golden_dir, act):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_config0_c1_step_on_hip_matches_reference(hiplib, golden_dir, act, prec, monkeypatch):
     """BASELINE configs[0] (UNet3d(16,32,32) + 4096 points) through sharded_step on the HIP path vs the reference (G8)."""
+    # VERDICT r3 #8(i): the same test, same tolerances, with the wide layers' products as exact-split bf16 MFMAs ("fp32x3")
+    from space_time_pde_amd import lig_jet as _lj
+    monkeypatch.setattr(_lj, "mlp_precision", prec)
     from space_time_pde_amd import local_implicit_grid as lig, physics
     from space_time_pde_amd.train_step import sharded_step
     d = np.load(os.path.join(golden_dir, "g8_c1_step.npz"))
@@ -431,10 +435,14 @@ def test_config0_c1_step_on_hip_matches_reference(hiplib, golden_dir, act):
     F.check_c1_step(d, act, unet, net, loss, reg, pde, pred, res, latent, slack=3.0 if act == "softplus" else 8.0)
 
 
-def test_config4_user_equations_backward_vs_oracle(hiplib, golden_dir):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_config4_user_equations_backward_vs_oracle(hiplib, golden_dir, prec, monkeypatch):
     """BASELINE configs[4]: the 5-channel user-string equation set of G9 (products, a mixed second derivative, explicit
     coordinates -> the (3,6) stream set and k_residual_bwd): gradients of a random functional of prediction + residuals
     w.r.t. the latent grid and every IM-NET parameter vs the oracle's reverse-sweep autograd in fp64."""
+    # VERDICT r3 #8(i): the same test, same tolerances, with the wide layers' products as exact-split bf16 MFMAs ("fp32x3")
+    from space_time_pde_amd import lig_jet as _lj
+    monkeypatch.setattr(_lj, "mlp_precision", prec)
     from space_time_pde_amd import _lib, implicit_net, local_implicit_grid as lig, pde
     d = np.load(os.path.join(golden_dir, "g9_generic.npz"))
     net = implicit_net.ImNet(dim=3, in_features=32, out_features=5, nf=16, activation=torch.nn.Softplus).to(DEV)

@@ -256,13 +256,13 @@ def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_pat
     bc = blocking["collectives"]
     assert bc[0] == (n_lat, False, True) and bc[1] == (sum(g.numel() for g in plain["g_im"]), False, True) and len(bc) == 3, bc
     for other in (hooks, blocking):
+        # (the loss sums are block reductions merged with one fp32 atomic per block, csrc/lig_gather_reduce.hip k_loss_sum:
+        # equal to summation-order rounding; their GRADIENT is elementwise and exact)
+        for k in ("loss", "reg", "pde"):
+            assert abs(float(other[k]) - float(plain[k])) <= 1e-6 * abs(float(plain[k])), k
         if fixed_latent:
-            for k in ("loss", "reg", "pde"):
-                assert torch.equal(other[k], plain[k]), k
             assert torch.equal(other["dlat"], plain["dlat"])
         else:
-            for k in ("loss", "reg", "pde"):
-                assert abs(float(other[k]) - float(plain[k])) <= 1e-6 * abs(float(plain[k])), k
             assert (other["dlat"] - plain["dlat"]).abs().max().item() <= 1e-4 * plain["dlat"].abs().max().item()
         for a, b in zip(other["g_im"], plain["g_im"]):
             assert (a - b).abs().max().item() <= 5e-6 * b.abs().max().item() + 1e-12

@@ -202,11 +202,15 @@ def test_device_loader_hip(hiplib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("act", ["softplus", "leakyrelu"])
-def test_lattice_inference_matches_oracle_incl_tie_points(hiplib, act):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_lattice_inference_matches_oracle_incl_tie_points(hiplib, act, prec, monkeypatch):
     """N2 (evaluation.py:26-74, train.py:135-166): values and all RB2 residuals on a structured lattice whose end points
     are exactly the clip bounds ``linspace(eps, 1 - eps, n)`` (train.py:136-139: clip ties -> half derivatives, quirk
     a-Q2) against the CPU oracle (reverse-sweep restatement of the reference), and the value-only query on the same
     lattice through the value-tile kernels."""
+    # VERDICT r3 #8(i): the same test, same tolerances, with the wide layers' products as exact-split bf16 MFMAs ("fp32x3")
+    from space_time_pde_amd import lig_jet as _lj
+    monkeypatch.setattr(_lj, "mlp_precision", prec)
     from oracle import cpu_ref as O
     from space_time_pde_amd import _lib, lig_jet, nonlinearities
     dev = "cuda:0"
