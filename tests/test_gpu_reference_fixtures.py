@@ -123,7 +123,9 @@ def _assert_mode_kernels(tr, prec):
 def _assert_bf16_kernels(tr, cfg, dump):
     # first hidden layer forward: the wave-specialised persistent kernel (csrc/jet_spec_bf16.h)
     assert tr.has("k_fc1_fwd_spec", cfg), dump
-    for pro, epi in ((0, 2), (1, 0), (0, 1)):
+    # ... and its input gradient (round 4: k_fc1_dgrad_spec; the cooperative kernel with STPDE_BF_SPEC_DGRAD=0)
+    assert tr.has("k_fc1_dgrad_spec", cfg) or tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 2"), dump
+    for pro, epi in ((1, 0), (0, 1)):
         assert tr.has("k_layer_coop", "true", cfg, "PRO = %d" % pro, "EPI = %d" % epi), dump
     # bf16 weight gradients with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
     # (the packed-stash instantiations carry two more template arguments: ..., false, true, 1, PKA>)
