@@ -364,6 +364,53 @@ int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* 
 int stpde_conv3d_wgrad_bias(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias,
                             void* stream);
 
+/* ---- a10 (round 4): the convolutions of one ResBlock3D with its BatchNorm work folded in (src/unet3d.py:39-56:
+ * conv1-bn1-relu-conv2-bn2-relu-conv3-bn3 + shortcut, relu).  One call = one convolution of the chain plus what the
+ * BatchNorm next to it would otherwise do in passes of its own over the same tensor:
+ *   out_sums  the per-channel sums of y and y^2 the following BatchNorm needs, from the accumulator tiles (doubles,
+ *             [STPDE_BN_REP][2][Co], caller zero-fills; every wave sums around its own first voxel and converts in fp64)
+ *   in_sums   ksize 1: x is the RAW output of the previous convolution; its training-mode BatchNorm + ReLU are applied to
+ *             the operand as it is loaded: x' = max(0, (x - mean) * (rstd * gamma) + beta), mean / rstd from in_sums over
+ *             the N = B*T*Z*X voxels; the call writes in_stat = [mean; rstd] and updates the running statistics
+ *   y2        ksize 1: a second convolution of the same input (conv1 and the shortcut of a block: x is read once)
+ *   x2        ksize 1: a second input, y = W x + W2 x2 (the input gradient of a block = conv1's + the shortcut's)
+ *   m         input-gradient convolutions: y is the gradient of act = relu(bn(m)); the call stores dz = y * [act > 0] and adds
+ *             sum(dz), sum(dz * xhat) to m_bsum ([STPDE_BN_REP][2][Co] floats, zero-filled) -- the reduction pass of
+ *             stpde_bn_bwd.  Volumes small enough for the tap-split kernel cannot do this in their epilogue:
+ *             *epilogue_done = 0 then (y holds the unmasked gradient) and the caller runs the full stpde_bn_bwd.
+ * Unused features: NULL pointers / zero channel counts. */
+typedef struct {
+  stpde_conv3d_desc d;
+  const float* x;
+  const float* w_pack;
+  const float* bias;
+  float* y;
+  const float* x2;       /* [voxels][Ci2] */
+  const float* w2_pack;  /* [Ci2/16][Co/16][64][4] */
+  float* y2;             /* [voxels][Co2] */
+  const float* wo2_pack; /* [Ci/16][Co2/16][64][4] */
+  const float* bias2;
+  const double* in_sums;
+  const float* in_gamma; /* NULL = 1 */
+  const float* in_beta;  /* NULL = 0 */
+  float* in_running_mean; /* NULL: no running statistics */
+  float* in_running_var;
+  float* in_stat;        /* [2][Ci] */
+  double* out_sums;
+  const float* m;        /* [voxels][Co] */
+  const float* m_stat;   /* [2][Co]: mean, rstd of m */
+  const float* m_gamma;
+  const float* m_beta;
+  float* m_bsum;
+  int Ci2, Co2;
+  float in_eps, in_momentum;
+} stpde_conv3d_fused_args;
+int stpde_conv3d_fused(const stpde_conv3d_fused_args* a, int* epilogue_done, void* stream);
+/* Weight (+ bias) gradient of a 1x1x1 convolution whose input was x' = max(0, bn(x)) applied on load (in_stat = [mean; rstd]
+ * of x as written by stpde_conv3d_fused, in_gamma / in_beta nullable): the same transform on the operand here. */
+int stpde_conv3d_wgrad_onload(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias,
+                              const float* in_stat, const float* in_gamma, const float* in_beta, void* stream);
+
 /* ---- a10: BatchNorm3d (+ residual add) (+ ReLU) of the ResBlock3D chain (src/unet3d.py:39-56) -------------
  * Channels-last x [N][C], N = B*T*Z*X, C a power of two in [16, 512].
  * forward:  y = act(bn(x) [+ residual]);  training != 0: batch statistics (biased variance for the normalisation,
@@ -381,6 +428,11 @@ typedef struct {
   float eps, momentum;
   int scratch_zeroed;   /* != 0: the caller hands over zero-filled sums / bsum scratch (e.g. slices of one buffer cleared once
                            per step), so no memset is queued in front of the reduction kernels */
+  int stats_mode;       /* forward, training: 0 = sums is the float scratch above; 1 = sums is double [STPDE_BN_REP][2][C]
+                           (sum of x, sum of x^2; the format stpde_conv3d_fused writes) and this call fills it; 2 = the same
+                           format, already complete (no statistics pass) */
+  int reduce_done;      /* backward: bsum is already complete and dy already carries the ReLU mask (stpde_conv3d_fused, m):
+                           only the elementwise pass runs; pass relu = 0 */
 } stpde_bn_desc;
 int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float* residual, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float* sums, float* stat, float* y, void* stream);

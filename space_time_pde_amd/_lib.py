@@ -13,10 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 # STPDE_LIB: load another build of the library (A/B timing of kernel variants on one box; never set by tests or the driver)
 LIB_PATH = os.environ.get("STPDE_LIB") or os.path.join(_HERE, "libstpde_hip.so")
-_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
+_SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "conv3d_fused.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
-ABI_VERSION = 307   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 308   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
@@ -67,6 +67,16 @@ class Conv3dDesc(C.Structure):
                 ("ksize", C.c_int)]
 
 
+class Conv3dFusedArgs(C.Structure):     # stpde_conv3d_fused_args
+    _fields_ = [("d", Conv3dDesc), ("x", C.c_void_p), ("w_pack", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
+                ("x2", C.c_void_p), ("w2_pack", C.c_void_p), ("y2", C.c_void_p), ("wo2_pack", C.c_void_p),
+                ("bias2", C.c_void_p), ("in_sums", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p),
+                ("in_running_mean", C.c_void_p), ("in_running_var", C.c_void_p), ("in_stat", C.c_void_p),
+                ("out_sums", C.c_void_p), ("m", C.c_void_p), ("m_stat", C.c_void_p), ("m_gamma", C.c_void_p),
+                ("m_beta", C.c_void_p), ("m_bsum", C.c_void_p), ("Ci2", C.c_int), ("Co2", C.c_int),
+                ("in_eps", C.c_float), ("in_momentum", C.c_float)]
+
+
 class ResampleDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("Z", C.c_int), ("X", C.c_int), ("C", C.c_int), ("ft", C.c_int),
                 ("fz", C.c_int), ("fx", C.c_int)]
@@ -77,7 +87,7 @@ BN_REP = 16        # STPDE_BN_REP: replicas of the BatchNorm reduction scratch (
 
 class BnDesc(C.Structure):
     _fields_ = [("N", C.c_long), ("C", C.c_int), ("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float),
-                ("momentum", C.c_float), ("scratch_zeroed", C.c_int)]
+                ("momentum", C.c_float), ("scratch_zeroed", C.c_int), ("stats_mode", C.c_int), ("reduce_done", C.c_int)]
 
 
 class AdamDesc(C.Structure):
@@ -206,6 +216,8 @@ _SIGNATURES = {
     "stpde_conv3d_fwd": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),
     "stpde_conv3d_wgrad": ([C.POINTER(Conv3dDesc)] + [_VP] * 4, C.c_int),
     "stpde_conv3d_wgrad_bias": ([C.POINTER(Conv3dDesc)] + [_VP] * 5, C.c_int),
+    "stpde_conv3d_fused": ([C.POINTER(Conv3dFusedArgs), C.POINTER(C.c_int), _VP], C.c_int),
+    "stpde_conv3d_wgrad_onload": ([C.POINTER(Conv3dDesc)] + [_VP] * 8, C.c_int),
     "stpde_residual_fwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP], C.c_int),
     "stpde_residual_bwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP],
                            C.c_int),

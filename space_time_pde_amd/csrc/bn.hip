@@ -101,7 +101,18 @@ __global__ __launch_bounds__(256) void k_bn_stats(BnArgs a) {
   }
   s1 = bn_block_sum(s1, sh, m);
   s2 = bn_block_sum(s2, sh, m);
-  if (m.row0 == 0) {
+  if (m.row0 == 0 && a.d.stats_mode) {
+    // double format (round 4, shared with the convolution epilogues of conv3d_fused.hip): sum of x and of x^2, the shifted
+    // block sums converted in fp64 (exact to fp32 rounding of the shifted sums whatever the mean / deviation ratio is)
+    double* rep = reinterpret_cast<double*>(a.sums) + (size_t)(blockIdx.x % STPDE_BN_REP) * 2 * C;
+    const double n = hi > lo ? (double)(hi - lo) : 0.;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double sh = shift[i], t1 = s1[i], t2 = s2[i];
+      atomicAdd(rep + c + i, t1 + n * sh);
+      atomicAdd(rep + C + c + i, t2 + 2. * sh * t1 + n * sh * sh);
+    }
+  } else if (m.row0 == 0) {
     // the partial sums of a block go to replica blockIdx % STPDE_BN_REP: with one copy, ~1000 blocks queue up on the same 2 C
     // addresses in the L2 atomic units (that, not HBM, bounded this kernel: 62 us for 67 MB)
     float* rep = a.sums + (size_t)(blockIdx.x % STPDE_BN_REP) * 3 * C;
@@ -120,7 +131,15 @@ __global__ __launch_bounds__(256) void k_bn_apply(BnArgs a) {
   const long hi = lo + rows_per_block < N ? lo + rows_per_block : N;
   const int c = 4 * m.q;
   f32x4 mean, var;
-  if (a.d.training) {
+  if (a.d.training && a.d.stats_mode) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float mi, vi, ri;
+      bn_stat_f64(reinterpret_cast<const double*>(a.sums), C, c + i, N, a.d.eps, mi, vi, ri);
+      mean[i] = mi;
+      var[i] = vi;
+    }
+  } else if (a.d.training) {
     f32x4 t1 = f32x4{0.f, 0.f, 0.f, 0.f}, t2 = t1;
     for (int r = 0; r < STPDE_BN_REP; ++r) {          // fixed order: every block gets the same sums
       t1 += ld4(a.sums + ((size_t)r * 3 + 1) * C + c);
@@ -327,8 +346,9 @@ extern "C" int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float*
   const unsigned grid = bn_grid(d);
   // the reduction kernels end in 8 atomics per channel quad and block: a quarter of the blocks (>= 4 waves per SIMD still)
   const unsigned rgrid = grid > 1024 ? 1024 : grid;
-  if (d->training) {
-    if (!d->scratch_zeroed) (void)hipMemsetAsync(sums, 0, (size_t)STPDE_BN_REP * 3 * d->C * sizeof(float), (hipStream_t)stream);
+  if (d->training && d->stats_mode != 2) {
+    const size_t bytes = d->stats_mode ? (size_t)STPDE_BN_REP * 2 * d->C * sizeof(double) : (size_t)STPDE_BN_REP * 3 * d->C * sizeof(float);
+    if (!d->scratch_zeroed) (void)hipMemsetAsync(sums, 0, bytes, (hipStream_t)stream);
     STPDE_LAUNCH(k_bn_stats, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, a);
     rc = stpde_check_launch("k_bn_stats");
     if (rc) return rc;
@@ -362,10 +382,31 @@ extern "C" int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float*
   static const int rg_env = getenv("STPDE_BN_RGRID") ? atoi(getenv("STPDE_BN_RGRID")) : 1024;
   a.il = il_env;
   const unsigned grid = bn_grid(d);
-  if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, (size_t)STPDE_BN_REP * 2 * d->C * sizeof(float), (hipStream_t)stream);
-  STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid > (unsigned)rg_env ? (unsigned)rg_env : grid), dim3(256), 0, (hipStream_t)stream, a);
-  rc = stpde_check_launch("k_bn_bwd_reduce");
-  if (rc) return rc;
+  if (!d->reduce_done) {
+    if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, (size_t)STPDE_BN_REP * 2 * d->C * sizeof(float), (hipStream_t)stream);
+    STPDE_LAUNCH(k_bn_bwd_reduce, dim3(grid > (unsigned)rg_env ? (unsigned)rg_env : grid), dim3(256), 0, (hipStream_t)stream, a);
+    rc = stpde_check_launch("k_bn_bwd_reduce");
+    if (rc) return rc;
+  }
   STPDE_LAUNCH(k_bn_bwd_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return stpde_check_launch("k_bn_bwd_apply");
+}
+
+// statistics of x in the double format, for stpde_conv3d_fused when the convolution ran in the tap-split kernel (its epilogue
+// holds partial sums only); sums zero-filled by the caller
+int stpde_bn_stats_f64(const float* x, long N, int C, double* sums, hipStream_t stream) {
+  stpde_bn_desc d{};
+  d.N = N;
+  d.C = C;
+  d.training = 1;
+  d.stats_mode = 1;
+  int rc = bn_check(&d);
+  if (rc) return rc;
+  BnArgs a{};
+  a.d = d;
+  a.x = x;
+  a.sums = reinterpret_cast<float*>(sums);
+  const unsigned grid = bn_grid(&d);
+  STPDE_LAUNCH(k_bn_stats, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, stream, a);
+  return stpde_check_launch("k_bn_stats");
 }

@@ -427,5 +427,22 @@ __device__ __forceinline__ void load_cq(const float* cw, int point, float* cq) {
 }
 
 // Host-side helpers (api.cpp)
+// mean / biased variance / rstd of one channel from the double-format BatchNorm sums ([STPDE_BN_REP][2][C]: sum x, sum x^2);
+// every consumer (k_bn_apply, the on-load transform of k_conv_fused) calls this one function, so all of them see the same bits
+__device__ __forceinline__ void bn_stat_f64(const double* sums, int C, int c, long N, float eps, float& mean, float& var,
+                                            float& rstd) {
+  double s1 = 0., s2 = 0.;
+  for (int r = 0; r < STPDE_BN_REP; ++r) {
+    s1 += sums[(size_t)(2 * r) * C + c];
+    s2 += sums[(size_t)(2 * r + 1) * C + c];
+  }
+  const double m = s1 / (double)N;
+  double v = s2 / (double)N - m * m;
+  if (v < 0.) v = 0.;
+  mean = (float)m;
+  var = (float)v;
+  rstd = 1.f / sqrtf(var + eps);
+}
+int stpde_bn_stats_f64(const float* x, long N, int C, double* sums, hipStream_t stream);
 void stpde_set_error(const char* fmt, ...);
 int stpde_check_launch(const char* what);

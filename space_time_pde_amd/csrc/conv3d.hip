@@ -8,72 +8,7 @@
 // back to channels-last memory.  No im2col buffer, no LDS.
 // Weight gradient: contraction over voxels, operands are dword loads (lane 16k+i: voxel 4s+k, channel i).
 #include "common.h"
-
-struct ConvArgs {
-  stpde_conv3d_desc d;
-  const float* x;
-  const float* w;
-  const float* bias;
-  float* y;
-  const float* ybar;
-  float* dW;
-  float* dbias;      // weight-gradient kernels: sum over the voxels of ybar, added with atomics (nullable)
-  int nvox, gx;
-};
-
-struct Vox {
-  int b, t, z, x;
-};
-
-__device__ __forceinline__ Vox vox_coords(const stpde_conv3d_desc& d, int v) {
-  Vox c;
-  c.x = v % d.X;
-  int r = v / d.X;
-  c.z = r % d.Z;
-  r /= d.Z;
-  c.t = r % d.T;
-  c.b = r / d.T;
-  return c;
-}
-
-// flattened index of the tap neighbour of voxel c, or -1 outside the volume
-__device__ __forceinline__ int tap_neighbour(const stpde_conv3d_desc& d, const Vox& c, int tap) {
-  if (d.ksize == 1) return ((c.b * d.T + c.t) * d.Z + c.z) * d.X + c.x;
-  const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-  const int t = c.t + dt, z = c.z + dz, x = c.x + dx;
-  if (t < 0 || t >= d.T || z < 0 || z >= d.Z || x < 0 || x >= d.X) return -1;
-  return ((c.b * d.T + t) * d.Z + z) * d.X + x;
-}
-
-// Cheap neighbour indexing (round 3): the linear index of a voxel and nine validity bits (bit 3 * dim + delta + 1: the
-// neighbour at delta = -1 / 0 / +1 along dim exists) are computed ONCE per voxel; a tap then costs an AND, a compare, an add
-// and a select instead of the ~15 integer instructions of tap_neighbour -- on the fp32 MFMA every VALU instruction is paid in
-// MFMA time, and the 16-channel 3x3x3 convolutions of the full-resolution levels spent more cycles on indices than on MFMAs.
-struct VoxN {
-  int lin;
-  unsigned ok;
-};
-__device__ __forceinline__ VoxN vox_prepare(const stpde_conv3d_desc& d, const Vox& c) {
-  VoxN v;
-  v.lin = ((c.b * d.T + c.t) * d.Z + c.z) * d.X + c.x;
-  v.ok = (c.t > 0 ? 1u : 0u) | 2u | (c.t + 1 < d.T ? 4u : 0u) | (c.z > 0 ? 8u : 0u) | 16u | (c.z + 1 < d.Z ? 32u : 0u) |
-         (c.x > 0 ? 64u : 0u) | 128u | (c.x + 1 < d.X ? 256u : 0u);
-  return v;
-}
-// wave-uniform part of a tap: validity mask and linear offset
-__device__ __forceinline__ void tap_uniform(const stpde_conv3d_desc& d, int tap, unsigned& mask, int& off) {
-  if (d.ksize == 1) {
-    mask = 0u;
-    off = 0;
-    return;
-  }
-  const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-  mask = (1u << (dt + 1)) | (1u << (3 + dz + 1)) | (1u << (6 + dx + 1));
-  off = (dt * d.Z + dz) * d.X + dx;
-}
-__device__ __forceinline__ int tap_nb(const VoxN& v, unsigned mask, int off) {
-  return (v.ok & mask) == mask ? v.lin + off : -1;
-}
+#include "conv_common.h"
 
 // VT voxel tiles (16 voxels each) per wave: every weight block that is loaded feeds VT*4 MFMAs per output tile.
 // SPLIT (small volumes = the deep U-Net levels, where a handful of waves would otherwise walk 27 taps x all channel
@@ -166,7 +101,9 @@ __global__ __launch_bounds__(256) void k_conv3d_fwd(ConvArgs a) {
 // ybar fragment of a tile is loaded once and reused for the TG taps (the shifted x fragments mostly hit L1), and the
 // voxel coordinates are decoded once per tile.  The four waves of a block are summed through LDS before ONE set of
 // fp32 atomics per block, so at most gridDim.x atomics hit any dW address.
-template <int MCW, int KCW, int TG>
+// ONLOAD (round 4, 1x1x1): x is the raw output of the previous convolution of a residual block and the convolution consumed
+// max(0, bn(x)) applied on load (k_conv_fused); the same per-channel transform on the operand dwords here.
+template <int MCW, int KCW, int TG, bool ONLOAD = false>
 __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63;
@@ -198,6 +135,17 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
   for (int tg = 0; tg < TG; ++tg) tap_uniform(a.d, tap0 + tg, tmask[tg], toff[tg]);
   // bias gradient = column sums of ybar: taken from the ybar fragments by the blocks of tap group 0 / ci block 0 (every
   // element of ybar passes through exactly one of them) -- saves the separate reduction pass over ybar
+  float omean[KCW], oscale[KCW], obeta[KCW];
+  if (ONLOAD) {
+#pragma unroll
+    for (int ki = 0; ki < KCW; ++ki) {
+      const int ch = 16 * (kb * KCW + ki) + i;
+      const bool okc = kb * KCW + ki < KT;
+      omean[ki] = okc ? a.in_stat[ch] : 0.f;
+      oscale[ki] = okc ? a.in_stat[Ci + ch] * (a.in_gamma ? a.in_gamma[ch] : 1.f) : 0.f;
+      obeta[ki] = okc && a.in_beta ? a.in_beta[ch] : 0.f;
+    }
+  }
   const bool dob = a.dbias && kb == 0 && tap0 == 0;
   float bs[MCW];
 #pragma unroll
@@ -236,6 +184,10 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
         for (int ki = 0; ki < KCW; ++ki) {
           const int kt = kb * KCW + ki;
           f.qb[s][tg][ki] = (nb >= 0 && kt < KT) ? a.x[(size_t)nb * Ci + 16 * kt + i] : 0.f;
+          if (ONLOAD) {
+            const float h = (f.qb[s][tg][ki] - omean[ki]) * oscale[ki] + obeta[ki];
+            f.qb[s][tg][ki] = (nb >= 0 && kt < KT && h > 0.f) ? h : 0.f;
+          }
         }
       }
     }
@@ -464,6 +416,35 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
 }
 
 static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias, void* stream);
+
+extern "C" int stpde_conv3d_wgrad_onload(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW, float* dbias,
+                                         const float* in_stat, const float* in_gamma, const float* in_beta, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!x || !ybar || !dW || !in_stat || d->ksize != 1) {
+    stpde_set_error("conv3d_wgrad_onload: null pointer or ksize != 1");
+    return STPDE_E_BADARG;
+  }
+  ConvArgs a{};
+  a.d = *d;
+  a.x = x;
+  a.ybar = ybar;
+  a.dW = dW;
+  a.dbias = dbias;
+  a.in_stat = in_stat;
+  a.in_gamma = in_gamma;
+  a.in_beta = in_beta;
+  a.nvox = d->B * d->T * d->Z * d->X;
+  const int ntiles = (a.nvox + 15) / 16;
+  const int KT = d->Ci / 16, MT = d->Co / 16;
+  const int gy = ((MT + 1) / 2) * ((KT + 1) / 2);
+  int gx = 2048 / gy;
+  if (gx > 1024) gx = 1024;
+  if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+  if (gx < 1) gx = 1;
+  STPDE_LAUNCH((k_conv3d_wgrad<2, 2, 1, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, a);
+  return stpde_check_launch("k_conv3d_wgrad");
+}
 
 extern "C" int stpde_conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float* ybar, float* dW,
                                   void* stream) {
