@@ -12,6 +12,7 @@ only the channel concatenation of the skip connections is a torch copy.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -292,11 +293,13 @@ class _BnActHip(torch.autograd.Function):
         c = x.shape[-1]
         d = _lib.BnDesc()
         d.N, d.C, d.training, d.relu, d.eps, d.momentum = x.numel() // c, c, int(training), int(relu), eps, momentum
-        # scratch = zero-filled [BN_REP][5][C] slice of the U-Net's per-step buffer (forward + backward sums): no memsets
+        # scratch = zero-filled [BN_REP][6][C] slice of the U-Net's per-step buffer (forward + backward sums): no memsets
         ctx.scratch = scratch
         d.scratch_zeroed = int(scratch is not None)
         R = _lib.BN_REP
         sums = (scratch[:3 * R * c] if scratch is not None else torch.empty(3 * R * c, device=x.device)) if training else None
+        # (scratch layout, shared with _ResBlockHip: [0 : 4RC] forward sums -- this path's float format takes the first 3RC --,
+        # [4RC : 6RC] backward sums)
         stat = torch.empty(2 * c, device=x.device)
         y = torch.empty_like(x)
         _lib.check(L.stpde_bn_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(residual),
@@ -327,7 +330,7 @@ class _BnActHip(torch.autograd.Function):
         scratch, ctx.scratch = ctx.scratch, None          # used once (a second backward gets a fresh buffer + memset)
         d.scratch_zeroed = int(scratch is not None)
         R = _lib.BN_REP
-        bsum = scratch[3 * R * c:] if scratch is not None else torch.empty(2 * R * c, device=x.device)
+        bsum = scratch[4 * R * c:] if scratch is not None else torch.empty(2 * R * c, device=x.device)
         _lib.check(L.stpde_bn_bwd(C.byref(d), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gy),
                                   _lib.ptr(weight.detach() if weight is not None else None), _lib.ptr(stat),
                                   _lib.ptr(bsum), _lib.ptr(dx), _lib.ptr(dr), _lib.ptr(dw), _lib.ptr(db),
@@ -424,6 +427,271 @@ def _upsample_cl(x, factors):
     return x
 
 
+stats = {"fused_resblocks": 0}     # calls that took the fused residual-block path (tests assert it)
+
+
+def _fused_ok(blk, x):
+    """Envelope of the fused residual block (_ResBlockHip): every convolution on the HIP path, every BatchNorm normalising
+    with batch statistics.  STPDE_FUSED_RESBLOCK=0 keeps the one-kernel-per-layer path (the A/B switch of the tests)."""
+    if os.environ.get("STPDE_FUSED_RESBLOCK", "1") == "0":
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.numel() // x.shape[-1] >= 2):
+        return False
+    if not all(_hip_conv_ok(x, c) for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut)):
+        return False
+    if blk.conv1.weight.shape[2] != 1 or blk.conv2.weight.shape[2] != 3 or blk.conv3.weight.shape[2] != 1 \
+            or blk.shortcut.weight.shape[2] != 1:
+        return False
+    for bn in (blk.bn1, blk.bn2, blk.bn3):
+        c = bn.num_features
+        if not ((bn.training or not bn.track_running_stats) and bn.momentum is not None and 16 <= c <= 512
+                and (c & (c - 1)) == 0 and (bn.weight is None) == (bn.bias is None)
+                and (bn.weight is None or bn.weight.dtype == torch.float32)):
+            return False
+    return True
+
+
+def _ptr(t):
+    return _lib.ptr(t) if t is not None else None
+
+
+class _ResBlockHip(torch.autograd.Function):
+    """One ResBlock3D (reference src/unet3d.py:39-56) in training mode as ONE autograd node over the fused kernels of
+    csrc/conv3d_fused.hip (round 4):
+
+      forward   conv1 + shortcut in one pass over x (+ bn1 statistics) | bn1 + relu | conv2 (+ bn2 statistics) |
+                conv3 with bn2 + relu applied to its operand on load (+ bn3 statistics) | bn3 + shortcut + relu
+      backward  bn3 backward | conv3 input gradient (+ relu mask + bn2 backward sums) | bn2 elementwise |
+                conv2 input gradient (+ mask + bn1 sums) | bn1 elementwise | conv1 and shortcut input gradients as one
+                convolution of two inputs | the four weight (+ bias) gradients (side stream when the U-Net defers them)
+
+    5 + 7 + 4 launches and 11 + 23 tensor passes instead of 10 + 17 + 4 and 18 + 32; the normalised output of bn2 is never
+    stored.  Saved for backward: x, the three raw convolution outputs, relu(bn1) and the block output."""
+
+    @staticmethod
+    @_lib.guarded
+    def forward(ctx, blk, x, w1, b1, w2, b2, w3, b3, ws, bs, g1, be1, g2, be2, g3, be3):
+        L = _lib.lib()
+        dev = x.device
+        ci, cn, co = x.shape[-1], w1.shape[0], w3.shape[0]
+        cip = (ci + 15) // 16 * 16
+        xin = x.detach()
+        if cip != ci:
+            xin = F.pad(xin, (0, cip - ci))
+        xin = xin.contiguous()
+        shp = tuple(xin.shape[:4])
+        N = shp[0] * shp[1] * shp[2] * shp[3]
+        R = _lib.BN_REP
+        convs = (blk.conv1, blk.conv2, blk.conv3, blk.shortcut)
+        packs = []
+        for conv, w in zip(convs, (w1, w2, w3, ws)):
+            p = getattr(conv, "_stpde_packs", None)
+            if p is None:
+                fidx, bidx, _, _ = _pack_indices(w.shape[0], w.shape[1], w.shape[2], dev)
+                wflat = torch.cat([w.detach().reshape(-1), w.new_zeros(1)])
+                p = (wflat[fidx], wflat[bidx], None)
+            packs.append(p)
+        bns = (blk.bn1, blk.bn2, blk.bn3)
+        fsum, bsum, stat = [], [], []
+        for bn in bns:
+            c = bn.num_features
+            sc = getattr(bn, "_stpde_scratch", None)
+            if sc is not None:
+                bn._stpde_scratch = None              # one use per step
+            else:
+                sc = torch.zeros(6 * R * c, device=dev)
+            fsum.append(sc[:4 * R * c])
+            bsum.append(sc[4 * R * c:])
+            stat.append(torch.empty(2 * c, device=dev))
+        rm = [bn.running_mean if bn.track_running_stats else None for bn in bns]
+        rv = [bn.running_var if bn.track_running_stats else None for bn in bns]
+
+        def conv_args(ci_, co_, k):
+            a = _lib.Conv3dFusedArgs()
+            a.d.B, a.d.T, a.d.Z, a.d.X = shp
+            a.d.Ci, a.d.Co, a.d.ksize = ci_, co_, k
+            return a
+
+        def bn_desc(c, relu, bn):
+            d = _lib.BnDesc()
+            d.N, d.C, d.training, d.relu, d.eps, d.momentum = N, c, 1, int(relu), float(bn.eps), float(bn.momentum)
+            d.scratch_zeroed, d.stats_mode = 1, 2
+            return d
+
+        st = _lib.stream_ptr()
+        new = lambda c: torch.empty(shp + (c,), device=dev, dtype=torch.float32)
+        # conv1 + shortcut: one pass over x, bn1's statistics from conv1's accumulator tiles
+        y1, sc_out = new(cn), new(co)
+        a = conv_args(cip, cn, 1)
+        a.x, a.w_pack, a.bias, a.y = _ptr(xin), _ptr(packs[0][0]), _ptr(b1.detach() if b1 is not None else None), _ptr(y1)
+        a.y2, a.wo2_pack, a.bias2, a.Co2 = _ptr(sc_out), _ptr(packs[3][0]), _ptr(bs.detach() if bs is not None else None), co
+        a.out_sums = _ptr(fsum[0])
+        _lib.check(L.stpde_conv3d_fused(C.byref(a), None, st))
+        # bn1 + relu (elementwise pass only)
+        h1 = new(cn)
+        d = bn_desc(cn, True, bns[0])
+        _lib.check(L.stpde_bn_fwd(C.byref(d), _ptr(y1), None, _ptr(g1.detach() if g1 is not None else None),
+                                  _ptr(be1.detach() if be1 is not None else None), _ptr(rm[0]), _ptr(rv[0]),
+                                  _ptr(fsum[0]), _ptr(stat[0]), _ptr(h1), st))
+        # conv2 (+ bn2 statistics)
+        y2 = new(cn)
+        a = conv_args(cn, cn, 3)
+        a.x, a.w_pack, a.bias, a.y = _ptr(h1), _ptr(packs[1][0]), _ptr(b2.detach() if b2 is not None else None), _ptr(y2)
+        a.out_sums = _ptr(fsum[1])
+        _lib.check(L.stpde_conv3d_fused(C.byref(a), None, st))
+        # conv3 of relu(bn2(y2)) applied on load (+ bn3 statistics)
+        y3 = new(co)
+        a = conv_args(cn, co, 1)
+        a.x, a.w_pack, a.bias, a.y = _ptr(y2), _ptr(packs[2][0]), _ptr(b3.detach() if b3 is not None else None), _ptr(y3)
+        a.in_sums, a.in_gamma, a.in_beta = _ptr(fsum[1]), _ptr(g2.detach() if g2 is not None else None), \
+            _ptr(be2.detach() if be2 is not None else None)
+        a.in_running_mean, a.in_running_var, a.in_stat = _ptr(rm[1]), _ptr(rv[1]), _ptr(stat[1])
+        a.in_eps, a.in_momentum = float(bns[1].eps), float(bns[1].momentum)
+        a.out_sums = _ptr(fsum[2])
+        _lib.check(L.stpde_conv3d_fused(C.byref(a), None, st))
+        # bn3 + shortcut (+ relu)
+        out = new(co)
+        d = bn_desc(co, blk.final_relu, bns[2])
+        _lib.check(L.stpde_bn_fwd(C.byref(d), _ptr(y3), _ptr(sc_out), _ptr(g3.detach() if g3 is not None else None),
+                                  _ptr(be3.detach() if be3 is not None else None), _ptr(rm[2]), _ptr(rv[2]),
+                                  _ptr(fsum[2]), _ptr(stat[2]), _ptr(out), st))
+        ctx.save_for_backward(xin, y1, h1, y2, y3, out if blk.final_relu else None, stat[0], stat[1], stat[2],
+                              g1, be1, g2, be2, g3, packs[0][1], packs[1][1], packs[2][1], packs[3][1])
+        ctx.meta = (shp, N, ci, cip, cn, co, bool(blk.final_relu), [float(bn.eps) for bn in bns],
+                    [float(bn.momentum) for bn in bns], (b1 is not None, b2 is not None, b3 is not None, bs is not None))
+        ctx.bsum = bsum
+        ctx.dw = [(p[2], p[3:5] if len(p) > 3 else None) for p in packs]
+        stats["fused_resblocks"] += 1
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    @_lib.guarded
+    def backward(ctx, gout):
+        L = _lib.lib()
+        (xin, y1, h1, y2, y3, out, st1, st2, st3, g1, be1, g2, be2, g3, bp1, bp2, bp3, bps) = ctx.saved_tensors
+        shp, N, ci, cip, cn, co, final_relu, eps, mom, has_b = ctx.meta
+        dev = gout.device
+        R = _lib.BN_REP
+        gout = gout.contiguous()
+        bsum, ctx.bsum = ctx.bsum, None               # zero-filled, used once (a second backward gets fresh buffers)
+        zeroed = bsum is not None
+        if bsum is None:
+            bsum = [torch.empty(2 * R * c, device=dev) for c in (cn, cn, co)]
+        st = _lib.stream_ptr()
+        new = lambda c: torch.empty(shp + (c,), device=dev, dtype=torch.float32)
+        vec = lambda t, c: torch.empty(c, device=dev) if t is not None else None
+
+        def conv_args(ci_, co_, k):
+            a = _lib.Conv3dFusedArgs()
+            a.d.B, a.d.T, a.d.Z, a.d.X = shp
+            a.d.Ci, a.d.Co, a.d.ksize = ci_, co_, k
+            return a
+
+        def bn_desc(c, relu, k, reduce_done):
+            d = _lib.BnDesc()
+            d.N, d.C, d.training, d.relu, d.eps, d.momentum = N, c, 1, int(relu), eps[k], mom[k]
+            d.scratch_zeroed, d.reduce_done = int(zeroed), int(reduce_done)
+            return d
+
+        defer = ctx.dw[0][1][0] if ctx.dw[0][1] else None
+        # bn3 backward (reduction + elementwise): gradient of conv3's output and of the shortcut branch
+        dy3, dsc = new(co), new(co)
+        dg3, db3 = vec(g3, co), vec(g3, co)
+        d = bn_desc(co, final_relu, 2, False)
+        _lib.check(L.stpde_bn_bwd(C.byref(d), _ptr(y3), _ptr(out), _ptr(gout), _ptr(g3), _ptr(st3), _ptr(bsum[2]),
+                                  _ptr(dy3), _ptr(dsc), _ptr(dg3), _ptr(db3), st))
+        ev3 = torch.cuda.current_stream().record_event() if defer is not None else None
+        # conv3 input gradient; its epilogue applies the relu mask of bn2's output and adds bn2's backward sums
+        dz2 = new(cn)
+        a = conv_args(co, cn, 1)
+        a.x, a.w_pack, a.y = _ptr(dy3), _ptr(bp3), _ptr(dz2)
+        a.m, a.m_stat, a.m_gamma, a.m_beta, a.m_bsum = _ptr(y2), _ptr(st2), _ptr(g2), _ptr(be2), _ptr(bsum[1])
+        done = C.c_int(1)
+        if not zeroed:
+            bsum[1].zero_()
+            bsum[0].zero_()
+        _lib.check(L.stpde_conv3d_fused(C.byref(a), C.byref(done), st))
+        dy2 = new(cn)
+        dg2, db2 = vec(g2, cn), vec(g2, cn)
+        d = bn_desc(cn, False, 1, True)
+        _lib.check(L.stpde_bn_bwd(C.byref(d), _ptr(y2), None, _ptr(dz2), _ptr(g2), _ptr(st2), _ptr(bsum[1]),
+                                  _ptr(dy2), None, _ptr(dg2), _ptr(db2), st))
+        ev2 = torch.cuda.current_stream().record_event() if defer is not None else None
+        # conv2 input gradient (+ mask of bn1's output + bn1's sums where the kernel can: not the tap-split deep levels)
+        dz1 = new(cn)
+        a = conv_args(cn, cn, 3)
+        a.x, a.w_pack, a.y = _ptr(dy2), _ptr(bp2), _ptr(dz1)
+        a.m, a.m_stat, a.m_gamma, a.m_beta, a.m_bsum = _ptr(y1), _ptr(st1), _ptr(g1), _ptr(be1), _ptr(bsum[0])
+        done = C.c_int(1)
+        _lib.check(L.stpde_conv3d_fused(C.byref(a), C.byref(done), st))
+        dy1 = new(cn)
+        dg1, db1 = vec(g1, cn), vec(g1, cn)
+        if done.value:
+            d = bn_desc(cn, False, 0, True)
+            _lib.check(L.stpde_bn_bwd(C.byref(d), _ptr(y1), None, _ptr(dz1), _ptr(g1), _ptr(st1), _ptr(bsum[0]),
+                                      _ptr(dy1), None, _ptr(dg1), _ptr(db1), st))
+        else:
+            d = bn_desc(cn, True, 0, False)
+            d.scratch_zeroed = 1                                      # zero either way (see above)
+            _lib.check(L.stpde_bn_bwd(C.byref(d), _ptr(y1), _ptr(h1), _ptr(dz1), _ptr(g1), _ptr(st1), _ptr(bsum[0]),
+                                      _ptr(dy1), None, _ptr(dg1), _ptr(db1), st))
+        ev1 = torch.cuda.current_stream().record_event() if defer is not None else None
+        # input gradient: conv1's and the shortcut's in one convolution of two inputs
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dxp = new(cip)
+            a = conv_args(cn, cip, 1)
+            a.x, a.w_pack, a.y = _ptr(dy1), _ptr(bp1), _ptr(dxp)
+            a.x2, a.w2_pack, a.Ci2 = _ptr(dsc), _ptr(bps), co
+            _lib.check(L.stpde_conv3d_fused(C.byref(a), None, st))
+            dx = dxp[..., :ci] if cip != ci else dxp
+        # weight (+ bias) gradients: (conv, input, output gradient, kernel size, channels, on-load transform of the input)
+        jobs = [(2, y2, dy3, 1, cn, co, ev3, True), (3, xin, dsc, 1, cip, co, ev3, False),
+                (1, h1, dy2, 3, cn, cn, ev2, False), (0, xin, dy1, 1, cip, cn, ev1, False)]
+        need_w = any(ctx.needs_input_grad[i] for i in (2, 4, 6, 8))
+        gw = [None] * 4
+        gb = [None] * 4
+        for k, xi, gy, ks, ci_, co_, ev, onload in jobs:
+            if not need_w:
+                break
+            dwt, dfr = ctx.dw[k]
+            ctx.dw[k] = (None, dfr)                     # the zero-filled slice of the per-step buffer is used once
+            cd = _lib.Conv3dDesc()
+            cd.B, cd.T, cd.Z, cd.X = shp
+            cd.Ci, cd.Co, cd.ksize = ci_, co_, ks
+
+            def launch(dwt, dbt):
+                if onload:
+                    _lib.check(L.stpde_conv3d_wgrad_onload(C.byref(cd), _ptr(xi), _ptr(gy), _ptr(dwt), _ptr(dbt), _ptr(st2),
+                                                           _ptr(g2), _ptr(be2), _lib.stream_ptr()))
+                else:
+                    _lib.check(L.stpde_conv3d_wgrad_bias(C.byref(cd), _ptr(xi), _ptr(gy), _ptr(dwt), _ptr(dbt),
+                                                         _lib.stream_ptr()))
+
+            if dfr and dwt is not None:
+                dobj, idx = dfr
+                dobj.keep.append((gy, xi, st2, g2, be2))
+                dobj.side.wait_event(ev)
+                with torch.cuda.stream(dobj.side):
+                    launch(dwt, dobj.bias_slice(idx) if has_b[k] else None)
+                dobj.enqueue(idx)
+            else:
+                if dwt is None:
+                    dwt = torch.zeros(ks ** 3, co_, ci_, device=dev)
+                dbt = torch.zeros(co_, device=dev) if has_b[k] else None
+                launch(dwt, dbt)
+                cin = ci if k in (0, 3) else ci_
+                gw[k] = dwt[:, :, :cin].permute(1, 2, 0).reshape(co_, cin, ks, ks, ks)
+                gb[k] = dbt
+        if _ResBlockHip.debug is not None:
+            _ResBlockHip.debug.update(dy3=dy3, dsc=dsc, dz2=dz2, dy2=dy2, dz1=dz1, dy1=dy1, dx=dx, y1=y1, h1=h1, y2=y2, y3=y3,
+                                      done=done.value)
+        return (None, dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], gw[3], gb[3], dg1, db1, dg2, db2, dg3, db3)
+
+    debug = None     # a dict here makes backward leave its intermediate gradients in it (tools/micro/dbg_resblock.py)
+
+
 class ResBlock3D(nn.Module):
     """3D convolutional residue block, keeps the resolution (reference :12-56)."""
 
@@ -443,6 +711,15 @@ class ResBlock3D(nn.Module):
 
     def forward_cl(self, x):
         """Channels-last in, channels-last out: conv1-bn1-relu-conv2-bn2-relu-conv3-bn3 + shortcut (+relu)."""
+        if _fused_ok(self, x):
+            for bn in (self.bn1, self.bn2, self.bn3):
+                if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None \
+                        and not getattr(bn, "_stpde_counted", False):
+                    bn.num_batches_tracked.add_(1)
+            return _ResBlockHip.apply(self, x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                      self.conv3.weight, self.conv3.bias, self.shortcut.weight, self.shortcut.bias,
+                                      self.bn1.weight, self.bn1.bias, self.bn2.weight, self.bn2.bias,
+                                      self.bn3.weight, self.bn3.bias)
         h = _bn_act(_conv_cl(x, self.conv1), self.bn1, True)
         h = _bn_act(_conv_cl(h, self.conv2), self.bn2, True)
         # bn3 + shortcut + final ReLU in one pass
@@ -596,7 +873,7 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
             # one zero-filled buffer for the statistics scratch of every BatchNorm of the step (forward + backward sums):
             # one memset instead of two per BatchNorm call
             allbn = [m for m in self.modules() if isinstance(m, nn.BatchNorm3d)]
-            per = 5 * _lib.BN_REP
+            per = 6 * _lib.BN_REP
             zero = torch.zeros(per * sum(m.num_features for m in allbn), device=device)
             o = 0
             for m in allbn:
