@@ -123,6 +123,12 @@ typedef struct {
    * of stpde_jet_layer_bwd / _bwd_to, including the layer-0 adjoint of a first-hidden-layer call: adjoint format),
    * 4 = abar_out (input of the backward / weight-gradient kernels) is a packed adjoint buffer. */
   int packed;
+  /* bf16 mode (round 4): the ACTIVATED input of this layer as the bf16 MFMA operand blocks its forward pass produces anyway
+   * (activation jet of in_pre -- of the layer-0 pre-activations for the first hidden layer -- rounded to bf16), kept as
+   * [tile][KT][S][16 rows][16 features] bf16 (KT * S * 512 bytes per row tile).  stpde_jet_layer_fwd WRITES it when non-NULL;
+   * stpde_jet_wgrad then READS it as its second operand instead of loading in_pre and evaluating the activation jets a
+   * second time (those jets were 2/3 of the first-hidden-layer weight gradient's instructions).  NULL: not kept. */
+  void* act16;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
  * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16.
@@ -300,6 +306,7 @@ typedef struct {
   unsigned long sort_tmp_bytes;
   float* abar4x;   /* packed buffers: adjoint buffer of fc4's output rows (abar2x / abar3x / abar4x / abar1x then hold packed
                       ADJOINT buffers: nt * S * MT_l * 512 bytes) */
+  void* act16[2];  /* bf16 mode, nullable: stpde_layer_desc.act16 of fc1 and fc2 (nt * KT_l * S * 512 bytes each) */
 } stpde_lig_workspace;
 #define STPDE_F_STASH 1          /* forward: keep what the backward needs (XR, z0) */
 #define STPDE_F_VALUE_TILES 2    /* forward-only value queries: four row tiles per pass over the weights */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("STPDE_LIB") or os.path.join(_HERE, "libstpde_hip.so")
 _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s36.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "conv3d_fused.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
-ABI_VERSION = 308   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 309   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
@@ -36,7 +36,7 @@ class GatherDesc(C.Structure):
 
 class LayerDesc(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg),
-                ("mfma_bf16", C.c_int), ("packed", C.c_int)]
+                ("mfma_bf16", C.c_int), ("packed", C.c_int), ("act16", C.c_void_p)]
 
 
 class XbarDesc(C.Structure):
@@ -55,7 +55,8 @@ class LigWorkspace(C.Structure):        # stpde_lig_workspace
     _fields_ = [("X", C.c_void_p), ("XR", C.c_void_p), ("coef", C.c_void_p), ("cw", C.c_void_p), ("cell", C.c_void_p),
                 ("pre", C.c_void_p * 8), ("abar2x", C.c_void_p), ("abar3x", C.c_void_p), ("tan0", C.c_void_p),
                 ("abar0", C.c_void_p), ("abar1x", C.c_void_p), ("abar0x", C.c_void_p), ("xrows", C.c_void_p), ("perm", C.c_void_p), ("start", C.c_void_p),
-                ("sort_tmp", C.c_void_p), ("sort_tmp_bytes", C.c_ulong), ("abar4x", C.c_void_p)]
+                ("sort_tmp", C.c_void_p), ("sort_tmp_bytes", C.c_ulong), ("abar4x", C.c_void_p),
+                ("act16", C.c_void_p * 2)]
 
 
 F_STASH, F_VALUE_TILES, F_FUSED_TAIL, F_TAN0_ROWSUM, F_DETERMINISTIC, F_WGRAD, F_WGRAD_FP32 = 1, 2, 4, 8, 16, 32, 64

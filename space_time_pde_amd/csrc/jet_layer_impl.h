@@ -69,6 +69,8 @@ struct LayerArgs {
   float* Z0;           // [tile][KT or MT][256] value stream of the layer-0 pre-activations: written by the PRO_L0 forward
                        // (nullable there: the stores are dropped), read by EPI_ADJ_L0 instead of regenerating it from X
                        // (may alias Out when Out holds the value stream only: each lane reads its element before it writes it)
+  void* H16;           // forward, bf16 mode, nullable: [tile][KT][S][16][16] bf16 = the activated B-operand blocks of this
+                       // layer as the produce stage rounds them (stpde_layer_desc.act16), kept for the weight gradient
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   int pk;              // packed-buffer flags (common.h: ld_blk / st_blk): 1 = Bin, 2 = Out, 4 = Pre -- a forward kernel reads /
@@ -615,6 +617,11 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     static const int dspec_env = getenv("STPDE_BF_SPEC_DGRAD") ? atoi(getenv("STPDE_BF_SPEC_DGRAD")) : 1;
     if (a.Wp16 && a.nsplit == 1 && dspec_env && a.pk == 3 && a.MT == 32 && a.KT == 16 && a.Tan0 && a.Z0)
       return launch_fc1_dgrad_spec<S1, S2, ACT>(a, stream);
+  }
+  if (EPI == EPI_FWD && a.H16) {
+    stpde_set_error("jet_layer_fwd: act16 is written by the wave-specialised bf16 forward of the first hidden layer only "
+                    "(S1 = 3, S2 <= 2, 16 output tiles, 16 / 32 input tiles, STPDE_BF_SPEC != 0)");
+    return STPDE_E_UNSUPPORTED;
   }
   const int npass = a.MT / (NW * MCg);
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass

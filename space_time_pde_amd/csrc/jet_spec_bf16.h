@@ -80,6 +80,11 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
     auto produce = [&](auto gc, int tile) {
       constexpr int g = decltype(gc)::value;
       const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
+      // the operand blocks of this tile for the weight gradient (stpde_layer_desc.act16): [kt][st][row][feature] bf16, this
+      // lane's four features of its row as one 8-byte store (empty descriptor when not kept: the stores are dropped)
+      const auto h16r = opt_store_rsrc(a.H16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.H16) + (size_t)tile * KT * S * 512) : nullptr,
+                                       (unsigned)(KT * S) * 512u);
+      const int h16lane = ((lane & 15) * 16 + 4 * (lane >> 4)) * 2;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int slot = 4 * k + w, kt = GK * g + slot;
@@ -101,7 +106,11 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
         }
         act_jet_fwd<S1, S2, ACT>(a.cfg, raw, B, cq);
 #pragma unroll
-        for (int st = 0; st < S; ++st) *reinterpret_cast<bf16x4*>(&hb[g & 1][slot][st][lane * 2]) = to_bf4(B[st]);
+        for (int st = 0; st < S; ++st) {
+          const bf16x4 b4 = to_bf4(B[st]);
+          *reinterpret_cast<bf16x4*>(&hb[g & 1][slot][st][lane * 2]) = b4;
+          buf_st8(h16r, h16lane, (kt * S + st) * 512, b4);
+        }
       }
     };
     for (int it = 0; it <= ntl; ++it) {

@@ -29,11 +29,15 @@ struct WgradArgs {
   const float* tanc0;  // [3][KT][256] layer-0 tangent constants W0[:, d], column-major image (MODE 1)
   float* dW;           // [16*MT][16*(KT+XT)]
   const float* cw;     // [P][8] weights of the combined second-order stream (S2 == 1)
+  const void* H16;     // bf16 mode, nullable: the activated input as the forward's bf16 operand blocks [tile][KT][S][16][16]
+                       // (stpde_layer_desc.act16); the kernels compiled for it (PKM bit 8) copy these blocks into the ring
+                       // instead of loading Q and evaluating the activation jets
   int SP, KT, MT, ntiles;
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
   int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
   int pk;              // packed-buffer flags (common.h: ld_blk): 1 = Q (the layer input's pre-activations), 4 = P (abar_out)
+  int swap;            // plain bf16 mode: the second wave of every SIMD runs the two phases of an iteration in the other order
   int xfold;           // fp32 hidden-group launches: the (k-group, k-slot) pairs 0 .. XT-1 also contract their abar blocks with
                        // raw-input tile 0 .. XT-1 (one extra 16x16 tile per wave, the XR fragment straight from memory), and all
                        // of them keep the row sums of the tangent-stream adjoints (the tangent "input" of a skip connection is the
@@ -89,6 +93,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // with one ds_read_b64 -- the same layout serves the column-major producers (transposing ds_write_b16) and the
   // row-major ones (ds_write_b64).
   constexpr bool SPLP = BF && SPL == 3;
+  // HQ (PKM bit 8, plain bf16 mode): the hidden k-tiles' operand blocks come ready-made from the forward pass (a.H16, the
+  // very bytes put() would write: [row][feature] bf16) -- load_q fetches 8 bytes per lane and stream, finish_q copies them
+  // into the ring slot.  No stash load, no activation jet, no rounding: bit-identical blocks for 2/3 fewer instructions.
+  constexpr bool HQ = (PKM & 8) != 0;
+  static_assert(!HQ || (BF && SPL == 1), "ready-made operand blocks are a plain-bf16-mode feature");
   // bf16-pipe modes: every LDS block (ring slots and the private abar patches) holds the SPL bf16 terms of a fragment as
   // [term][16][16] bf16 (512 B per term), written with ONE ds_write_b64 per lane and term at (lane & 15) * 16 + 4 * (lane >> 4)
   // -- which is [row][feature] for a column-major source and [feature][row] for a row-major one -- and read back as the
@@ -101,7 +110,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   constexpr int NBUF = (2 * RS * S * BLK * 4 + NW * 2 * BLK * 4 <= 150 * 1024) ? 2 : 1;
   constexpr int SX = S1 == 3 ? 4 : 1;       // raw-input tiles only feed the value and tangent streams
   __shared__ __attribute__((aligned(16))) float hl[NBUF][RS][S][BLK];
-  __shared__ __attribute__((aligned(16))) float pp[NW][2][BLK];
+  // plain bf16 mode: one patch per adjoint block of a wave (S * MCW of them) -- all blocks of a tile are written, then all
+  // are read back transposed: ONE LDS round trip per tile and wave instead of one per block (the waves of this kernel are
+  // bound by their dependent chains, not by pipe throughput: profiles/r4_wgrad_bf16_steps.txt)
+  constexpr int NPP = (BF && SPL == 1 && 2 * RS * S * 512 + NW * S * MCW * 512 <= 100 * 1024) ? S * MCW : 2;
+  __shared__ __attribute__((aligned(16))) float pp[NW][NPP][BLK];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int lo = lane * 4;
@@ -149,6 +162,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // so the loads' latency hides behind the MFMAs instead of sitting in front of the barrier
   auto load_q = [&](int tile, f32x4* pre, float* cq) {
     const int kq = kq0 + wv;
+    if constexpr (HQ) {
+      if (!HASX || kq < KT) {
+        const char* hb8 = reinterpret_cast<const char*>(a.H16) + ((size_t)tile * KT + kq) * S * 512 + lane * 8;
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+          const float2 v = *reinterpret_cast<const float2*>(hb8 + st * 512);
+          pre[st] = f32x4{v.x, v.y, 0.f, 0.f};
+        }
+        return;
+      }
+    }
     if (!HASX || kq < KT) {
       // rows of this lane (column-major image): row = lane & 15
       load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
@@ -172,6 +196,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   };
   auto finish_q = [&](const f32x4* pre, const float* cq, int buf) {
     const int kq = kq0 + wv;
+    if constexpr (HQ) {
+      if (!HASX || kq < KT) {
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+          *reinterpret_cast<float2*>(&hl[buf][wv][st][lane * 2]) = float2{pre[st][0], pre[st][1]};
+        return;
+      }
+    }
     if (!HASX || kq < KT) {
       f32x4 H[S];
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
@@ -225,7 +257,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // bf16-pipe modes: the column-major abar blocks `raw_` of the tile -> split into bf16 terms, transposed through this
   // wave's private patch (one ds_write_b64 + one transpose read per term), packed two streams per MFMA operand
   auto pack_p = [&](f32x4 (*raw_)[MCW]) {
-    if constexpr (BF) {
+    if constexpr (BF && NPP > 2) {
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) put(pp[wv][st * MCW + mi], blk_val(raw_[st][mi], st < SP ? PMODE : 0, st), false);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int sp = 0; sp < SH; ++sp)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi)
+          pa8[0][sp][mi] = cat8(get16(pp[wv][2 * sp * MCW + mi], 0, true),
+                                2 * sp + 1 < S ? get16(pp[wv][(2 * sp + 1 < S ? 2 * sp + 1 : 0) * MCW + mi], 0, true) : zero4);
+      __builtin_amdgcn_wave_barrier();
+    } else if constexpr (BF) {
       int flip = 0;
       auto terms = [&](f32x4 v, bf16x4* t) {
         float* patch = pp[wv][flip];
@@ -273,7 +318,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   const int xsel = xslot < XT ? xslot : XT - 1;
   f32x4 accx[(XF || XB) ? MCW : 1];
   float acct[XF && S1 == 3 ? 3 : 1][XF ? MCW : 1];
-  f32x4 acctb[XB && S1 == 3 ? 3 : 1][XB ? MCW : 1];
+  // XB, wave of raw-input tile 0: the tangent columns (the tangent "input" of a skip connection is the unit vector e_d) go
+  // through the same accumulator tile as the value product -- stream d of the second operand is the pattern [feature == d]
+  // -- two more MFMAs per row tile instead of 24 accumulator registers and 48 VALU instructions (round 4; those registers
+  // are what the double-buffered ring reads below needed)
+  const bf16x4 one4 = to_bf4(f32x4{1.f, 1.f, 1.f, 1.f});
+  const bool tanw = XB && S1 == 3 && xslot == 0;
+  const bf16x4 e0 = (tanw && c == 0) ? one4 : zero4;
+  const bf16x8 x8t = cat8((tanw && c == 1) ? one4 : zero4, (tanw && c == 2) ? one4 : zero4);
   f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (XF || XB) {
 #pragma unroll
@@ -285,19 +337,43 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) acct[d][mi] = 0.f;
   }
-  if constexpr (XB && S1 == 3) {
+  // value product with the raw-input tile + tangent columns (XB): part of the MFMA phase of a row tile
+  auto xb_mma = [&]() {
+    if constexpr (XB) {
+      const bf16x8 x8 = cat8(to_bf4(xr), S1 == 3 ? e0 : zero4);
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+      for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[0][0][mi], x8, accx[mi]);
+      if constexpr (S1 == 3) {
 #pragma unroll
-      for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // XB: every tile's column-major abar blocks are added exactly once (the last iteration re-loads its own tile: weight 0)
-  auto tangent_sums_b = [&](f32x4 (*raw_)[MCW], float wgt) {
-    if constexpr (XB && S1 == 3) {
+        for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[0][1][mi], x8t, accx[mi]);
+      }
+    }
+  };
+  // plain bf16 mode, hidden k-tiles: the MFMAs of a row tile with the ring reads of k-tile ki + 1 requested BEFORE the MFMAs
+  // of k-tile ki (the compiler's own schedule re-used ONE operand register set: read, s_waitcnt lgkmcnt(0), two MFMAs, 24
+  // times per tile -- ~3,000 cycles of exposed LDS latency per wave and tile, the largest single item of this kernel)
+  auto ring_mma = [&](int rb) {
+    auto rd = [&](int ki, bf16x8* H8) {
+      const int q = ks * KC + ki;
 #pragma unroll
-      for (int d = 0; d < 3; ++d)
+      for (int sp = 0; sp < SH; ++sp)
+        H8[sp] = cat8(get16(&hl[rb][q][2 * sp][0], 0, true),
+                      2 * sp + 1 < S ? get16(&hl[rb][q][2 * sp + 1 < S ? 2 * sp + 1 : 0][0], 0, true) : zero4);
+    };
+    bf16x8 Hn[SH];
+    rd(0, Hn);
 #pragma unroll
-        for (int mi = 0; mi < MCW; ++mi) acctb[d][mi] += wgt * blk_val(raw_[1 + d][mi], PMODE, 1 + d);
+    for (int ki = 0; ki < KC; ++ki) {
+      bf16x8 Hc[SH];
+#pragma unroll
+      for (int sp = 0; sp < SH; ++sp) Hc[sp] = Hn[sp];
+      if (ki + 1 < KC) rd(ki + 1, Hn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sp = 0; sp < SH; ++sp)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma_bf(pa8[0][sp][mi], Hc[sp], acc[mi][ki]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   if (tile < a.ntiles) {
@@ -306,13 +382,96 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     load_p_raw(tile, raw);
     transpose_p(raw, pa);
     pack_p(raw);
-    tangent_sums_b(raw, 1.f);
     if constexpr (XF || XB) {
       if (a.xfold) xr = ld4(a.XR + ((size_t)tile * XT + xsel) * 256 + lo);
     }
   }
   __syncthreads();
   int buf = 0;
+  // Phase swap (round 4, plain bf16 mode, hidden k-groups): the two waves of a SIMD meet at one barrier per row tile, and in
+  // the loop below both run the same phases at the same time -- ring reads + bf16 MFMAs (the vector ALU idle), then the
+  // preparation of the next tile: adjoint blocks through the patch, ring slot, tangent sums (the matrix pipe idle).  Within
+  // an iteration the order of the two phases is free (the ring buffer being written is not the one being read, the prepared
+  // adjoint operand goes to a staging set), so waves 4 .. 7 -- the second wave of every SIMD -- run them the other way
+  // round: while one wave of a SIMD issues MFMAs the other one is in its VALU / LDS phase.  Their operand loads are
+  // requested one iteration ahead (behind the preparation, in flight during the MFMAs and across the barrier).
+  // STPDE_WGRAD_SWAP=0: every wave in the same order.
+  // (compiled for the packed-buffer variants: with fp32 blocks on both sides the second loop body spills)
+  constexpr bool SWAPOK = BF && SPL == 1 && NBUF == 2 && !HASX && PKM != 0 && MODE == 1;
+  if constexpr (SWAPOK) {
+    if (a.swap && wv >= NW / 2) {
+      auto pack_to = [&](f32x4 (*raw_)[MCW], bf16x8 (*dst)[MCW]) {
+        if constexpr (NPP > 2) {
+#pragma unroll
+          for (int st = 0; st < S; ++st)
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi) put(pp[wv][st * MCW + mi], blk_val(raw_[st][mi], st < SP ? PMODE : 0, st), false);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int sp = 0; sp < SH; ++sp)
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi)
+              dst[sp][mi] = cat8(get16(pp[wv][2 * sp * MCW + mi], 0, true),
+                                 2 * sp + 1 < S ? get16(pp[wv][(2 * sp + 1 < S ? 2 * sp + 1 : 0) * MCW + mi], 0, true) : zero4);
+          __builtin_amdgcn_wave_barrier();
+          return;
+        }
+        int flip = 0;
+        auto term = [&](f32x4 v) -> bf16x4 {
+          float* patch = pp[wv][flip];
+          flip ^= 1;
+          put(patch, v, false);
+          __builtin_amdgcn_wave_barrier();
+          const bf16x4 t = get16(patch, 0, true);
+          __builtin_amdgcn_wave_barrier();
+          return t;
+        };
+#pragma unroll
+        for (int sp = 0; sp < SH; ++sp)
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi) {
+            const bf16x4 t0 = term(blk_val(raw_[2 * sp][mi], 2 * sp < SP ? PMODE : 0, 2 * sp));
+            bf16x4 t1 = zero4;
+            if (2 * sp + 1 < S) t1 = term(blk_val(raw_[2 * sp + 1][mi], 2 * sp + 1 < SP ? PMODE : 0, 2 * sp + 1));
+            dst[sp][mi] = cat8(t0, t1);
+          }
+      };
+      f32x4 raw[S][MCW];
+      f32x4 preq[S];
+      float cqq[6];
+      f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tile < a.ntiles) {
+        const int nx0 = tile + stride < a.ntiles ? tile + stride : tile;
+        load_p_raw(nx0, raw);
+        load_q(nx0, preq, cqq);
+        if constexpr (XB) xrn = ld4(a.XR + ((size_t)nx0 * XT + xsel) * 256 + lo);
+      }
+      for (; tile < a.ntiles; tile += stride) {
+        const int next = tile + stride;
+        const int nx = next < a.ntiles ? next : tile;
+        // ---- preparation of tile nx (operands requested during the previous iteration)
+        bf16x8 tmp8[SH][MCW];
+        finish_q(preq, cqq, buf ^ 1);
+        pack_to(raw, tmp8);
+        const f32x4 xr_next = xrn;
+        // ---- request the tile after it
+        const int nn = nx + stride < a.ntiles ? nx + stride : nx;
+        load_p_raw(nn, raw);
+        load_q(nn, preq, cqq);
+        if constexpr (XB) xrn = ld4(a.XR + ((size_t)nn * XT + xsel) * 256 + lo);
+        // ---- the MFMAs of the current tile
+        xb_mma();
+        ring_mma(buf);
+#pragma unroll
+        for (int sp = 0; sp < SH; ++sp)
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi) pa8[0][sp][mi] = tmp8[sp][mi];
+        if constexpr (XB) xr = xr_next;
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+  }
   for (; tile < a.ntiles; tile += stride) {
     const int next = tile + stride;
     const int nx = next < a.ntiles ? next : tile;   // branch-free tail: the last iteration re-produces its own tile
@@ -327,9 +486,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (XB) {
       xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
-      const bf16x8 x8 = cat8(to_bf4(xr), zero4);
-#pragma unroll
-      for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[0][0][mi], x8, accx[mi]);
+      xb_mma();
     }
     if constexpr (XF) {
       // branch-free: without xfold the pointer is this launch's own XR anyway and the results are simply not written
@@ -372,6 +529,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
                 acc[mi][ki + kk] = mfma_bf(pa8[TP[q6]][sp][mi], H8[kk][TH[q6]], acc[mi][ki + kk]);
         }
       }
+    } else if constexpr (BF && SPL == 1 && !HASX && STPDE_ABLATE_W == 0) {
+      ring_mma(buf);
     } else {
 #pragma unroll
     for (int ki = 0; ki < KC; ++ki) {
@@ -439,7 +598,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     }
     }
     if constexpr (XF || XB) xr = xrn;
-    tangent_sums_b(raw, next < a.ntiles ? 1.f : 0.f);
     if (NBUF == 2) {
       if (STPDE_ABLATE_W != 3) {
         if (!EARLYQ) load_q(nx, preq, cqq);
@@ -483,18 +641,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r]);
-        if constexpr (S1 == 3) {
-          if (xslot == 0) {
-            // column-major partial sums: lane (g, j) holds features 4g..4g+3 summed over the tiles' row j; fold the 16 rows
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float v = row_sum16(acctb[d][mi][r]);
-                if (c == 15) atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * KT + d, v);
-              }
-          }
-        }
       }
     }
   }
@@ -889,6 +1035,8 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   constexpr bool SPLIT_OK = KC >= 4 && S1 + S2 <= 4;
   const int bfm = (a.bf16 == 3 && !SPLIT_OK) ? 0 : a.bf16;
   const bool xfold = xfold_env && (!bfm || (bfm == 1 && KC >= 4)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
+  static const int swap_env = getenv("STPDE_WGRAD_SWAP") ? atoi(getenv("STPDE_WGRAD_SWAP")) : 1;
+  a.swap = swap_env;
   for (int part = 0; part < 2; ++part) {
     a.kz0 = part == 0 ? 0 : nhid;
     a.gz = part == 0 ? nhid : ngr - nhid;
@@ -915,7 +1063,11 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
           stpde_set_error("packed layer buffers: combination %d not compiled for this weight-gradient kind", a.pk);
           return STPDE_E_UNSUPPORTED;
         }
-        if (part == 0 && a.pk)
+        static const int hq_env = getenv("STPDE_WGRAD_H16") ? atoi(getenv("STPDE_WGRAD_H16")) : 1;
+        if (part == 0 && a.pk && a.H16 && hq_env && MODE == 1 && KC == 8)
+          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 1, (MODE == 1 && KC == 8) ? (PKA | 8) : PKA>), grid,
+                       dim3(512), 0, stream, a);
+        else if (part == 0 && a.pk)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 1, PKA>), grid, dim3(512), 0, stream, a);
         else if (part == 0)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true>), grid, dim3(512), 0, stream, a);

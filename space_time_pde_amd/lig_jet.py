@@ -346,6 +346,31 @@ def _buf_floats(meta, l, nt):
     return nt * meta.S * mt * _FRAG
 
 
+# bf16 mode: layers whose forward keeps its activated input as bf16 operand blocks for the weight gradient (act16 of
+# include/stpde_hip.h).
+# Measured (round 4, profiles/r4_act16_swap_ab.txt): the weight gradient of the first hidden layer gains 3 ms (26.2 -> 23.3 per
+# step), the forward that writes the blocks loses 4 (21.9 -> 25.9: 80 KB more stores per row tile), 40 GB more stash -- the
+# kernel is bound by its dependent chains, not by the jets' instruction count.  Kept as an opt-in (STPDE_ACT16=1), off by default.
+_act16_env = os.environ.get("STPDE_ACT16", "0") == "1"
+
+
+def _act16_layers(meta, l):
+    """True when layer l's forward keeps its operand blocks: the kernels that write them (csrc/jet_spec_bf16.h: the
+    wave-specialised forward of the first hidden layer) and read them (k_wgrad_coop with PKM bit 8) exist for the plain
+    bf16 mode with packed buffers, S1 = 3, S2 <= 2 and the reference width only."""
+    lay = meta.plan.layers[l]
+    return bool(_act16_env and l in ACT16_LAYERS and meta.packed_mask == 31 and meta.packs16 is not None and meta.nsplit == 1
+                and meta.cfg.S1 == 3 and meta.cfg.S2 <= 2 and lay["MT"] == 16 and lay["KT"] in (16, 32)
+                and os.environ.get("STPDE_BF_SPEC", "1") != "0")
+
+
+ACT16_LAYERS = (1,)
+
+
+def _act16_bytes(meta, l, nt):
+    return nt * meta.plan.layers[l]["KT"] * meta.S * 512
+
+
 def _adj_floats(meta, l, nt):
     """floats of the adjoint buffer of layer l's output rows: the size of the layer buffer, or -- packed mode -- a packed
     ADJOINT buffer, every stream bf16 (layer 0: its value stream only)."""
@@ -437,6 +462,11 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     s["cell"] = torch.empty(Pc, device=dev, dtype=torch.int32)
     s["bufs"] = [None] + [torch.empty(_buf_floats(meta, l, nt), device=dev) for l in range(1, 6)]
     s["z0"] = torch.empty(nt * plan.layers[0]["MT"] * _FRAG, device=dev) if need_grad else None
+    # bf16 mode: the activated inputs of fc1 / fc2 as the bf16 operand blocks their forward passes produce anyway
+    # (stpde_layer_desc.act16) -- the weight gradients read these instead of evaluating the activation jets again
+    s["act16"] = [torch.empty(_act16_bytes(meta, l, nt), device=dev, dtype=torch.uint8) if (need_grad and _act16_layers(meta, l))
+                  else None for l in (1, 2)]
+    ws.act16[0], ws.act16[1] = _dp(s["act16"][0]), _dp(s["act16"][1])
     ws.X, ws.XR, ws.coef, ws.cw, ws.cell = (_dp(s[k]) for k in ("X", "XR", "coef", "cw", "cell"))
     ws.pre[0] = _dp(s["z0"])
     for l in range(1, 6):
@@ -765,6 +795,7 @@ def _per_point_bytes(meta):
     mt0 = plan.layers[0]["MT"]
     cp = (plan.cin + 3) // 4 * 4
     fwd_tile = 4 * (sum(_buf_floats(meta, l, 1) for l in range(1, 6)) + mt0 * _FRAG + 2 * XT * _FRAG)
+    fwd_tile += sum(_act16_bytes(meta, l, 1) for l in (1, 2) if _act16_layers(meta, l))
     fwd = fwd_tile // 2 + 4 * 16 + (4 * 8 if meta.cfg_out.combo else 0) + 4
     bwd_tile = 4 * (_adj_floats(meta, 2, 1) + _adj_floats(meta, 3, 1) + mt0 * 48)
     if meta.packed_mask:
