@@ -109,7 +109,8 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
         for (int st = 0; st < S; ++st) {
           const bf16x4 b4 = to_bf4(B[st]);
           *reinterpret_cast<bf16x4*>(&hb[g & 1][slot][st][lane * 2]) = b4;
-          buf_st8(h16r, h16lane, (kt * S + st) * 512, b4);
+          // (the k-tile index depends on the wave index: through readfirstlane, or every store sits in a waterfall loop)
+          buf_st8(h16r, h16lane, (__builtin_amdgcn_readfirstlane(kt) * S + st) * 512, b4);
         }
       }
     };
