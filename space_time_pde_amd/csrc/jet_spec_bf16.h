@@ -39,7 +39,10 @@
 template <int S1, int S2, int ACT, int NST>
 __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, MCg = 4, GK = 8, KT = GK * NST, KP = KT / 2, ST = S1 == 3 ? 3 : 1;
-  __shared__ __attribute__((aligned(16))) float hb[2][GK][S][128];     // bf16 fragment blocks (512 B each)
+  // bf16 fragment blocks (512 B each); the two k-tiles of a pair sit next to each other per stream, so that a consumer's
+  // K = 32 operand is ONE ds_read2st64_b64 into four consecutive registers (round 4; with [slot][stream] the compiler paired
+  // neighbouring streams instead and re-arranged the registers with 18 v_mov per k-tile pair)
+  __shared__ __attribute__((aligned(16))) float hb[2][GK / 2][S][2][128];
   __shared__ __attribute__((aligned(16))) float tcl[ST][KT][256];      // tangent constants of layer 0 (S1 == 3)
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
 #pragma unroll
         for (int st = 0; st < S; ++st) {
           const bf16x4 b4 = to_bf4(B[st]);
-          *reinterpret_cast<bf16x4*>(&hb[g & 1][slot][st][lane * 2]) = b4;
+          *reinterpret_cast<bf16x4*>(&hb[g & 1][slot >> 1][st][slot & 1][lane * 2]) = b4;
           // (the k-tile index depends on the wave index: through readfirstlane, or every store sits in a waterfall loop)
           buf_st8(h16r, h16lane, (__builtin_amdgcn_readfirstlane(kt) * S + st) * 512, b4);
         }
@@ -158,20 +161,39 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
       return __builtin_bit_cast(bf16x8, buf_ld16(wrs, wlane, ((kp * MT + mt0 + mi) * 64) * 16));
     };
     // The skip GEMM with the raw input (bias through its ones column) and the tangent constants are ADDED to the accumulators
-    // during the steps of the tile (output tiles 2(g-1), 2(g-1)+1 in step g: the consumers' steps stay as long as the
-    // producers'), so that the only work left when the last group is done is the store of the pre-activations.  Every address
+    // during the steps of the tile, so that little work is left when the last group is done.  Every address
     // is descriptor + scalar offset + the lane offset (no per-block address registers).
-    auto skip_part = [&](int mi) {
+    // Round 4: the fragments of an output tile (3 skip-weight blocks + 3 tangent constants) are REQUESTED before the k-tile
+    // pairs of a step and used after them -- the first version loaded each one right in front of its use and the compiler
+    // waited for every single one (s_waitcnt vmcnt(0): six exposed L2 round trips per output tile, tools/micro/isa_waits.py);
+    // one output tile per step-slot (the slot in front of the epilogue takes the last one), so one set of registers.
+    constexpr int PER = MCg / NST, NSK = XT + (S1 == 3 ? 3 : 0);
+    f32x4 sk[PER][NSK];
+    auto skip_load = [&](int slot) {
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) {
-        const f32x4 wv4 = __builtin_bit_cast(f32x4, buf_ld16(srs, wlane, (xt * MT + mt0 + mi) * 1024));
+      for (int p = 0; p < PER; ++p) {
+        const int mi = slot * PER + p;
 #pragma unroll
-        for (int r = 0; r < x_live(xt); ++r) acc[mi][0] = mfma4(wv4[r], xb[0][xt][r], acc[mi][0]);
+        for (int xt = 0; xt < XT; ++xt) sk[p][xt] = __builtin_bit_cast(f32x4, buf_ld16(srs, wlane, (xt * MT + mt0 + mi) * 1024));
+        if (S1 == 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) sk[p][XT + d] = __builtin_bit_cast(f32x4, buf_ld16(trs, wlane, (d * MT + mt0 + mi) * 1024));
+        }
       }
-      if (S1 == 3) {
+    };
+    auto skip_apply = [&](auto slotc) {
+      constexpr int slot = decltype(slotc)::value;
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-          acc[mi][1 + d] += __builtin_bit_cast(f32x4, buf_ld16(trs, wlane, (d * MT + mt0 + mi) * 1024));
+      for (int p = 0; p < PER; ++p) {
+        constexpr int mi0 = slot * PER;
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+          for (int r = 0; r < x_live(xt); ++r) acc[mi0 + p][0] = mfma4(sk[p][xt][r], xb[0][xt][r], acc[mi0 + p][0]);
+        if (S1 == 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc[mi0 + p][1 + d] += sk[p][XT + d];
+        }
       }
     };
     auto epilogue = [&](int tile) {
@@ -200,17 +222,25 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
     // the 4 k-tile pairs of group gg (compile-time) out of ring buffer (gg & 1)
     auto consume = [&](auto ggc) {
       constexpr int gg = decltype(ggc)::value;
+      // stream-major MFMA order (round 4): the operand of stream st is dead after its MCg MFMAs and is re-read for the NEXT
+      // k-tile pair right there, (S - 1) * MCg MFMAs ahead of its use -- the compiler's own schedule read all S operands after
+      // the last MFMA of a pair and waited for them (one exposed LDS latency + 18 v_mov per pair, the MFMA pipe idle)
+      auto rd = [&](int q, int st) -> bf16x8 {
+        return cat8(*reinterpret_cast<const bf16x4*>(&hb[gg & 1][q][st][0][lane * 2]),
+                    *reinterpret_cast<const bf16x4*>(&hb[gg & 1][q][st][1][lane * 2]));
+      };
+      bf16x8 B8[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) B8[st] = rd(0, st);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bf16x8 B8[S];
 #pragma unroll
-        for (int st = 0; st < S; ++st)
-          B8[st] = cat8(*reinterpret_cast<const bf16x4*>(&hb[gg & 1][2 * q][st][lane * 2]),
-                        *reinterpret_cast<const bf16x4*>(&hb[gg & 1][2 * q + 1][st][lane * 2]));
+        for (int st = 0; st < S; ++st) {
 #pragma unroll
-        for (int mi = 0; mi < MCg; ++mi)
-#pragma unroll
-          for (int st = 0; st < S; ++st) acc[mi][st] = mfma_bf(wr[q][mi], B8[st], acc[mi][st]);
+          for (int mi = 0; mi < MCg; ++mi) acc[mi][st] = mfma_bf(wr[q][mi], B8[st], acc[mi][st]);
+          if (q + 1 < 4) B8[st] = rd(q + 1, st);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         // ring: this slot now fetches the pair four ahead (wraps into the next row tile: the weights are the same)
         const int kpn = (4 * gg + q + 4) % KP;          // compile-time after unrolling
 #pragma unroll
@@ -221,7 +251,9 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
       const int tile = (int)blockIdx.x + it * G;        // the producers' tile; step 0 finishes tile - G here
       SPEC_STAMP(it, 0);
       if (it >= 1) {
+        skip_load(NST - 1);
         consume(std::integral_constant<int, NST - 1>{});
+        skip_apply(std::integral_constant<int, NST - 1>{});
         SPEC_STAMP(it, 9);
         epilogue(tile - G);
       }
@@ -239,11 +271,10 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
 #pragma unroll
           for (int xt = 0; xt < XT; ++xt) xb[0][xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);   // for the epilogue
         }
+        skip_load(g - 1);
         consume(std::integral_constant<int, g - 1>{});
-        // this step's share of the skip GEMM (NST = 4: tiles 0,1 / 2,3 / none; NST = 2: all four in step 1)
-        constexpr int per = NST == 2 ? MCg : 2;
-#pragma unroll
-        for (int mi = per * (g - 1); mi < per * g && mi < MCg; ++mi) skip_part(mi);
+        // this step's share of the skip GEMM: output tile(s) (g - 1) * PER ... (the last share runs in front of the epilogue)
+        skip_apply(std::integral_constant<int, g - 1>{});
         SPEC_STAMP(it, 1 + 2 * g);
         __syncthreads();
         SPEC_STAMP(it, 2 + 2 * g);

@@ -6,7 +6,7 @@ mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_lig_jet.py tests/test_gpu_reference_fixtures.py tests/test_gpu_interp_generic.py -m gpu -q -k "bf16 or packed or one_call or g5b" > $O/pytest_bf16.log 2>&1
 echo "pytest rc=$?" >> $O/pytest_bf16.log
 tail -4 $O/pytest_bf16.log
-for sw in 1; do for f in 0 1; do
+for sw in 1; do for f in 0; do
 STPDE_WGRAD_SWAP=$sw STPDE_ACT16=$f python bench.py --no-cpu-baseline --steps 6 --warmup 2 --mlp-precision bf16 > $O/bench_bf16_s${sw}_a$f.json 2> $O/bench_bf16_s${sw}_a$f.err
 done; done
 python - <<'P'
