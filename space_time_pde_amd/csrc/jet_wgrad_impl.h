@@ -957,6 +957,112 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
   }
 }
 
+// Second hidden layer, plain bf16 mode with packed buffers (round 4): k_wgrad_quad<..., 8> above keeps fp32 blocks in LDS --
+// every adjoint block goes bf16 -> fp32 -> four transposing ds_write_b32 -> ds_read_b128 -> v_cvt back to bf16 in EVERY wave
+// and for EVERY k-tile that uses it: 970 VALU instructions per wave and row tile for 80 MFMAs (tools/micro/isa_waits.py), the
+// kernel ran at its VALU issue time (13.3 ms per step for 6.2 ms of HBM traffic).  Same work split here (wave w: adjoint
+// blocks of output tile w into the shared patch, hidden k-tiles 2w / 2w + 1, raw-input tile w), but
+//   * the patches hold bf16 [row][feature] blocks: the adjoint blocks go in as the bytes they are stored as (one
+//     ds_write_b64 per lane, no conversion), the activated blocks after ONE rounding; every operand fragment comes back
+//     through the hardware transpose read ds_read_b64_tr_b16 -- no conversion at the consumers,
+//   * an adjoint fragment is read once per stream and feeds the MFMAs of BOTH k-tiles of the wave,
+//   * the tangent columns of the skip connection (sum over the rows of the tangent-stream adjoints) come out of wave 0's
+//     raw-input accumulator tile: stream d against the pattern [feature == d] (three bf16 MFMAs per output tile) instead
+//     of 72 VALU adds in five waves.
+template <int S1, int S2, int ACT>
+__global__ __launch_bounds__(512, 2) void k_wgrad_oct_bf(WgradArgs a) {
+  constexpr int S = 1 + S1 + S2, NWV = 8, KTT = 16, MCW = 8, KW = 2;
+  static_assert(S1 == 3, "tangent streams expected");
+  __shared__ __attribute__((aligned(16))) __bf16 pshare[S][MCW][256];        // adjoint blocks of the row tile
+  __shared__ __attribute__((aligned(16))) __bf16 ppriv[NWV][KW][S][256];     // activated-input blocks of each wave's k-tiles
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lo = lane * 4;
+  const int g = lane >> 4, c = lane & 15;
+  const int wofs = (lane & 15) * 16 + 4 * (lane >> 4);                                   // this lane's 4 features of its row
+  const int rofs = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + 4 * (lane & 3);         // transpose read (common.h)
+  const bf16x4 zero4 = to_bf4(f32x4{0.f, 0.f, 0.f, 0.f}), one4 = to_bf4(f32x4{1.f, 1.f, 1.f, 1.f});
+  f32x4 acc[MCW][KW + 1];
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi)
+#pragma unroll
+    for (int k = 0; k <= KW; ++k) acc[mi][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float2 praw[S];
+  f32x4 qraw[KW][S];
+  f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_p = [&](int t) {
+    const char* pb = reinterpret_cast<const char*>(a.P) + (size_t)t * (S * MCW * 512) + (size_t)wv * 512 + lane * 8;
+#pragma unroll
+    for (int st = 0; st < S; ++st) praw[st] = *reinterpret_cast<const float2*>(pb + (size_t)st * MCW * 512);
+    if (wv < XT) xr = ld4(a.XR + ((size_t)t * XT + wv) * 256 + lo);
+  };
+  auto load_qk = [&](int t, int k) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) qraw[k][st] = ld_blk_raw(a.Q, 1, t, S, KTT, st, KW * wv + k, lane);
+  };
+  if ((int)blockIdx.x < a.ntiles) {
+    load_p(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) load_qk(blockIdx.x, k);
+  }
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tnext = tile + (int)gridDim.x < a.ntiles ? tile + (int)gridDim.x : tile;
+    float cq[6];
+    load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) *reinterpret_cast<float2*>(&pshare[st][wv][wofs]) = praw[st];
+    const f32x4 xcur = xr;
+    load_p(tnext);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      f32x4 pre[S], H[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) pre[st] = blk_val(qraw[k][st], 1, st);
+      load_qk(tnext, k);
+      act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
+#pragma unroll
+      for (int st = 0; st < S; ++st) *reinterpret_cast<bf16x4*>(&ppriv[wv][k][st][wofs]) = to_bf4(H[st]);
+    }
+    __syncthreads();
+    bf16x4 h16[KW][S];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int st = 0; st < S; ++st) h16[k][st] = lds_read_tr16(&ppriv[wv][k][st][rofs]);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+#pragma unroll
+      for (int mi = 0; mi < MCW; ++mi) {
+        const bf16x4 pa = lds_read_tr16(&pshare[st][mi][rofs]);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[mi][k] = mfma_bf16k(pa, h16[k][st], acc[mi][k]);
+        if (st == 0) {
+          if (wv < XT) {                                   // raw-input tile wv: exact fp32 skip operand (wave-uniform branch)
+            const f32x4 p0 = bf4_to_f32(pa);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][KW] = mfma4(p0[r], xcur[r], acc[mi][KW]);
+          }
+        } else if (st <= 3) {
+          if (wv == 0) acc[mi][KW] = mfma_bf16k(pa, c == st - 1 ? one4 : zero4, acc[mi][KW]);   // tangent column st - 1
+        }
+      }
+    }
+    __syncthreads();        // every wave is done with pshare before the next tile's blocks go in
+  }
+  const int ldw = 16 * (KTT + XT);
+#pragma unroll
+  for (int mi = 0; mi < MCW; ++mi) {
+#pragma unroll
+    for (int k = 0; k <= KW; ++k) {
+      if (k == KW && wv >= XT) continue;
+      const int col = k < KW ? 16 * (KW * wv + k) : 16 * (KTT + wv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r]);
+    }
+  }
+}
+
 template <int S1, int S2, int ACT, int MCW, int KTT>
 static int launch_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
   const int gy = (a.MT + MCW - 1) / MCW;
@@ -1112,6 +1218,11 @@ static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
           ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5))) {
         int gx = 256;                          // one workgroup per CU, persistent
         if (gx > a.ntiles) gx = a.ntiles;
+        static const int octbf = getenv("STPDE_WGRAD_OCT_BF") ? atoi(getenv("STPDE_WGRAD_OCT_BF")) : 1;
+        if (a.pk && octbf) {
+          STPDE_LAUNCH((k_wgrad_oct_bf<S1, S2, ACT>), dim3(gx), dim3(512), 0, stream, a);
+          return stpde_check_launch("k_wgrad_oct_bf");
+        }
         if (a.pk)
           STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 3, true, 8>), dim3(gx), dim3(512), 0, stream, a);
         else
