@@ -969,9 +969,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
 //   * the tangent columns of the skip connection (sum over the rows of the tangent-stream adjoints) come out of wave 0's
 //     raw-input accumulator tile: stream d against the pattern [feature == d] (three bf16 MFMAs per output tile) instead
 //     of 72 VALU adds in five waves.
-template <int S1, int S2, int ACT>
-__global__ __launch_bounds__(512, 2) void k_wgrad_oct_bf(WgradArgs a) {
-  constexpr int S = 1 + S1 + S2, NWV = 8, KTT = 16, MCW = 8, KW = 2;
+// NWV = 4: the same kernel for fc3 (4 output tiles, 8 hidden k-tiles; was k_wgrad_quad<..., 3, true, 4>: 613 VALU per wave and tile).
+template <int S1, int S2, int ACT, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_oct_bf(WgradArgs a) {
+  constexpr int S = 1 + S1 + S2, KTT = 2 * NWV, MCW = NWV, KW = 2;
   static_assert(S1 == 3, "tangent streams expected");
   __shared__ __attribute__((aligned(16))) __bf16 pshare[S][MCW][256];        // adjoint blocks of the row tile
   __shared__ __attribute__((aligned(16))) __bf16 ppriv[NWV][KW][S][256];     // activated-input blocks of each wave's k-tiles
@@ -1109,6 +1110,11 @@ static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
         if (a.KT == 8 && a.MT == 4 && quad && XT == 3 && (a.pk == 0 || a.pk == 5)) {
           int gx = 768;                        // three workgroups per CU, persistent
           if (gx > a.ntiles) gx = a.ntiles;
+          static const int octbf4 = getenv("STPDE_WGRAD_OCT_BF") ? atoi(getenv("STPDE_WGRAD_OCT_BF")) : 1;
+          if (a.pk && octbf4) {
+            STPDE_LAUNCH((k_wgrad_oct_bf<S1, S2, ACT, 4>), dim3(gx), dim3(256), 0, stream, a);
+            return stpde_check_launch("k_wgrad_oct_bf");
+          }
           if (a.pk)
             STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 3, true>), dim3(gx), dim3(256), 0, stream, a);
           else

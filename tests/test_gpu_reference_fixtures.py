@@ -130,8 +130,8 @@ def _assert_bf16_kernels(tr, cfg, dump):
     # bf16 weight gradients with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
     # (the packed-stash instantiations carry two more template arguments: ..., false, true, 1, PKA>)
     assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1", "KC = 8"), dump
-    assert tr.has("k_wgrad_oct_bf", cfg), dump       # layer 2: eight waves on one row tile, bf16 blocks in LDS (round 4)
-    assert tr.has("k_wgrad_quad", "true>)", cfg), dump             # fc3: four waves
+    assert tr.has("k_wgrad_oct_bf", "ACT>)", cfg), dump       # layer 2: eight waves on one row tile, bf16 blocks in LDS (round 4)
+    assert tr.has("k_wgrad_oct_bf", "ACT, 4>)", cfg), dump    # fc3: four waves
     assert not tr.has("k_wgrad_coop", "KC, true, true", cfg), dump
 
 
