@@ -44,6 +44,30 @@ def test_abi_rejects_bad_arguments_without_gpu(hiplib):
         _lib.check(hiplib.stpde_lig_gather(ctypes.byref(g), None, None, None, None, None, None, None, None))
 
 
+def test_fused_residual_block_entry_points_check_arguments(hiplib):
+    """Round 4: stpde_conv3d_fused / stpde_conv3d_wgrad_onload (the convolutions of a ResBlock3D with the BatchNorm work folded
+    in) refuse inconsistent feature combinations before any launch."""
+    from space_time_pde_amd import _lib
+    a = _lib.Conv3dFusedArgs()
+    with pytest.raises(ValueError):                                   # empty descriptor
+        _lib.check(hiplib.stpde_conv3d_fused(ctypes.byref(a), None, None))
+    a.d.B, a.d.T, a.d.Z, a.d.X, a.d.Ci, a.d.Co, a.d.ksize = 1, 2, 2, 2, 16, 16, 3
+    a.x = a.w_pack = a.y = ctypes.c_void_p(256)
+    a.y2, a.wo2_pack, a.Co2 = ctypes.c_void_p(256), ctypes.c_void_p(256), 16
+    with pytest.raises(ValueError):                                   # a second output needs a 1x1x1 kernel
+        _lib.check(hiplib.stpde_conv3d_fused(ctypes.byref(a), None, None))
+    a.d.ksize = 1
+    a.x2, a.w2_pack, a.Ci2 = ctypes.c_void_p(256), ctypes.c_void_p(256), 16
+    with pytest.raises(ValueError):                                   # second input AND second output
+        _lib.check(hiplib.stpde_conv3d_fused(ctypes.byref(a), None, None))
+    d = _lib.Conv3dDesc()
+    d.B, d.T, d.Z, d.X, d.Ci, d.Co, d.ksize = 1, 2, 2, 2, 16, 16, 3
+    with pytest.raises(ValueError):                                   # on-load weight gradient: 1x1x1 only, statistics required
+        _lib.check(hiplib.stpde_conv3d_wgrad_onload(ctypes.byref(d), None, None, None, None, None, None, None, None))
+    b = _lib.BnDesc()
+    assert [f[0] for f in _lib.BnDesc._fields_][-2:] == ["stats_mode", "reduce_done"]
+
+
 def test_one_call_per_direction_entry_points_exist_and_check_arguments(hiplib):
     """SURVEY 8(b): lig_imnet_jet_fwd / lig_imnet_jet_bwd are single entry points of the C ABI (VERDICT r2 #7)."""
     from space_time_pde_amd import _lib
