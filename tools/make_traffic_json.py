@@ -58,4 +58,4 @@ if __name__ == "__main__":
             kernels[name] = dict(symbol=sym, fetch_bytes_corrected=f, write_bytes=w, hbm_bytes_per_launch=f + w)
     json.dump(dict(chunk=int(sys.argv[3]), act=sys.argv[4], kernels=kernels,
                    source="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
-                          "profiles/r3_pmc_fetch_size*.txt / r3_pmc_write_size*.txt"), open(sys.argv[5], "w"), indent=1)
+                          "profiles/r4_pmc_fetch_size*.txt / r4_pmc_write_size*.txt"), open(sys.argv[5], "w"), indent=1)
