@@ -922,10 +922,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
     } else if (S1 == 3) {
       // tangent stream d of a skip connection sees the unit vector e_d: column d of the raw-input block gets the sum over the
       // rows of the adjoint (per-lane partial sums, folded once at the end)
+      // (round 4: the output tiles are dealt to the NWV - XT waves without a raw-input tile -- every one of them used to sum
+      // all of them, and only wave XT's sums were added at the end)
 #pragma unroll
       for (int d = 0; d < 3; ++d)
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) {
+          if (mi % (NWV - XT) != wv - XT) continue;          // wave-uniform
           const f32x4 pd = lds_get_R<TP>(&pshare[1 + d][mi][0], lane);
           acct[d][mi] += (pd[0] + pd[1]) + (pd[2] + pd[3]);
         }
@@ -943,12 +946,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
       for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r]);
     }
   }
-  if (S1 == 3 && wv == XT) {
+  if (S1 == 3 && wv >= XT) {
     // lane (g, c): partial row sums (rows 4g..4g+3 of every tile) of output feature c; fold the four lane groups
 #pragma unroll
     for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
+        if (mi % (NWV - XT) != wv - XT) continue;
         float v = acct[d][mi];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
