@@ -476,7 +476,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     const int next = tile + stride;
     const int nx = next < a.ntiles ? next : tile;   // branch-free tail: the last iteration re-produces its own tile
     f32x4 raw[S][MCW];
-    load_p_raw(nx, raw);                           // lands while the MFMAs below run
+    // (many-stream sets, S >= 8 = configs[4]'s (3,6): the S * MCW in-flight blocks do not fit next to the S * MCW transposed
+    // ones -- 216 ... 432 bytes of scratch per lane -- so those load right in front of the transposes, round 4)
+    constexpr bool EARLYP = S < 8;
+    if (EARLYP) load_p_raw(nx, raw);               // lands while the MFMAs below run
     f32x4 preq[S];
     float cqq[6];
     // bf16-pipe modes: likewise the next tile's activated-input source blocks (first-layer weight gradient 29.3 -> 27.0 ms
@@ -603,6 +606,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         if (!EARLYQ) load_q(nx, preq, cqq);
         finish_q(preq, cqq, buf ^ 1);
       }
+      if (!EARLYP) load_p_raw(nx, raw);
       if (STPDE_ABLATE_W != 2) {
         transpose_p(raw, pa);
         pack_p(raw);
@@ -612,6 +616,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     } else {
       __syncthreads();
       produce(nx, 0);
+      if (!EARLYP) load_p_raw(nx, raw);
       transpose_p(raw, pa);
       pack_p(raw);
       __syncthreads();
