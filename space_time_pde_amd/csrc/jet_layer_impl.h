@@ -728,6 +728,12 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
       if (a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
     }
   }
+  // many-stream sets (S = 10, configs[4]): the cooperative kernel with two output tiles per wave, one workgroup per CU (its
+  // ring takes 80 KB) instead of the per-wave kernel below (round 4: configs[4] step 994 -> 892 ms, first-layer forward 251 -> 183 ms; STPDE_COOP_S10=0: per-wave kernels)
+  if constexpr (S1 + S2 > 5) {
+    static const int coop10 = getenv("STPDE_COOP_S10") ? atoi(getenv("STPDE_COOP_S10")) : 1;
+    if (coop10 && a.KT % 4 == 0 && a.KT >= 8 && a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
+  }
   // kernels that stream their B operand from memory (everything except the layer-0-on-the-fly forward) halve that
   // traffic with 8 output tiles per pass; S=10 would not fit the register file
   if (PRO != PRO_L0 && S1 + S2 <= 5 && a.MT % 8 == 0) return launch_fwd_act_mc<S1, S2, PRO, EPI, 8>(a, stream);
