@@ -722,12 +722,34 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
     return r;
   };
 
+  // packed adjoint blocks (8 bytes per lane and block): the next tile's are requested a tile ahead (round 4)
+  constexpr bool PFP = (PKW & 2) != 0;
+  f32x4 rawn[PFP ? S : 1][PFP ? MCW : 1];
+  auto load_p = [&](int t, f32x4 (*raw)[PFP ? MCW : 1]) {
+    if constexpr (PFP) {
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) {
+          const int mt = mt0 + mi < MT ? mt0 + mi : MT - 1;
+          raw[st][mi] = ld_blk_raw(a.P, 2, t, S, MT, st, mt, lane);
+        }
+    }
+  };
+  if (PFP && (int)(blockIdx.x * 4 + wv) < a.ntiles) load_p(blockIdx.x * 4 + wv, rawn);
 #pragma unroll 1
   for (int tile = blockIdx.x * 4 + wv; tile < a.ntiles; tile += gridDim.x * 4) {
     float cq[6];
     load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
     f32x4 pa[S][MCW];
-    {
+    if constexpr (PFP) {
+#pragma unroll
+      for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(blk_val(rawn[st][mi], 2, st));
+      const int tn = tile + (int)gridDim.x * 4 < a.ntiles ? tile + (int)gridDim.x * 4 : tile;
+      load_p(tn, rawn);
+    } else {
       f32x4 raw[S][MCW];
 #pragma unroll
       for (int st = 0; st < S; ++st)
@@ -741,11 +763,23 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) pa[st][mi] = transpose(blk_val(raw[st][mi], (PKW & 2) ? 2 : 0, st));
     }
+    // (round 4) the input blocks of k-tile ki + 1 and the raw-input fragments are requested before the jets / MFMAs of k-tile
+    // ki: the loop used to load every block right in front of its use -- KTT + 1 exposed HBM round trips per row tile and
+    // wave (tools/micro/isa_waits.py), which three or four waves per SIMD do not cover
+    f32x4 qn[S], xrp[XT];
+#pragma unroll
+    for (int st = 0; st < S; ++st) qn[st] = ld_blk_raw(a.Q, (PKW & 1) ? 1 : 0, tile, S, KTT, st, 0, lane);
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) xrp[xt] = ld4(a.XR + ((size_t)tile * XT + xt) * 256 + lo);   // already the row-major image
 #pragma unroll
     for (int ki = 0; ki < KTT; ++ki) {
       f32x4 pre[S], H[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKW & 1) ? 1 : 0, tile, S, KTT, st, ki, lane);
+      for (int st = 0; st < S; ++st) pre[st] = blk_val(qn[st], (PKW & 1) ? 1 : 0, st);
+      if (ki + 1 < KTT) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) qn[st] = ld_blk_raw(a.Q, (PKW & 1) ? 1 : 0, tile, S, KTT, st, ki + 1, lane);
+      }
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) {
@@ -764,7 +798,7 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
     }
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
-      const f32x4 xr = ld4(a.XR + ((size_t)tile * XT + xt) * 256 + lo);   // already the row-major image
+      const f32x4 xr = xrp[xt];
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
