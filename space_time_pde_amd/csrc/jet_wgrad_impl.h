@@ -49,6 +49,9 @@ struct WgradArgs {
 // Timing-only ablations (tools/micro/ablate_wgrad.py, private builds with -DSTPDE_ABLATE_W=n; results are WRONG):
 // 1 = one partial product instead of six, 2 = abar blocks transposed / split for the first tile only, 3 = no produce stage
 // in the loop, 4 = consumer operands not read from the LDS ring, 5 = no barrier in the loop.
+#ifndef STPDE_QUAD_PIPE
+#define STPDE_QUAD_PIPE 1
+#endif
 #ifndef STPDE_ABLATE_W
 #define STPDE_ABLATE_W 0
 #endif
@@ -936,6 +939,21 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
 #pragma unroll
       for (int st = 0; st < S; ++st) {
         const f32x4 hr = transpose(H[st]);
+        if constexpr (!BFM && STPDE_QUAD_PIPE && NWV == 8) {
+          // exact fp32 (round 4): the adjoint fragment of output tile mi + 1 is requested before the four MFMAs of tile mi (the
+          // compiler read them in pairs and waited for each pair right in front of its MFMAs)
+          f32x4 pc = lds_get_R<TP>(&pshare[st][0][0], lane);
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi) {
+            f32x4 pn = pc;
+            if (mi + 1 < MCW) pn = lds_get_R<TP>(&pshare[st][mi + 1][0], lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][k] = mfma4(pc[r], hr[r], acc[mi][k]);
+            pc = pn;
+          }
+          continue;
+        }
         f32x4 pa[MCW];
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) pa[mi] = lds_get_R<TP>(&pshare[st][mi][0], lane);
