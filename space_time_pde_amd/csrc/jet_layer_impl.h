@@ -38,6 +38,9 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #ifndef STPDE_EPI_PF
 #define STPDE_EPI_PF 1
 #endif
+#ifndef STPDE_EPI_PF_BF
+#define STPDE_EPI_PF_BF 1
+#endif
 #if STPDE_STAMP
 #define STPDE_STAMP_B0 8192
 static __device__ unsigned long long g_stamp[256 * 8 * 16];
@@ -572,16 +575,18 @@ __global__ __launch_bounds__(64 * NW, (!BF && PRO == PRO_ACT && EPI == EPI_FWD &
     // exact-fp32 input-gradient kernels of the hidden layers (round 4): the stashed pre-activation blocks of output tile
     // mi + 1 are requested before the adjoint of tile mi is computed (they were loaded tile by tile right in front of their
     // use: MCg exposed HBM round trips per pass with one co-resident workgroup to cover them).  STPDE_EPI_PF=0: as before.
-    constexpr bool EPF = EPI == EPI_ADJ && !BF && MCg > 1 && STPDE_EPI_PF;
+    // (round 4: also the plain bf16 kernels with their packed stash, STPDE_EPI_PF_BF)
+    constexpr bool EPF = EPI == EPI_ADJ && (!BF || (SPL == 1 && STPDE_EPI_PF_BF)) && MCg > 1 && STPDE_EPI_PF;
     if constexpr (EPF) {
+      constexpr int PMD = (PKM & 4) ? 1 : 0;
       f32x4 prc[S], prn[S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) prc[st] = ld_blk(a.Pre, 0, tile, S, MT, st, mt0, lane);
+      for (int st = 0; st < S; ++st) prc[st] = ld_blk(a.Pre, PMD, tile, S, MT, st, mt0, lane);
 #pragma unroll
       for (int mi = 0; mi < MCg; ++mi) {
         if (mi + 1 < MCg) {
 #pragma unroll
-          for (int st = 0; st < S; ++st) prn[st] = ld_blk(a.Pre, 0, tile, S, MT, st, mt0 + mi + 1, lane);
+          for (int st = 0; st < S; ++st) prn[st] = ld_blk(a.Pre, PMD, tile, S, MT, st, mt0 + mi + 1, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, nullptr, prc);
