@@ -150,6 +150,49 @@ def cpu_baseline(act, chunk=1024, nchunks=16):
                        % (nchunks, chunk, act, best, ncpu, total, times[0], times[len(times) // 2], times[-1], t4k))
 
 
+def other_configs(args):
+    """BASELINE configs[3] and configs[4] in front of the driver: each is a child run of THIS script (its own
+    process: configs[4] alone peaks at 192 GB) after the headline's timed region, >= 5 timed steps, same bracket; the child's
+    whole line is condensed to ms_per_step / points per second / dominant kernel / its fractions."""
+    import gc
+    import subprocess
+    gc.collect()
+    torch.cuda.empty_cache()
+    runs = [("configs[3]", ["--igres", "64", "256", "256", "--mlp-precision", "bf16"]),
+            ("configs[4]", ["--workload", "c5"])]
+    steps, warm = max(5, min(args.steps, 8)), 2
+    out = {}
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm),
+               "--points", str(args.points), "--act", args.act, "--no-cpu-baseline", "--no-other-configs", "--sub"] + extra
+        rec = dict(cmd="python bench.py " + " ".join(cmd[2:]))
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                rec["error"] = "rc %d: %s" % (r.returncode, r.stderr[-400:])
+            else:
+                j = json.loads(line[-1])
+                rf = j["roofline"]
+                rec.update(workload=j["config"]["workload"], dtype=j["dtype"], steps=j["steps"], warmup=j["warmup"],
+                           ms_per_step=round(j["ms_per_step"], 3), value=round(j["value"]), unit=j["unit"],
+                           ms_per_step_hip_event_median=j["ms_per_step_hip_event_median"], peak_GB=j["peak_GB"],
+                           recompute_steps=j["recompute_steps"], loss=j["config"]["loss"],
+                           dominant_kernel=rf["kernel"], dominant_avg_launch_ms=rf["avg_launch_ms"], bound=rf["bound"],
+                           frac=rf["frac"], peak=rf["peak"], achieved=rf["achieved"], roof_unit=rf["unit"],
+                           executed_frac=rf.get("executed_frac"), kernels=rf["kernels"])
+                for side in ("hbm_side", "mfma_side"):
+                    if side in rf:
+                        rec[side] = {k: rf[side][k] for k in ("achieved", "peak", "unit", "frac") if k in rf[side]}
+                for k in ("step_frac_per_gpu", "step_algorithmic_tflops", "stream_set"):
+                    if k in rf:
+                        rec[k] = rf[k]
+        except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
+            rec["error"] = "%s: %s" % (type(e).__name__, e)
+        out[name] = rec
+    return out
+
+
 def _spawn_rank(rank, world, port, argv):
     """One self-spawned rank: the environment torch.distributed.run would have set, then the ordinary main()."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -190,6 +233,10 @@ def main(argv=None):
                     help="device-memory budget of the jet call's stash + scratch (lig_jet.set_memory_budget): above it the "
                          "backward recomputes the forward chunk by chunk; the line reports peak_GB either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` block (BASELINE configs[3] and configs[4], each timed by a child run of this "
+                         "script after the headline's timed region) and the second headline-grade line `value_fp32x3`")
+    ap.add_argument("--sub", action="store_true", help=argparse.SUPPRESS)   # child run of `other_configs`: no side figures
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
     args = ap.parse_args(argv)
@@ -300,7 +347,7 @@ def main(argv=None):
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30      # warm-up + timed steps (allocated, not reserved)
     recompute_steps = lig_jet.stats["recompute_steps"]
     # Per-rank diagnosis of a multi-GPU line (outside the timed region, VERDICT r3 #3c): what THIS rank's step costs with no
-    # collective in it (same shard, same kernels, same overlap of the U-Net backward with the IM-NET weight gradients) and what
+    # collective in it (same shard, same kernels, same STPDE_OVERLAP_UNET_BWD setting -- off by default) and what
     # its replicated U-Net costs alone; rank 0 prints the per-rank lists and ms_per_step - max(compute_ms) as the exposed
     # communication (+ load imbalance) of the timed steps.
     def local_step():
@@ -361,7 +408,7 @@ def main(argv=None):
     # SURVEY 8(d) side figures (outside the timed region, rank 0 of a single-GPU run only): value-only inference rate,
     # the step without the UNet, and the gather stage against its algorithmic 1036 B / point
     side = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.sub:
         import torch.nn.functional as F
         with torch.no_grad():
             latent = unet(crop).permute(0, 2, 3, 4, 1)
@@ -390,25 +437,36 @@ def main(argv=None):
         torch.cuda.synchronize()
         side = dict(inference_value_only_points_per_s=round(3 * args.points / (ev[0].elapsed_time(ev[1]) * 1e-3)),
                     lig_only_step_points_per_s=round(2 * args.points / (ev[2].elapsed_time(ev[3]) * 1e-3)))
-        if args.mlp_precision == "fp32" and not c5:
-            # second figure: the SAME full step with the wide layers' products as exact-split bf16 MFMAs
-            # ("fp32x3": fp32 tolerances incl. the 1e-5 loss bound hold, tests/test_gpu_reference_fixtures.py); the headline
-            # `value` above stays the exact-fp32 MFMA path
+    # Second headline-grade line: the SAME step with the wide layers' products as exact-split bf16 MFMAs
+    # ("fp32x3": every fp32-tolerance parity test is parametrised over it, tests/test_gpu_reference_fixtures.py), timed over the
+    # same --steps with the same bracket as `value`, then two profiled steps for its own dominant-kernel roofline.  `value` /
+    # `dtype` above stay the exact-fp32 MFMA path.
+    x3 = None
+    if rank == 0 and world == 1 and args.mlp_precision == "fp32" and not c5 and not args.sub and not args.no_other_configs:
+        if side is not None:
             del latent
-            lig_jet.set_mlp_precision("fp32x3")
-            try:
+        lig_jet.set_mlp_precision("fp32x3")
+        try:
+            for _ in range(max(1, min(args.warmup, 2))):
                 step()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    l3 = step()
-                e1.record()
-                torch.cuda.synchronize()
-                side["fp32x3_full_step_points_per_s"] = round(3 * args.points / (e0.elapsed_time(e1) * 1e-3))
-                side["fp32x3_full_step_ms"] = round(e0.elapsed_time(e1) / 3, 2)
-                side["fp32x3_loss"] = float(l3)
-            finally:
-                lig_jet.set_mlp_precision("fp32")
+            sync()
+            gc.collect()
+            gc.disable()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                l3 = step()
+            sync()
+            dt3 = time.perf_counter() - t3
+            gc.enable()
+            lig_jet.profile = {}
+            for _ in range(nprof):
+                step()
+            sync()
+            x3 = dict(dt=dt3, loss=float(l3), prof=lig_jet.profile)
+            lig_jet.profile = None
+        finally:
+            lig_jet.set_mlp_precision("fp32")
+            lig_jet.profile = None
 
     if rank == 0:
         smooth = args.act not in ("relu", "leakyrelu")
@@ -545,8 +603,13 @@ def main(argv=None):
                          "exposed_comm_ms": round(1e3 * dt / args.steps - max(r[0] for r in per_rank), 2),
                          "note": "compute_ms = this rank's step on its shard with no collective in it (2 steps after the timed "
                                  "region); unet_*_ms = its replicated U-Net alone, eager launches with their gaps (inside the "
-                                 "step the backward runs beside the IM-NET weight gradients); exposed_comm_ms = ms_per_step - "
-                                 "max(compute_ms): exchange + load imbalance not hidden behind compute"},
+                                 "step the backward runs %s); exposed_comm_ms = ms_per_step - "
+                                 "max(compute_ms): exchange + load imbalance not hidden behind compute"
+                                 % ("beside the IM-NET weight gradients of the last launch chunk (STPDE_OVERLAP_UNET_BWD=1)"
+                                    if os.environ.get("STPDE_OVERLAP_UNET_BWD", "0") == "1" else
+                                    "after the IM-NET backward on the same stream: STPDE_OVERLAP_UNET_BWD=0, the default -- "
+                                    "the side-stream overlap was measured slower, profiles/r4_overlap_timeline.txt"),
+                         "overlap_unet_bwd": os.environ.get("STPDE_OVERLAP_UNET_BWD", "0") == "1"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -568,6 +631,40 @@ def main(argv=None):
                        "loss": float(loss)},
             "roofline": roofline,
         }
+        if x3 is not None:
+            # fp32x3: the wide layers issue SIX bf16 MFMA products per fp32 product, so the pipe that bounds its kernels is the
+            # bf16 one: its dominant kernel's executed bf16 work (combined-stream jet) against the dense bf16 peak
+            k3 = {}
+            for name, evs in x3["prof"].items():
+                ms = [a.elapsed_time(b) for a, b in evs]
+                k3[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
+            dom3 = max(k3, key=lambda k: k3[k]["total_ms"])
+            lps3 = k3[dom3]["launches"] / float(nprof)
+            rows3 = 8 * n_local / lps3
+            exe3 = 2.0 * macs_x.get(dom3, 0) * rows3 / (k3[dom3]["avg_ms"] * 1e-3) / 1e12
+            alg3 = 2.0 * macs.get(dom3, 0) * rows3 / (k3[dom3]["avg_ms"] * 1e-3) / 1e12
+            ms3 = 1e3 * x3["dt"] / args.steps
+            out["value_fp32x3"] = args.points * args.steps / x3["dt"]
+            out["ms_per_step_fp32x3"] = ms3
+            out["dtype_fp32x3"] = ("f32 via 3xbf16 split, f32 accumulate: every fp32 operand of the hidden-to-hidden GEMMs of the two "
+                                   "wide IM-NET layers (forward, input gradient, first-layer weight gradient) split exactly into "
+                                   "three bf16 terms, six partial products on the bf16 MFMA pipe; everything else exact f32; same "
+                                   "fp32 parity tolerances as `value` (tests parametrised over both modes)")
+            out["loss_fp32x3"] = x3["loss"]
+            out["roofline_fp32x3"] = dict(
+                bound="mfma", kernel=dom3, achieved=round(6.0 * exe3, 2), peak=2500.0, unit="TFLOP/s",
+                frac=round(6.0 * exe3 / 2500.0, 4), avg_launch_ms=round(k3[dom3]["avg_ms"], 3), launches_per_step=lps3,
+                fp32_equivalent_tflops=round(exe3, 2), algorithmic_fp32_tflops=round(alg3, 2),
+                algorithmic_over_fp32_mfma_peak=round(alg3 / PEAK_F32_TFLOPS, 4),
+                step_algorithmic_tflops=round(step_flop_pt * args.points / (ms3 * 1e-3) / 1e12, 2),
+                step_over_fp32_mfma_peak=round(step_flop_pt * args.points / (ms3 * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4),
+                note="achieved = executed bf16 MFMA work of the dominant kernel (6 partial products per fp32 product of the "
+                     "combined-stream jet) / launch time, against the dense bf16 peak; *_over_fp32_mfma_peak = the fp32 FLOP "
+                     "rate it stands for over the exact-fp32 MFMA peak (157.3): a speed-up figure, may exceed 1; timed over "
+                     "the same --steps as `value`, HIP-event kernel times from %d extra steps" % nprof,
+                kernels={k: round(v["total_ms"] / nprof, 2) for k, v in sorted(k3.items())})
+        if world == 1 and not args.sub and not args.no_other_configs and not c5 and args.mlp_precision == "fp32":
+            out["other_configs"] = other_configs(args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.act)
         sys.stdout.flush()

@@ -833,13 +833,15 @@ def _avail_bytes(meta, device):
 def _stash_bytes(meta, P):
     fwd, bwd = _per_point_bytes(meta)
     last = _chunk_ranges(meta, P)[-1][1]
-    return P * fwd + min(P, meta.chunk) * bwd + last * _two_phase_bytes(meta)
+    # (the dgrad-first scratch of the last chunk only when the point-sharded step's hooks are installed: ADVICE r4)
+    two = _two_phase_bytes(meta) if sync_hooks else 0
+    return P * fwd + min(P, meta.chunk) * bwd + last * two
 
 
 def _recompute_chunk(meta, device):
     """Largest power-of-two chunk whose stash + backward scratch takes at most half of the available memory."""
     fwd, bwd = _per_point_bytes(meta)
-    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd + _two_phase_bytes(meta))))
+    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd + (_two_phase_bytes(meta) if sync_hooks else 0))))
     c = 1 << (n.bit_length() - 1)
     mult = 8 if meta.S == 1 else 2
     return max(mult, min(c, DEFAULT_CHUNK))

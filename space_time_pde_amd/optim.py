@@ -43,7 +43,10 @@ class FusedClipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0, flat=True):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_grad=clip_grad))
+        # ``flat`` travels in ``defaults`` (what Optimizer.__getstate__ serialises), so a deepcopy / pickle of an optimizer
+        # built with flat=False comes back with flat=False
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_grad=clip_grad,
+                                      flat=bool(flat)))
         self._use_flat = bool(flat)
         self._flat = {}          # id(group) -> dict(P, G, M, V, offs, views...)
 
@@ -55,12 +58,13 @@ class FusedClipAdam(torch.optim.Optimizer):
         super().__setstate__(state)
         for group in self.param_groups:
             group.setdefault("clip_grad", self.defaults["clip_grad"])
+            group.setdefault("flat", self.defaults.get("flat", True))
             if group.get("amsgrad") or group.get("maximize"):
                 raise ValueError("FusedClipAdam does not implement amsgrad / maximize")
         self._flat = {}          # loaded state tensors are fresh allocations: rebuild the flat views on the next step
         # Optimizer.__getstate__ serialises defaults / state / param_groups only: an instance that comes back from
-        # copy.deepcopy or pickle has no ``_use_flat`` yet (flat mode is the default of __init__)
-        self._use_flat = bool(getattr(self, "_use_flat", True))
+        # copy.deepcopy or pickle takes its mode from ``defaults`` (it used to come back as flat=True)
+        self._use_flat = bool(self.defaults.get("flat", getattr(self, "_use_flat", True)))
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

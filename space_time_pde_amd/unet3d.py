@@ -437,6 +437,13 @@ def _fused_ok(blk, x):
         return False
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.numel() // x.shape[-1] >= 2):
         return False
+    # limits of stpde_conv3d_fused itself: fewer than 2^27 voxels (int32 voxel arithmetic of the fold-ins), all
+    # parameters on the input's device -- outside them the layer-wise path runs instead of an error from inside the node
+    if x.numel() // x.shape[-1] >= (1 << 27):
+        return False
+    mods = (blk.conv1, blk.conv2, blk.conv3, blk.shortcut, blk.bn1, blk.bn2, blk.bn3)
+    if any(p.device != x.device for m in mods for p in m.parameters(recurse=False)):
+        return False
     if not all(_hip_conv_ok(x, c) for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut)):
         return False
     if blk.conv1.weight.shape[2] != 1 or blk.conv2.weight.shape[2] != 3 or blk.conv3.weight.shape[2] != 1 \
@@ -649,12 +656,14 @@ class _ResBlockHip(torch.autograd.Function):
         # weight (+ bias) gradients: (conv, input, output gradient, kernel size, channels, on-load transform of the input)
         jobs = [(2, y2, dy3, 1, cn, co, ev3, True), (3, xin, dsc, 1, cip, co, ev3, False),
                 (1, h1, dy2, 3, cn, cn, ev2, False), (0, xin, dy1, 1, cip, cn, ev1, False)]
-        need_w = any(ctx.needs_input_grad[i] for i in (2, 4, 6, 8))
+        # per convolution: its weight gradient (inputs 2, 4, 6, 8) or its bias gradient (3, 5, 7, 9) is wanted -- a block with
+        # frozen weights and trainable biases still gets its bias gradients (the kernel produces both from one pass)
+        need = [ctx.needs_input_grad[2 + 2 * k] or (has_b[k] and ctx.needs_input_grad[3 + 2 * k]) for k in range(4)]
         gw = [None] * 4
         gb = [None] * 4
         for k, xi, gy, ks, ci_, co_, ev, onload in jobs:
-            if not need_w:
-                break
+            if not need[k]:
+                continue
             dwt, dfr = ctx.dw[k]
             ctx.dw[k] = (None, dfr)                     # the zero-filled slice of the per-step buffer is used once
             cd = _lib.Conv3dDesc()
@@ -682,8 +691,9 @@ class _ResBlockHip(torch.autograd.Function):
                 dbt = torch.zeros(co_, device=dev) if has_b[k] else None
                 launch(dwt, dbt)
                 cin = ci if k in (0, 3) else ci_
-                gw[k] = dwt[:, :, :cin].permute(1, 2, 0).reshape(co_, cin, ks, ks, ks)
-                gb[k] = dbt
+                if ctx.needs_input_grad[2 + 2 * k]:
+                    gw[k] = dwt[:, :, :cin].permute(1, 2, 0).reshape(co_, cin, ks, ks, ks)
+                gb[k] = dbt if ctx.needs_input_grad[3 + 2 * k] else None
         if _ResBlockHip.debug is not None:
             _ResBlockHip.debug.update(dy3=dy3, dsc=dsc, dz2=dz2, dy2=dy2, dz1=dz1, dy1=dy1, dx=dx, y1=y1, h1=h1, y2=y2, y3=y3,
                                       done=done.value)

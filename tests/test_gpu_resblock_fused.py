@@ -68,6 +68,7 @@ CASES = [  # (B, T, Z, X), in, neck, out, final_relu
     ((1, 16, 64, 64), 16, 16, 32, True),        # 65,536 voxels: one voxel tile per wave, no tap split
     ((1, 32, 128, 128), 16, 16, 32, True),      # full-resolution level of configs[1]: four voxel tiles per wave
     ((1, 32, 128, 128), 32, 32, 32, False),
+    ((1, 64, 256, 256), 16, 16, 32, True),      # full-resolution level of configs[3]: 4,194,304 voxels
 ]
 
 
@@ -193,3 +194,25 @@ assert err < 2e-5
         env = dict(os.environ, STPDE_CONV_WGRAD_LDS_GX=gx, PYTHONPATH=root)
         out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_fused_block_frozen_weights_still_deliver_bias_gradients(hiplib):
+    """a block whose convolution WEIGHTS are frozen but whose biases train must still get its bias gradients
+    from the fused node (it gated all weight AND bias jobs on the weights alone); same values as the layer-wise path."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    blk = unet3d.ResBlock3D(32, 16, 32, final_relu=True).to(dev).train()
+    for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
+        c.weight.requires_grad_(False)
+    x = torch.randn(1, 4, 8, 8, 32, device=dev)
+    cot = torch.randn(1, 4, 8, 8, 32, device=dev)
+    fus, yf, gxf = _run(blk, x, cot, True)
+    lay, yl, gxl = _run(blk, x, cot, False)
+    assert _rel(yf, yl) < 1e-5 and _rel(gxf, gxl) < 1e-4
+    for name in ("conv1", "conv2", "conv3", "shortcut"):
+        cf, cl = getattr(fus, name), getattr(lay, name)
+        assert cf.weight.grad is None and cl.weight.grad is None
+        assert cf.bias.grad is not None, name
+        # (a bias in front of a training-mode BatchNorm has an exactly-zero gradient: compare absolutely)
+        assert (cf.bias.grad - cl.bias.grad).abs().max().item() <= 1e-4 * max(1.0, cl.bias.grad.abs().max().item()), name
+    assert fus.shortcut.bias.grad.abs().max().item() > 0

@@ -268,3 +268,189 @@ def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_pat
             assert (a - b).abs().max().item() <= 5e-6 * b.abs().max().item() + 1e-12
         for a, b in zip(other["g_un"], plain["g_un"]):
             assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-10
+
+
+@pytest.mark.gpu
+def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
+    """BASELINE configs[3] as ONE composite (VERDICT r4 #3b; reference experiments/rb2d/train.py:58-77 at C4 size): the
+    training-mode UNet3d on the (64, 256, 256) grid (fused residual blocks, deferred weight gradients) + the bf16-MFMA
+    LIG / IM-NET path on 2^20 query points + RB2 residuals + L1 losses + backward, all through ``sharded_step``.
+
+    Asserted: the HIP jet path carried the call, the bf16 kernels of the benchmarked configuration were the ones dispatched,
+    every residual block took the fused node, a finite loss and a finite gradient for every parameter.  U-Net gradients vs
+    the layer-wise path: at this depth the training-mode U-Net is numerically chaotic (its deepest BatchNorms normalise
+    over a handful of voxels, DESIGN 2a: two runs of the SAME code differ in the last bits of their atomics and from there
+    by per cents), so element-wise equality of two runs is not defined.  The bound used instead is the repository's G8-style
+    one: the layer-wise path may differ from the fused path by no more than 3x what the fused path differs from ITSELF run
+    to run (+ a small absolute term), on the loss and on gradient norms from the full-resolution levels to the deepest one;
+    the fused kernels are pinned element-wise at this volume in tests/test_gpu_resblock_fused.py."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
+    from space_time_pde_amd.train_step import sharded_step
+    dev = torch.device("cuda:0")
+    igres, n_pts = (64, 256, 256), 1 << 20
+    torch.manual_seed(1)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES["softplus"]).to(dev)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256).to(dev).train()
+    layer = physics.get_rb2_pde_layer(mean=(0.01, 0.0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                      x_crop=1., use_continuity=True)
+    g = torch.Generator().manual_seed(0)
+    crop = torch.randn(1, 4, *igres, generator=g).to(dev)
+    pts = torch.rand(1, n_pts, 3, generator=g).to(dev)
+    tgt = torch.randn(1, n_pts, 4, generator=g).to(dev)
+    names = ("conv_in.conv2.weight", "down_modules.0.conv2.weight", "conv_mid.conv2.weight", "up_modules.0.conv2.weight",
+             "conv_out.conv3.weight", "conv_out.shortcut.weight")
+    n_blocks = len([m for m in unet.modules() if isinstance(m, unet3d.ResBlock3D)])
+    monkeypatch.setattr(lig_jet, "mlp_precision", "bf16")
+
+    def run(fused, trace=False):
+        monkeypatch.setenv("STPDE_FUSED_RESBLOCK", "1" if fused else "0")
+        for p in list(unet.parameters()) + list(net.parameters()):
+            p.grad = None
+        calls, blocks = lig.stats["hip_jet_calls"], unet3d.stats["fused_resblocks"]
+        tr = _lib.dispatch_trace() if trace else None
+        if tr:
+            tr.__enter__()
+        loss, reg, pde = sharded_step(unet, net, layer, crop, pts, tgt, n_pts, 1.0, 0.0125, "l1")
+        torch.cuda.synchronize()
+        if tr:
+            tr.__exit__(None, None, None)
+        assert lig.stats["hip_jet_calls"] == calls + 1, "HIP jet path was not taken"
+        assert unet3d.stats["fused_resblocks"] - blocks == (n_blocks if fused else 0)
+        assert torch.isfinite(loss) and torch.isfinite(reg) and torch.isfinite(pde)
+        prm = dict(unet.named_parameters())
+        for k, p in list(prm.items()) + [("imnet." + k, p) for k, p in net.named_parameters()]:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        gn = [prm[n].grad.double().norm().item() for n in names]
+        gim = [p.grad.double().norm().item() for p in net.parameters()]
+        return float(loss), float(reg), float(pde), gn, gim, (tr.kernels if tr else None)
+
+    a = run(True, trace=True)
+    kernels = a[5]
+    for needle in ("k_fc1_fwd_spec", "k_wgrad_oct_bf", "k_tail_fwd_bf", "k_tail_bwd_bf", "k_conv_fused"):
+        assert any(needle in k for k in kernels), (needle, kernels)
+    assert any(("k_fc1_bwd_fused" in k) or ("k_fc1_dgrad_spec" in k) for k in kernels), kernels
+    assert lig_jet.stats["recompute_steps"] == 0 or torch.cuda.get_device_properties(0).total_memory < 200e9
+    a2 = run(True)
+    b = run(False)
+    for i, what in enumerate(("loss", "reg", "pde")):
+        noise = abs(a2[i] - a[i])
+        assert abs(b[i] - a[i]) <= 3 * noise + 2e-2 * abs(a[i]), (what, a[i], a2[i], b[i])
+    for n, ga, ga2, gb in zip(names, a[3], a2[3], b[3]):
+        noise = abs(ga2 - ga) / ga
+        assert abs(gb - ga) / ga <= 3 * noise + 5e-2, (n, ga, ga2, gb)
+    for ga, ga2, gb in zip(a[4], a2[4], b[4]):
+        noise = abs(ga2 - ga) / ga
+        assert abs(gb - ga) / ga <= 3 * noise + 5e-2, (ga, ga2, gb)
+
+
+# ---- multi-rank readiness on ONE device (VERDICT r4 #8): BASELINE configs[4]'s 4-way split and configs[2]'s 8-way split ------
+C5_VARS = ("x, y, t", "c, u, v, w, p")
+C5_EQS = {
+    "adv_diff": "dif(c,t)+u*dif(c,x)+v*dif(c,y)-0.01*(dif(dif(c,x),x)+dif(dif(c,y),y))",
+    "prod_rule": "dif(u*c,x)+dif(v*c,y)",
+    "mixed": "dif(dif(c,x),y)-w*p",
+    "explicit_x": "x*dif(p,x)+t*dif(dif(p,t),t)",
+}
+
+
+def _shard_build(dev, kind):
+    """kind "c5": BASELINE configs[4]'s layer (5-output user-string equations; small grid, 2^14 points);
+    kind "c2": BASELINE configs[1] / [2]'s workload (latent [1,32,128,128,32], ImNet nf = 32, RB2 + continuity; 2^19 points).
+    The encoder runs in evaluation mode: a well-conditioned map (training mode at this depth is chaotic)."""
+    from space_time_pde_amd import implicit_net, nonlinearities, pde as pde_module, physics, unet3d
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    if kind == "c5":
+        igres, n_pts, n_out = (8, 32, 32), 1 << 14, 5
+        layer = pde_module.PDELayer(*C5_VARS)
+        for name, eq in C5_EQS.items():
+            layer.add_equation(eq, name)
+    else:
+        igres, n_pts, n_out = (32, 128, 128), 1 << 19, 4
+        layer = physics.get_rb2_pde_layer(mean=(0.01, 0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                          x_crop=1., use_continuity=True)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=igres, nf=16, mf=256).to(dev).eval()
+    with torch.no_grad():
+        for m in unet.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.copy_((0.1 * torch.randn(m.num_features, generator=g)).to(dev))
+                m.running_var.copy_((0.6 + 0.2 * torch.rand(m.num_features, generator=g)).to(dev))
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=n_out, nf=32,
+                             activation=nonlinearities.NONLINEARITIES["softplus"]).to(dev)
+    crop = torch.randn(1, 4, *igres, generator=g).to(dev)
+    pts = (0.02 + 0.96 * torch.rand(1, n_pts, 3, generator=g)).to(dev)
+    tgt = torch.randn(1, n_pts, n_out, generator=g).to(dev)
+    return unet, net, layer, crop, pts, tgt
+
+
+def _shard_worker(rank, world, port, out, kind):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from space_time_pde_amd import local_implicit_grid as lig
+    from space_time_pde_amd.train_step import sharded_step
+    unet, net, layer, crop, pts, tgt = _shard_build(dev, kind)
+    n = pts.shape[1] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    recorded = []
+    real = dist.all_reduce
+
+    def spy(t, *a, **k):
+        recorded.append((int(t.numel()), bool(k.get("async_op", False))))
+        return real(t, *a, **k)
+
+    dist.all_reduce = spy
+    calls = lig.stats["hip_jet_calls"]
+    try:
+        loss, reg, pde = sharded_step(unet, net, layer, crop, pts[:, sl].contiguous(), tgt[:, sl].contiguous(),
+                                      pts.shape[1], 1.0, 0.0125, "l1")
+    finally:
+        dist.all_reduce = real
+    torch.cuda.synchronize()
+    assert lig.stats["hip_jet_calls"] == calls + 1, "HIP jet path was not taken on rank %d" % rank
+    # exactly three collectives per step on every rank: d latent, the flat IM-NET gradient, the three loss statistics
+    assert len(recorded) == 3 and recorded[-1] == (3, False), recorded
+    assert recorded[0][0] == crop.shape[2] * crop.shape[3] * crop.shape[4] * 32, recorded
+    if rank == 0:
+        torch.save(dict(loss=loss.cpu(), reg=reg.cpu(), pde=pde.cpu(), g_im=[p.grad.cpu() for p in net.parameters()],
+                        g_un=[p.grad.cpu() for p in unet.parameters()], collectives=recorded), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("c5", 4), ("c2", 8)])
+def test_many_ranks_on_one_gpu_gloo_step_equals_single_rank(hiplib, tmp_path, kind, world):
+    """BASELINE configs[4] (4 x MI355X) and configs[2] (8 x MI355X, 2^16-point shards of the configs[1] workload) as far as
+    ONE device can carry them: `world` processes share cuda:0, every rank runs the HIP path on its contiguous shard of the
+    query points, the partial d latent / IM-NET gradients / loss statistics are exchanged over gloo (RCCL refuses several
+    ranks per device).  Asserted on every rank: the HIP jet path carried the shard, exactly three collectives per step;
+    on rank 0: losses and all gradients equal the single-rank step on the whole point set (reference: train_ddp.py:361-368,
+    401-406 -- averaged gradients of the shards = gradient of the global mean loss)."""
+    import socket
+    import torch.multiprocessing as mp
+    from space_time_pde_amd.train_step import sharded_step
+    torch.cuda.empty_cache()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / ("rank0_%s.pt" % kind))
+    mp.spawn(_shard_worker, args=(world, port, out, kind), nprocs=world, join=True)
+    got = torch.load(out)
+    dev = torch.device("cuda:0")
+    unet, net, layer, crop, pts, tgt = _shard_build(dev, kind)
+    loss, reg, pde = sharded_step(unet, net, layer, crop, pts, tgt, pts.shape[1], 1.0, 0.0125, "l1", distributed=False)
+    for k, v in (("loss", loss), ("reg", reg), ("pde", pde)):
+        assert abs(float(got[k]) - float(v)) < 1e-5 * abs(float(v)), k
+    for a, p in zip(got["g_im"], net.parameters()):
+        assert (a - p.grad.cpu()).abs().max().item() < 2e-4 * p.grad.abs().max().item() + 1e-9
+    gmax = max(p.grad.abs().max().item() for p in unet.parameters())
+    for (name, p), a in zip(unet.named_parameters(), got["g_un"]):
+        assert (a - p.grad.cpu()).abs().max().item() < 2e-3 * p.grad.abs().max().item() + 1e-5 * gmax, name

@@ -230,6 +230,6 @@ def test_fused_clip_adam_survives_deepcopy_and_pickle():
     for flat in (True, False):
         opt = FusedClipAdam([p], lr=1e-3, clip_grad=0.5, flat=flat)
         for clone in (copy.deepcopy(opt), pickle.loads(pickle.dumps(opt))):
-            assert clone._use_flat in (True, flat) and clone._flat == {}
+            assert clone._use_flat == flat and clone._flat == {}
             assert clone.param_groups[0]["clip_grad"] == 0.5
             clone.step()          # no gradients anywhere: nothing to launch, but every attribute step() reads must exist

@@ -12,18 +12,31 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from space_time_pde_amd import _lib, unet3d  # noqa: E402
 
 
+CONV_CALLS = ("stpde_conv3d_fwd", "stpde_conv3d_wgrad", "stpde_conv3d_wgrad_bias", "stpde_conv3d_wgrad_onload",
+              "stpde_conv3d_fused")
+
+
 class _Proxy:
+    """Brackets every convolution entry point of the library with a pair of events (round 5: the fused residual-block calls
+    stpde_conv3d_fused / stpde_conv3d_wgrad_bias / stpde_conv3d_wgrad_onload as well -- round 4's tables came out empty
+    because only the layer-wise entry points were wrapped).  Weight gradients that the U-Net defers to its side stream are
+    bracketed on THAT stream (the events are recorded on the current stream of the call)."""
+
     def __init__(self, real, rec):
         self._real, self._rec = real, rec
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if name not in ("stpde_conv3d_fwd", "stpde_conv3d_wgrad"):
+        if name not in CONV_CALLS:
             return fn
 
         def wrapped(desc, *args):
-            d = C.cast(desc, C.POINTER(_lib.Conv3dDesc)).contents
-            key = (name[6:], d.B * d.T * d.Z * d.X, d.Ci, d.Co, d.ksize)
+            d = C.cast(desc, C.POINTER(_lib.Conv3dFusedArgs if name == "stpde_conv3d_fused" else _lib.Conv3dDesc)).contents
+            ci2 = co2 = 0
+            if name == "stpde_conv3d_fused":
+                ci2, co2 = d.Ci2 if d.x2 else 0, d.Co2 if d.y2 else 0
+                d = d.d
+            key = (name[6:], d.B * d.T * d.Z * d.X, d.Ci + ci2, d.Co + co2, d.ksize)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(desc, *args)
@@ -70,6 +83,7 @@ def main():
     tot = 0.0
     print("%-14s %9s %4s %4s %2s %6s %9s %9s %8s" % ("kernel", "nvox", "Ci", "Co", "k", "calls", "ms/step", "us/call", "TFLOP/s"))
     for (kind, nvox, ci, co, k), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        # (a two-output call -- conv1 + shortcut -- reads Ci once for Co + Co2 outputs; a two-input call sums Ci + Ci2 inputs)
         flop = 2.0 * nvox * ci * co * k ** 3
         print("%-14s %9d %4d %4d %2d %6d %9.3f %9.1f %8.1f" % (kind, nvox, ci, co, k, n // 3, ms / 3, 1e3 * ms / n,
                                                               flop / (ms / n * 1e-3) / 1e12))
