@@ -473,7 +473,8 @@ def main(argv=None):
         # piecewise-linear activations have identically zero second-order MLP jets.  c5: the equation set needs
         # 4 second-order jets (xx, yy, xy, tt); SURVEY: "replace 32*4 by 32*5 in M and T"
         n2_alg = (4 if c5 else 2) if smooth else 0
-        n2_exe = (6 if c5 else 1) if smooth else 0       # c5: four pairs padded to the compiled (3,6) stream set
+        s34 = os.environ.get("STPDE_S34", "1") != "0"    # c5: the four named pairs on the (3,4) stream set (round 5), or padded to (3,6)
+        n2_exe = ((4 if s34 else 6) if c5 else 1) if smooth else 0
         macs, M, T = algorithmic_macs(n_second=n2_alg, cout=n_out)
         fwd_flop_pt = 2 * 8 * (M + (3 + n2_alg) * T)
         step_flop_pt = 3 * fwd_flop_pt
@@ -519,6 +520,7 @@ def main(argv=None):
                         kernels_note="ms per step of each kernel family, HIP events on the launch stream, from %d extra "
                                      "steps run after the timed region" % nprof,
                         kernels={k: round(v["total_ms"] / nprof, 2) for k, v in sorted(kern.items())})
+        roofline["stream_set"] = [3 if (smooth or True) else 0, n2_exe]      # (S1, S2) the MLP kernels carry
         if "gather" in kern:   # the gather stage in isolation is HBM-bound: algorithmic 1036 B per point
             g_ms = kern["gather"]["avg_ms"]
             g_pts = n_local * nprof / float(kern["gather"]["launches"])        # points per launch, averaged like g_ms
@@ -620,9 +622,10 @@ def main(argv=None):
                       if args.mlp_precision == "fp32x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4]: latent [1,%d,%d,%d,32], 2^%d query points, 5-output user-string "
-                                    "equations %s (3 inputs x, y, t; second derivatives xx, yy, xy, tt -> the (3,6) stream set), "
+                                    "equations %s (3 inputs x, y, t; second derivatives xx, yy, xy, tt -> the (3,%d) stream set), "
                                     "ImNet nf=32 out_features=5 %s, L1 losses, backward to ImNet + UNet3d parameters"
-                                    % (igres + (args.points.bit_length() - 1, json.dumps(C5_EQS), args.act))) if c5 else
+                                    % (igres + (args.points.bit_length() - 1, json.dumps(C5_EQS), 4 if os.environ.get("STPDE_S34", "1") != "0" else 6,
+                                       args.act))) if c5 else
                                    "BASELINE configs[%d]: latent [1,%d,%d,%d,32], 2^%d query points, RB2 "
                                    "(3 transport + continuity), ImNet nf=32 %s, L1 losses, backward to ImNet + UNet3d parameters"
                                    % ((3 if (bf16 and igres == (64, 256, 256)) else 1,) + igres + (args.points.bit_length() - 1, args.act)),

@@ -666,7 +666,7 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     // 4 output tiles per wave: weight fragments through the 3-deep register ring (-2.5 % on the forward of the widest
     // layer; no gain for the 2-tile-per-wave shapes).  STPDE_WRING=0 switches it off.
     static const int wring_env = getenv("STPDE_WRING") ? atoi(getenv("STPDE_WRING")) : 1;
-    if constexpr (NW == 4 && MCg == 4) {
+    if constexpr (NW == 4 && MCg == 4 && S1 + S2 <= 5) {      // (S = 8: the ring's 48 fragment registers spill)
       if (wring_env && a.KT >= 8) {
         STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false, 1, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
         return stpde_check_launch("k_layer_coop");
@@ -737,6 +737,12 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
   // ring takes 80 KB) instead of the per-wave kernel below (round 4: configs[4] step 994 -> 892 ms, first-layer forward 251 -> 183 ms; STPDE_COOP_S10=0: per-wave kernels)
   if constexpr (S1 + S2 > 5) {
     static const int coop10 = getenv("STPDE_COOP_S10") ? atoi(getenv("STPDE_COOP_S10")) : 1;
+    // S = 8 (round 5, the (3,4) set of configs[4]): its forward kernels also fit four output tiles per wave without scratch
+    // (250 registers, 64 KB ring: two workgroups per CU) -- half the ring reads per MFMA; STPDE_COOP_S8_MC4=0: two tiles
+    if constexpr (S1 + S2 == 7 && EPI == EPI_FWD) {
+      static const int mc4 = getenv("STPDE_COOP_S8_MC4") ? atoi(getenv("STPDE_COOP_S8_MC4")) : 1;   // (measured: configs[4] 690.0 -> 682.4 ms)
+      if (mc4 && coop10 && a.KT % 4 == 0 && a.KT >= 8 && a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4, 4>(a, stream);
+    }
     if (coop10 && a.KT % 4 == 0 && a.KT >= 8 && a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
   }
   // kernels that stream their B operand from memory (everything except the layer-0-on-the-fly forward) halve that
@@ -770,5 +776,6 @@ int stpde_layer_launch_0_0(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_0(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_1(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_2(const LayerArgs& a, int mode, hipStream_t stream);
+int stpde_layer_launch_3_4(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_3_6(const LayerArgs& a, int mode, hipStream_t stream);
 int stpde_layer_launch_0_3(const LayerArgs& a, int mode, hipStream_t stream);   // value-tile mode: 4 row tiles per pass

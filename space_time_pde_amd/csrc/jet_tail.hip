@@ -378,6 +378,7 @@ static int tail_fwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float*
   if (S1 == 3 && S2 == 0) return launch_tail_act<3, 0>(a, nf16, (hipStream_t)stream);
   if (S1 == 3 && S2 == 1 && cfg->combo && cw) return launch_tail_act<3, 1>(a, nf16, (hipStream_t)stream);
   if (S1 == 3 && S2 == 2) return launch_tail_act<3, 2>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 4) return launch_tail_act<3, 4>(a, nf16, (hipStream_t)stream);
   if (S1 == 0 && S2 == 3) return launch_tail_act<0, 3>(a, nf16, (hipStream_t)stream);   // value tiles: ntiles = row tiles / 4
   stpde_set_error("jet_tail_fwd: stream configuration S1=%d S2=%d not compiled", S1, S2);
   return STPDE_E_UNSUPPORTED;
@@ -408,7 +409,7 @@ struct TailBwdArgs {
 // its MFMAs (compiler listing: ~30 `global_load ; s_waitcnt vmcnt(0..1)` pairs per row tile), with two waves per SIMD (252
 // registers) to cover HBM / L2 round trips of 1-2 us each: 0.45 of the fp32 pipe.
 template <int S1, int S2, int ACT, int NFT>
-__global__ __launch_bounds__(256, 2) void k_tail_bwd(TailBwdArgs a) {
+__global__ __launch_bounds__(256, (1 + S1 + S2 >= 8 && NFT == 2) ? 1 : 2) void k_tail_bwd(TailBwdArgs a) {   // (S = 8: 552-700 B of scratch at two waves per SIMD)
   constexpr int S = 1 + S1 + S2;
   constexpr int T2 = 4 * NFT, T3 = 2 * NFT, T4 = NFT;     // feature tiles of the outputs of layers 2, 3, 4
   const int lane = threadIdx.x & 63;
@@ -728,6 +729,7 @@ static int tail_bwd(const stpde_jet_cfg* cfg, int ntiles, int nf16, const float*
   if (S1 == 3 && S2 == 0) return launch_tailb_act<3, 0>(a, nf16, (hipStream_t)stream);
   if (S1 == 3 && S2 == 1 && cfg->combo && cw) return launch_tailb_act<3, 1>(a, nf16, (hipStream_t)stream);
   if (S1 == 3 && S2 == 2) return launch_tailb_act<3, 2>(a, nf16, (hipStream_t)stream);
+  if (S1 == 3 && S2 == 4) return launch_tailb_act<3, 4>(a, nf16, (hipStream_t)stream);
   stpde_set_error("jet_tail_bwd: stream configuration S1=%d S2=%d not compiled", S1, S2);
   return STPDE_E_UNSUPPORTED;
 }

@@ -7,6 +7,7 @@ static int dispatch_streams(const WgradArgs& a, int mode, hipStream_t stream) {
   if (S1 == 3 && S2 == 0) return stpde_wgrad_launch_3_0(a, mode, stream);
   if (S1 == 3 && S2 == 1 && a.cfg.combo && a.cw) return stpde_wgrad_launch_3_1(a, mode, stream);
   if (S1 == 3 && S2 == 2) return stpde_wgrad_launch_3_2(a, mode, stream);
+  if (S1 == 3 && S2 == 4) return stpde_wgrad_launch_3_4(a, mode, stream);
   if (S1 == 3 && S2 == 6) return stpde_wgrad_launch_3_6(a, mode, stream);
   stpde_set_error("stream configuration S1=%d S2=%d not compiled", S1, S2);
   return STPDE_E_UNSUPPORTED;

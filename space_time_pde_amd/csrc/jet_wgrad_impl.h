@@ -1281,8 +1281,12 @@ static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
     // bf16 operands with packed buffers (the three-term split mode keeps the ring kernel)
     static const int oct = getenv("STPDE_WGRAD_OCT") ? atoi(getenv("STPDE_WGRAD_OCT")) : 1;
     if constexpr (S1 == 3 && S1 + S2 <= 5) {
+      // "fp32x3" (a.bf16 == 3, round 5): the exact-fp32 eight-wave kernel as well -- 25.7 ms per 2^20 points against 26.0 + 8.0
+      // for the split ring kernel and its separate raw-input launch; the mode is a contract on accuracy, not on the pipe
+      // (STPDE_X3_FC2_QUAD=0: the split kernels)
+      static const int x3quad = getenv("STPDE_X3_FC2_QUAD") ? atoi(getenv("STPDE_X3_FC2_QUAD")) : 1;
       if (oct && a.KT == 16 && a.MT == 8 && XT == 3 && a.SP == 1 + S1 + S2 && a.XR &&
-          ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5))) {
+          ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5) || (a.bf16 == 3 && a.pk == 0 && x3quad))) {
         int gx = 256;                          // one workgroup per CU, persistent
         if (gx > a.ntiles) gx = a.ntiles;
         static const int octbf = getenv("STPDE_WGRAD_OCT_BF") ? atoi(getenv("STPDE_WGRAD_OCT_BF")) : 1;
@@ -1339,4 +1343,5 @@ int stpde_wgrad_launch_0_0(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_0(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_1(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_2(const WgradArgs& a, int mode, hipStream_t stream);
+int stpde_wgrad_launch_3_4(const WgradArgs& a, int mode, hipStream_t stream);
 int stpde_wgrad_launch_3_6(const WgradArgs& a, int mode, hipStream_t stream);

@@ -42,7 +42,7 @@ stpde_layer_desc layer_desc(int ntiles, const stpde_imnet_plan* p, int l, const 
 bool tail_ok(const stpde_imnet_plan* p, const stpde_jet_cfg& c, const float* cw, bool value_tiles) {
   if (p->nlayers != 6 || (p->nf16 != 1 && p->nf16 != 2)) return false;
   if (value_tiles) return true;
-  const bool set = (c.S1 == 0 && c.S2 == 0) || (c.S1 == 3 && (c.S2 == 0 || c.S2 == 1 || c.S2 == 2));
+  const bool set = (c.S1 == 0 && c.S2 == 0) || (c.S1 == 3 && (c.S2 == 0 || c.S2 == 1 || c.S2 == 2 || c.S2 == 4));
   return set && (c.S2 != 1 || cw);
 }
 

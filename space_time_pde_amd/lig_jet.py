@@ -217,6 +217,8 @@ class ImNetPlan:
 # stream configuration
 # ------------------------------------------------------------------------------------------------------------
 CANON_PAIRS = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+# stream sets (S1, S2) the fused fc3 -> fc5 kernels (csrc/jet_tail.hip) and the dgrad-first two-phase backward are compiled for
+TAIL_SETS = ((0, 0), (3, 0), (3, 1), (3, 2), (3, 4))
 
 
 def make_cfg(act, act_param, first, pairs, combo=None):
@@ -240,6 +242,9 @@ def make_cfg(act, act_param, first, pairs, combo=None):
         s1, s2, pp = 3, 0, []
     elif len(pairs) <= 2:
         s1, s2, pp = 3, 2, pairs + [pairs[-1]] * (2 - len(pairs))
+    elif len(pairs) <= 4 and os.environ.get("STPDE_S34", "1") != "0":
+        # (round 5: BASELINE configs[4] names four second derivatives and ran padded to six; STPDE_S34=0 = the padded set)
+        s1, s2, pp = 3, 4, pairs + [pairs[-1]] * (4 - len(pairs))
     elif len(pairs) <= 6:
         s1, s2, pp = 3, 6, pairs + [pairs[-1]] * (6 - len(pairs))
     else:
@@ -520,7 +525,7 @@ def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None,
     pd = _plan_desc(meta, packs)
     flags = _flags(meta, True)
     two_phase = (after_dlatent is not None and fused_tail and tan0_rowsum and plan.nf in (16, 32) and SP0 in (1, 4)
-                 and (meta.cfg.S1, meta.cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2)) and (meta.cfg.S2 != 1 or saved["cw"] is not None))
+                 and (meta.cfg.S1, meta.cfg.S2) in TAIL_SETS and (meta.cfg.S2 != 1 or saved["cw"] is not None))
 
     def call(fl):
         check(_lib.lib().stpde_lig_imnet_jet_bwd(C.byref(pd), C.byref(meta.cfg), C.byref(meta.cfg_out), C.byref(meta.cfg_val),
@@ -586,7 +591,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
         lcfg.S1, lcfg.S2, lcfg.act, lcfg.act_param = 0, 3, cfg.act, cfg.act_param
         lnt = nt // 4
     # fc3 -> fc4 -> fc5 in one kernel (inter-layer data in registers) for the reference widths and the training stream sets
-    tail = (fused_tail and plan.nf in (16, 32) and (vt or ((cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
+    tail = (fused_tail and plan.nf in (16, 32) and (vt or ((cfg.S1, cfg.S2) in TAIL_SETS
                                                            and (cfg.S2 != 1 or cw is not None))))
     for l in range(1, 6):
         lay = plan.layers[l]
@@ -655,7 +660,7 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
     # fc5 -> fc4 -> fc3 input gradients in one kernel (adjoints of layers 4 and 3 feed the next GEMM from the registers).
     # Order: wgrad_5 (needs the pre-activations of fc4's output intact), the chain (abar4 in place; abar3 / abar2 into
     # fresh buffers because wgrad_4 / wgrad_3 still need the pre-activations they would overwrite), wgrad_4, wgrad_3.
-    tail = (fused_tail and plan.nf in (16, 32) and (cfg.S1, cfg.S2) in ((0, 0), (3, 0), (3, 1), (3, 2))
+    tail = (fused_tail and plan.nf in (16, 32) and (cfg.S1, cfg.S2) in TAIL_SETS
             and (cfg.S2 != 1 or cw is not None))
     abar = {l: bufs[l] for l in range(1, 6)}      # where the adjoint of layer l's output rows lives once it exists
     if meta.packed_mask:           # packed ADJOINT buffers are a format of their own: none of them goes over a stash

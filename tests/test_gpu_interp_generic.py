@@ -80,13 +80,15 @@ def test_cell_index_bit_exact_in_gather_kernel(hiplib, golden_dir, tag):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("s2", [4, 6])
 @pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
-def test_generic_equations_config5_style(hiplib, golden_dir, prec, monkeypatch):
+def test_generic_equations_config5_style(hiplib, golden_dir, prec, s2, monkeypatch):
     """G9: 5-channel user-string PDELayer (products, mixed 2nd derivative, explicit coordinates) on the HIP jet path."""
     # VERDICT r3 #8(i): the same test, same tolerances, with the wide layers' products as exact-split bf16 MFMAs ("fp32x3")
     from space_time_pde_amd import lig_jet as _lj
     monkeypatch.setattr(_lj, "mlp_precision", prec)
-    from space_time_pde_amd import implicit_net, local_implicit_grid as lig, pde
+    monkeypatch.setenv("STPDE_S34", "1" if s2 == 4 else "0")      # the (3,4) stream set (default) / padded to (3,6)
+    from space_time_pde_amd import _lib, implicit_net, local_implicit_grid as lig, pde
     d = _load(golden_dir, "g9_generic.npz")
     net = implicit_net.ImNet(dim=3, in_features=32, out_features=5, nf=16, activation=torch.nn.Softplus).to(DEV)
     with torch.no_grad():
@@ -100,8 +102,10 @@ def test_generic_equations_config5_style(hiplib, golden_dir, prec, monkeypatch):
         layer.add_equation(str(eq), str(name))
     layer.update_forward_method(lambda q: lig.query_local_implicit_grid(net, lat, q, 0., 1.))
     n0 = lig.stats["hip_jet_calls"]
-    pred, res = layer(pts)
-    assert lig.stats["hip_jet_calls"] == n0 + 1                    # 4 second-order pairs -> the (3,6) stream set
+    with _lib.dispatch_trace() as tr:
+        pred, res = layer(pts)
+    assert lig.stats["hip_jet_calls"] == n0 + 1                    # 4 second-order pairs -> the (3,4) stream set
+    assert tr.has("S1 = 3, S2 = %d" % s2), "\n".join(tr.kernels)
     np.testing.assert_allclose(pred.detach().cpu().numpy(), d["pred"], rtol=2e-5, atol=2e-6)
     for name in d["names"]:
         ref = d["res_" + str(name)]
@@ -213,7 +217,7 @@ def test_full_size_step_subset_vs_oracle_and_additivity(hiplib, prec, grid, monk
 
 def test_config5_full_size_properties(hiplib):
     """VERDICT r3 #1c -- BASELINE configs[4] at ITS size: the 5-output user-string equation set (bench.py C5_EQS = the strings
-    of fixture G9: products, a mixed second derivative, explicit coordinates -> stream set (3,6), S = 10) on 2^20 points over
+    of fixture G9: products, a mixed second derivative, explicit coordinates -> stream set (3,4), S = 8; round 4: padded to (3,6)) on 2^20 points over
     the [1,32,128,128,32] grid, ImNet nf = 32, through whichever of stash / recomputation the memory plan picks:
     (a) a random subset of the points equals the oracle's reverse-sweep autograd on just that subset;
     (b) chunk invariance: one 2^20-point launch chunk and 2^18-point chunks give bit-identical jets;
@@ -247,7 +251,11 @@ def test_config5_full_size_properties(hiplib):
     r0 = lig_jet.stats["recompute_steps"]
     with _lib.dispatch_trace() as tr:
         pred, res, gl, gp = run(slice(0, N))
-    assert tr.has("S1 = 3, S2 = 6") and tr.has("k_residual_bwd"), "\n".join(sorted(set(tr.kernels)))
+    # round 5: exactly the four second derivatives the strings name (xx, yy, xy, tt) -> the (3,4) stream set, S = 8, with the
+    # fused fc3 -> fc5 kernels; nothing of the padded (3,6) set
+    assert tr.has("S1 = 3, S2 = 4") and tr.has("k_residual_bwd") and tr.has("k_tail_fwd") and tr.has("k_tail_bwd"), \
+        "\n".join(sorted(set(tr.kernels)))
+    assert not tr.has("S1 = 3, S2 = 6"), "\n".join(sorted(set(tr.kernels)))
     print("config5 full size: recompute path taken =", lig_jet.stats["recompute_steps"] > r0)
     assert all(torch.isfinite(v).all() for v in [pred, gl] + gp + list(res.values()))
     # (a) subset vs the oracle (reference formulation: one reverse sweep per dif, fp32 like the reference)
@@ -264,12 +272,12 @@ def test_config5_full_size_properties(hiplib):
         # second derivatives carry 1/cubesize^2 = 127^2 (the fp32 reference itself: max-rel ~2e-4 per point, SURVEY a-Q8)
         err = (res[k][:, sel].cpu() - v.detach()).abs() / v.detach().abs().max()
         assert err.median().item() < 1e-5 and err.max().item() < 1e-3, (k, err.max().item())
-    # (b) chunk invariance of the forward (all ten streams)
+    # (b) chunk invariance of the forward (all eight streams)
     pairs = ((0, 0), (0, 1), (1, 1), (2, 2))
     with torch.no_grad():
         a, _ = lig_jet.lig_jets(net, latd, ptsd, 0., 1., True, pairs, chunk_points=1 << 20)
         b, _ = lig_jet.lig_jets(net, latd, ptsd, 0., 1., True, pairs, chunk_points=1 << 18)
-    assert a.shape[0] == 10 and torch.equal(a, b)
+    assert a.shape[0] == 8 and torch.equal(a, b)
     del a, b
     # (c) additivity over the two halves of the points
     _, _, gl1, gp1 = run(slice(0, N // 2))

@@ -336,12 +336,14 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
     for i, what in enumerate(("loss", "reg", "pde")):
         noise = abs(a2[i] - a[i])
         assert abs(b[i] - a[i]) <= 3 * noise + 2e-2 * abs(a[i]), (what, a[i], a2[i], b[i])
+    # (the deepest level of this grid holds ONE voxel: its training-mode BatchNorm output is its bias, conv_mid's weight
+    # gradient is exactly zero in every path -- hence absolute differences)
     for n, ga, ga2, gb in zip(names, a[3], a2[3], b[3]):
-        noise = abs(ga2 - ga) / ga
-        assert abs(gb - ga) / ga <= 3 * noise + 5e-2, (n, ga, ga2, gb)
+        assert abs(gb - ga) <= 3 * abs(ga2 - ga) + 5e-2 * abs(ga) + 1e-12, (n, ga, ga2, gb)
     for ga, ga2, gb in zip(a[4], a2[4], b[4]):
-        noise = abs(ga2 - ga) / ga
-        assert abs(gb - ga) / ga <= 3 * noise + 5e-2, (ga, ga2, gb)
+        assert abs(gb - ga) <= 3 * abs(ga2 - ga) + 5e-2 * abs(ga) + 1e-12, (ga, ga2, gb)
+    print("configs[3] composite: loss fused %.6f / fused again %.6f / layer-wise %.6f; U-Net gradient norms %s / %s / %s"
+          % (a[0], a2[0], b[0], ["%.3e" % v for v in a[3]], ["%.3e" % v for v in a2[3]], ["%.3e" % v for v in b[3]]))
 
 
 # ---- multi-rank readiness on ONE device: BASELINE configs[4]'s 4-way split and configs[2]'s 8-way split ------
