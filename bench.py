@@ -60,6 +60,7 @@ def algorithmic_macs(nf=32, cin=32, cout=4, n_first=3, n_second=2):
         macs["layer%d_dgrad" % l] = S * hidden
         macs["layer%d_wgrad" % l] = S * hidden + skip
     macs["layer0_wgrad"] = dz * widths[0]
+    macs["layer1_bwd"] = macs["layer1_dgrad"] + macs["layer1_wgrad"]       # bf16 mode: one kernel (csrc/jet_fc1_bwd.hip)
     T = sum(widths[l - 1] * widths[l] for l in range(1, 6))          # hidden-to-hidden blocks: every stream
     M = T + dz * sum(widths[:5])                                       # value pass also has the raw-input blocks
     return macs, M, T
@@ -81,6 +82,9 @@ def algorithmic_bytes(S, smooth_sp0=4, nf=32, cin=32, cout=4, packed=False):
             by["layer%d_dgrad" % l] = adj(l) + ((stash(l - 1) + adj(l - 1)) if l > 1 else xb + (4 + 2) * widths[0])
             by["layer%d_wgrad" % l] = adj(l) + (stash(l - 1) if l > 1 else 4 * widths[0]) + 2 * xb     # (l = 1: the z0 stash)
         by["layer0_wgrad"] = 2 * widths[0] + xb
+        # fused backward of the first hidden layer: the adjoint tile once for both products + once more for the raw-input
+        # columns' own launch, z0 read, layer-0 adjoint written
+        by["layer1_bwd"] = 2 * adj(1) + (4 + 2) * widths[0] + 2 * xb
         return by
     for l in range(1, 6):
         out_b, in_b = 4 * S * widths[l], (4 * S * widths[l - 1] if l > 1 else 0)

@@ -217,6 +217,21 @@ int stpde_jet_layer_bwd_to(const stpde_layer_desc* d, const float* abar_out, con
 int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* XR,
                     const float* tanc0, float* dW_aug, const float* cw, void* stream);
 
+/* bf16 mode, first hidden layer of the reference width (round 5): stpde_jet_wgrad(first_hidden) + stpde_jet_layer_bwd(first_hidden)
+ * in ONE call -- one kernel reads the packed adjoint tile of fc1's rows once (LDS) for both products, W1h^T abar1 and
+ * abar1^T act_jet(z0), and evaluates the activation jet of every z0 element once for the layer-0 adjoint and for the weight
+ * gradient's operand blocks (csrc/jet_fc1_bwd.hip; the backward of src/implicit_net.py:48-54 through fc1 that loss.backward(),
+ * experiments/rb2d/train.py:77, performs).  d: the description stpde_jet_layer_bwd takes for this layer (first_hidden = 1,
+ * KT = 32, MT = 16, mfma_bf16 = 1, packed bits 2 and 4, S1 = 3, S2 = 0 or the combined stream).  abar1: packed ADJOINT buffer
+ * of fc1's rows; WhT_pack_bf16: bf16 pack of W1h^T; z0 / tanc0 / cw / XR as for the two calls it replaces; abar0 (packed
+ * ADJOINT blocks of the value stream, must not alias z0), abar0_tan ([tile][32][3][16] row sums) as stpde_jet_layer_bwd writes
+ * them; dW_aug: fc1's block of the flat gradient buffer (accumulated with fp32 atomics).
+ * stpde_jet_fc1_bwd_supported(d) != 0 iff this call serves d (STPDE_FC1_FUSED=0 switches it off for A/B timing). */
+int stpde_jet_fc1_bwd_supported(const stpde_layer_desc* d);
+int stpde_jet_fc1_bwd(const stpde_layer_desc* d, const float* abar1, const void* WhT_pack_bf16, const float* z0,
+                      const float* tanc0, const float* cw, const float* XR, float* abar0, float* abar0_tan, float* dW_aug,
+                      float* act_param_bar, void* stream);
+
 /* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
  * jets[(s*n_out + ch)*ldp + p] (ldp >= P lets a chunk of points write into a larger [S][n_out][Ptotal] array)
  * from out_pre[tile][S][1][64][4] (fc5 output) and coef; and its adjoint. */

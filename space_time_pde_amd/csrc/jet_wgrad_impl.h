@@ -37,6 +37,7 @@ struct WgradArgs {
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
   int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
   int pk;              // packed-buffer flags (common.h: ld_blk): 1 = Q (the layer input's pre-activations), 4 = P (abar_out)
+  int xonly;           // launch the raw-input k-group only (the hidden k-tiles were done by k_fc1_bwd_fused, jet_fc1_bwd.hip)
   int swap;            // plain bf16 mode: the second wave of every SIMD runs the two phases of an iteration in the other order
   int xfold;           // fp32 hidden-group launches: the (k-group, k-slot) pairs 0 .. XT-1 also contract their abar blocks with
                        // raw-input tile 0 .. XT-1 (one extra 16x16 tile per wave, the XR fragment straight from memory), and all
@@ -54,6 +55,12 @@ struct WgradArgs {
 #endif
 #ifndef STPDE_ABLATE_W
 #define STPDE_ABLATE_W 0
+#endif
+#ifndef STPDE_X3_XFOLD
+#define STPDE_X3_XFOLD 1     // fp32x3: raw-input k-tiles folded into the hidden-group launch of the split kernel (round 5)
+#endif
+#ifndef STPDE_X3_EARLYP
+#define STPDE_X3_EARLYP 0
 #endif
 // Padded row length TP (floats) of a transposed (feature-major) LDS block.  Under the per-instruction banking of gfx950
 // (MI355X_MICROARCH.md, LDS): TP = 24 makes the ds_read_b128 of a block conflict-free and its four ds_write_b32 2-way
@@ -317,20 +324,26 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // column-major abar blocks (per lane and feature over all tiles; folded over the 16 rows at the end).  Not the split mode:
   // its kernel has no registers left (248 VGPRs).
   constexpr bool XB = !HASX && BF && SPL == 1;
+  // ... and the three-term split mode (round 5, XS): the raw-input fragment split into three bf16 terms like every operand of
+  // that mode (six partial products per output tile: fp32-accurate), the tangent columns through the pattern operand with all
+  // three terms of the adjoint.  It used to keep a separate launch for the three raw-input k-tiles that re-read and re-split
+  // every adjoint block of the layer (15.8 ms per 2^20 points for the first hidden layer); the registers come from loading
+  // the next tile's adjoint blocks right in front of their split instead of a tile ahead (EARLYP below).
+  constexpr bool XS = !HASX && BF && SPL == 3 && STPDE_X3_XFOLD;
   const int xslot = (kz - a.kz0) * (NW / NM) + ks;
   const int xsel = xslot < XT ? xslot : XT - 1;
-  f32x4 accx[(XF || XB) ? MCW : 1];
+  f32x4 accx[(XF || XB || XS) ? MCW : 1];
   float acct[XF && S1 == 3 ? 3 : 1][XF ? MCW : 1];
   // XB, wave of raw-input tile 0: the tangent columns (the tangent "input" of a skip connection is the unit vector e_d) go
   // through the same accumulator tile as the value product -- stream d of the second operand is the pattern [feature == d]
   // -- two more MFMAs per row tile instead of 24 accumulator registers and 48 VALU instructions (round 4; those registers
   // are what the double-buffered ring reads below needed)
   const bf16x4 one4 = to_bf4(f32x4{1.f, 1.f, 1.f, 1.f});
-  const bool tanw = XB && S1 == 3 && xslot == 0;
+  const bool tanw = (XB || XS) && S1 == 3 && xslot == 0;
   const bf16x4 e0 = (tanw && c == 0) ? one4 : zero4;
   const bf16x8 x8t = cat8((tanw && c == 1) ? one4 : zero4, (tanw && c == 2) ? one4 : zero4);
   f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (XF || XB) {
+  if constexpr (XF || XB || XS) {
 #pragma unroll
     for (int mi = 0; mi < MCW; ++mi) accx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -349,6 +362,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       if constexpr (S1 == 3) {
 #pragma unroll
         for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[0][1][mi], x8t, accx[mi]);
+      }
+    }
+  };
+  auto xs_mma = [&]() {
+    if constexpr (XS) {
+      bf16x4 xt3[3];
+      f32x4 v = xr;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        xt3[t] = to_bf4(v);
+        if (t < 2) v -= bf4_to_f32(xt3[t]);
+      }
+      constexpr int TP[6] = {1, 0, 2, 0, 1, 0}, TH[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int q6 = 0; q6 < 6; ++q6) {
+        // second stream slot of the operand: tangent stream 0 against the pattern [feature == 0] (exact in bf16: only the
+        // products with the pattern's single term, i.e. TH == 0, carry it -- all three terms of the adjoint)
+        const bf16x8 x8 = cat8(xt3[TH[q6]], (S1 == 3 && TH[q6] == 0) ? e0 : zero4);
+#pragma unroll
+        for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[TP[q6]][0][mi], x8, accx[mi]);
+      }
+      if constexpr (S1 == 3) {
+#pragma unroll
+        for (int k = 2; k >= 0; --k)
+#pragma unroll
+          for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[k][1][mi], x8t, accx[mi]);
       }
     }
   };
@@ -385,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     load_p_raw(tile, raw);
     transpose_p(raw, pa);
     pack_p(raw);
-    if constexpr (XF || XB) {
+    if constexpr (XF || XB || XS) {
       if (a.xfold) xr = ld4(a.XR + ((size_t)tile * XT + xsel) * 256 + lo);
     }
   }
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     f32x4 raw[S][MCW];
     // (many-stream sets, S >= 8 = configs[4]'s (3,6): the S * MCW in-flight blocks do not fit next to the S * MCW transposed
     // ones -- 216 ... 432 bytes of scratch per lane -- so those load right in front of the transposes, round 4)
-    constexpr bool EARLYP = S < 8;
+    constexpr bool EARLYP = S < 8 && !(XS && !STPDE_X3_EARLYP);
     if (EARLYP) load_p_raw(nx, raw);               // lands while the MFMAs below run
     f32x4 preq[S];
     float cqq[6];
@@ -493,6 +532,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     if constexpr (XB) {
       xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
       xb_mma();
+    }
+    if constexpr (XS) {
+      xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
+      xs_mma();
     }
     if constexpr (XF) {
       // branch-free: without xfold the pointer is this launch's own XR anyway and the results are simply not written
@@ -603,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       }
     }
     }
-    if constexpr (XF || XB) xr = xrn;
+    if constexpr (XF || XB || XS) xr = xrn;
     if (NBUF == 2) {
       if (STPDE_ABLATE_W != 3) {
         if (!EARLYQ) load_q(nx, preq, cqq);
@@ -640,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * kq + c, acc[mi][ki][r]);
     }
   }
-  if constexpr (XB) {
+  if constexpr (XB || XS) {
     if (a.xfold && xslot < XT) {
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
@@ -1207,14 +1250,15 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   // compiled for take the exact-fp32 kernels (round 4; they used to be refused)
   constexpr bool SPLIT_OK = KC >= 4 && S1 + S2 <= 4;
   const int bfm = (a.bf16 == 3 && !SPLIT_OK) ? 0 : a.bf16;
-  const bool xfold = xfold_env && (!bfm || (bfm == 1 && KC >= 4)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
+  static const int x3fold_env = getenv("STPDE_X3_XFOLD") ? atoi(getenv("STPDE_X3_XFOLD")) : 1;
+  const bool xfold = xfold_env && !a.xonly && (!bfm || (bfm == 1 && KC >= 4) || (bfm == 3 && KC >= 4 && STPDE_X3_XFOLD && x3fold_env)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
   static const int swap_env = getenv("STPDE_WGRAD_SWAP") ? atoi(getenv("STPDE_WGRAD_SWAP")) : 1;
   a.swap = swap_env;
   for (int part = 0; part < 2; ++part) {
     a.kz0 = part == 0 ? 0 : nhid;
     a.gz = part == 0 ? nhid : ngr - nhid;
     a.xfold = (xfold && part == 0) ? 1 : 0;
-    if (a.gz <= 0 || (xfold && part == 1)) continue;
+    if (a.gz <= 0 || (xfold && part == 1) || (a.xonly && part == 0)) continue;
     int gx = 512 / (a.gy * a.gz);           // ~2 rounds of one 8-wave workgroup per CU
     if (gx > a.ntiles) gx = a.ntiles;
     gx = (gx + 7) / 8 * 8;

@@ -255,6 +255,21 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
                                  stream);
     });
   };
+  // bf16 mode, reference width: weight gradient + input gradient of the first hidden layer in one kernel (jet_fc1_bwd.hip)
+  auto fc1_fused_ok = [&]() -> bool {
+    if (!wgrad || !split0) return false;
+    stpde_layer_desc d = layer_desc(nt, p, 1, cfg, p->mfma_bf16 ? p->mfma_bf16 : 0);
+    d.packed = packed_flags(p, 1, 0);
+    return p->WhT16[1] && stpde_jet_fc1_bwd_supported(&d) != 0 && abar0 != z0;
+  };
+  auto fc1_fused = [&] {
+    stpde_layer_desc d = layer_desc(nt, p, 1, cfg, p->mfma_bf16);
+    d.packed = packed_flags(p, 1, 0);
+    seq([&] {
+      return stpde_jet_fc1_bwd(&d, abar[1], p->WhT16[1], z0, p->tanc[0], ws->cw, ws->XR, abar0, ws->tan0,
+                               dW_flat + p->dw_off[1], act_param_bar, stream);
+    });
+  };
   auto dlatent_part = [&] {
     if (!dlatent) return;
     stpde_xbar_desc xd{};
@@ -293,11 +308,14 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
       if (wgrad) wgrad_l(5);
       tail_bwd();
       dgrad_l(2);
-      dgrad_l(1);
+      if (fc1_fused_ok())
+        fc1_fused();          // (fc1's weight gradient comes with its input gradient: phase B skips it)
+      else
+        dgrad_l(1);
       dlatent_part();
     }
     if (phaseB && wgrad) {
-      for (int l = 4; l >= 1; --l) wgrad_l(l);
+      for (int l = 4; l >= (fc1_fused_ok() ? 2 : 1); --l) wgrad_l(l);
       wgrad_0();
     }
     return seq.rc;
@@ -305,6 +323,10 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   // one call: weight gradient of layer l, then its input gradient (which overwrites what the weight gradient read)
   seq([&] { return stpde_lig_reduce_bwd(cfg_out, S, gd->P, p->cout, jets_bar, ldp, ws->coef, ws->pre[NL - 1], stream); });
   for (int l = NL - 1; l >= 1; --l) {
+    if (l == 1 && fc1_fused_ok()) {
+      fc1_fused();
+      continue;
+    }
     if (wgrad) wgrad_l(l);
     if (tail && l >= 3) {
       if (l == 5) tail_bwd();

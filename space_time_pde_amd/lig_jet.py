@@ -675,6 +675,14 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
         dwg = _layer_desc(nt, lay, cfg, l == 1, (meta.nsplit if wgrad_split or meta.nsplit == 1 else 0)
                           if (w16 is not None and lay["MT"] >= 8) else 0, _pk(meta, l, -1) & 5)
         off, mp, ka = plan.dw_off[l]
+        if (l == 1 and meta.need_wgrad and split0 and w16 is not None and abar0 is not z0
+                and L.stpde_jet_fc1_bwd_supported(C.byref(d))):
+            # bf16 mode, reference width (round 5): weight gradient + input gradient of the first hidden layer in ONE kernel
+            # (csrc/jet_fc1_bwd.hip: one read of the adjoint tile, one activation-jet evaluation per z0 element)
+            with _timed("layer1_bwd"):
+                check(L.stpde_jet_fc1_bwd(C.byref(d), ptr(abar[1]), ptr(w16), ptr(z0), ptr(pv(packs, 0, "tanc")), ptr(cw),
+                                          ptr(XR), ptr(abar0), ptr(tan0), ptr(dw_flat[off:off + mp * ka]), ptr(pbar), st))
+            continue
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
                 check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(abar[l]), ptr(bufs[l - 1]) if l > 1 else ptr(saved["z0"]),
@@ -733,15 +741,18 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
                 check(L.stpde_lig_xbar_scatter(C.byref(xd), ab, wt, ptr(cell), ptr(dlatent), st))
         else:
             # deterministic scatter: per-row adjoints, then a per-node gather in fixed order over the cell-sorted points
+            # (the same three library calls the one-call path makes, scratch allocated OUTSIDE the timed region: with torch.sort /
+            # index_add_ / cumsum in here the caching allocator's stalls showed up as a 60-75 ms "kernel" in bench.py's table)
             cp = (plan.cin + 3) // 4 * 4
             xrows = torch.empty(Pc * 8 * cp, device=dev)
+            n_nodes = meta.B * meta.grid_shape[0] * meta.grid_shape[1] * meta.grid_shape[2]
+            perm = torch.empty(Pc, device=dev, dtype=torch.int32)
+            start = torch.empty(n_nodes + 1, device=dev, dtype=torch.int32)
+            nb = int(L.stpde_lig_sort_tmp_bytes(Pc, n_nodes))
+            tmp = torch.empty(nb, device=dev, dtype=torch.uint8)
             with _timed("xbar_scatter"):
                 check(L.stpde_lig_xbar_rows(C.byref(xd), ab, wt, ptr(xrows), st))
-                n_nodes = meta.B * meta.grid_shape[0] * meta.grid_shape[1] * meta.grid_shape[2]
-                perm = torch.sort(cell, stable=True)[1].int()          # int32 keys: radix sort
-                counts = torch.zeros(n_nodes + 1, device=dev, dtype=torch.int32)
-                counts.index_add_(0, cell + 1, torch.ones(1, device=dev, dtype=torch.int32).expand(Pc))
-                start = torch.cumsum(counts, 0, dtype=torch.int32)     # start[c] = number of points in cells < c
+                check(L.stpde_lig_cell_sort(Pc, n_nodes, ptr(cell), ptr(perm), ptr(start), ptr(tmp), nb, st))
                 check(L.stpde_lig_dlatent_reduce(meta.B, meta.grid_shape[0], meta.grid_shape[1], meta.grid_shape[2],
                                                  plan.cin, ptr(xrows), ptr(perm), ptr(start), ptr(dlatent), st))
     if after_dlatent is not None:      # per-kernel (profiling) path: weight gradients first, nothing left to overlap

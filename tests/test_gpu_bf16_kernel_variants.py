@@ -65,13 +65,15 @@ def _run(tmp_path, tag, combo, **env):
 
 @pytest.mark.parametrize("combo", [True, False])
 def test_round4_bf16_kernels_equal_the_ones_they_replaced(hiplib, tmp_path, combo):
-    base = _run(tmp_path, "base", combo)
+    # (round 5: the fused backward of the first hidden layer is the default; these variants belong to the two kernels it
+    # replaced, which STPDE_FC1_FUSED=0 still selects -- test_fused_fc1_backward_equals_the_two_kernel_path ties the two together)
+    base = _run(tmp_path, "base", combo, STPDE_FC1_FUSED="0")
     kern = str(base["kernels"])
     assert "k_wgrad_oct_bf" in kern and "k_fc1_fwd_spec" in kern, kern
     assert ("k_fc1_dgrad_spec" in kern) == combo, kern         # the wave-specialised input gradient is compiled for S2 <= 1
     variants = {"noswap": dict(STPDE_WGRAD_SWAP="0"), "quad": dict(STPDE_WGRAD_OCT_BF="0"), "act16": dict(STPDE_ACT16="1")}
     for tag, env in variants.items():
-        other = _run(tmp_path, tag, combo, **env)
+        other = _run(tmp_path, tag, combo, STPDE_FC1_FUSED="0", **env)
         ok = str(other["kernels"])
         if tag == "quad":
             assert "k_wgrad_oct_bf" not in ok and "k_wgrad_quad" in ok, ok
@@ -84,3 +86,45 @@ def test_round4_bf16_kernels_equal_the_ones_they_replaced(hiplib, tmp_path, comb
             a, b = base[k].astype(np.float64), other[k].astype(np.float64)
             err = np.abs(a - b).max() / max(np.abs(a).max(), 1e-30)
             assert err < 2e-5, (tag, k, err)
+
+
+def test_fused_fc1_backward_equals_the_two_kernel_path(hiplib, monkeypatch):
+    """Round 5: k_fc1_bwd_fused (csrc/jet_fc1_bwd.hip -- input gradient + weight gradient of the first hidden layer in one
+    kernel, one activation-jet evaluation per z0 element) against the two kernels it replaces (STPDE_FC1_FUSED=0:
+    k_fc1_dgrad_spec + k_wgrad_coop): the layer-0 adjoint is computed in the same order (d latent and the layer-0 weight
+    gradient equal to rounding), fc1's weight gradient sums the same bf16 products in another order (fp32 summation rounding).
+    Both stream sets of the mode (combined second-order stream, and leaky-relu's S = 4), several row-tile counts incl. ones
+    that leave workgroups without work and an odd pair count."""
+    import torch
+    from space_time_pde_amd import _lib, implicit_net, lig_jet
+    dev = torch.device("cuda:0")
+    monkeypatch.setattr(lig_jet, "mlp_precision", "bf16")
+    for act, npts in ((torch.nn.Softplus, 4096), (torch.nn.LeakyReLU, 1024), (torch.nn.Softplus, 6), (torch.nn.Tanh, 70)):
+        torch.manual_seed(3)
+        net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32, activation=act).to(dev)
+        lat0 = 0.5 * torch.randn(1, 6, 9, 7, 32, device=dev)
+        pts = 0.02 + 0.96 * torch.rand(1, npts, 3, device=dev)
+        combo = {(0, 0): 0.7, (1, 1): 1.3} if act is not torch.nn.LeakyReLU else None
+        cot = None
+        res = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("STPDE_FC1_FUSED", fused)
+            lat = lat0.clone().requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            with _lib.dispatch_trace() as tr:
+                jets, _ = lig_jet.lig_jets(net, lat, pts, 0., 1., True, () if combo else ((0, 0), (1, 1)), combo=combo)
+                if cot is None:
+                    cot = torch.randn_like(jets)
+                (jets * cot).sum().backward()
+                torch.cuda.synchronize()
+            assert tr.has("k_fc1_bwd_fused") == (fused == "1"), "\n".join(tr.kernels)
+            assert tr.has("k_fc1_dgrad_spec") == (fused == "0"), "\n".join(tr.kernels)
+            res[fused] = (lat.grad.clone(), [p.grad.clone() for p in net.parameters()])
+        (la, ga), (lb, gb) = res["1"], res["0"]
+        # (same expression sequence for the layer-0 adjoint in both kernels; the compiler may still contract its FMAs differently
+        # inside the fused evaluation, so d latent / fc0's gradient are compared to rounding as well, not bit for bit)
+        assert (la - lb).abs().max().item() <= 2e-5 * lb.abs().max().item(), (act, npts)
+        for k, (a, b) in enumerate(zip(ga, gb)):
+            # (fc0's bias gradient is a plain sum of the bf16 adjoint blocks: a handful of flipped bf16 roundings show at 1e-4)
+            assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-12, (act, npts, k)

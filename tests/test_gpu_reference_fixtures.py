@@ -110,11 +110,12 @@ def _assert_mode_kernels(tr, prec):
     if prec == "fp32x3":
         for pro, epi in ((2, 0), (0, 2), (1, 0), (0, 1)):
             assert tr.has("k_layer_coop", "1, false, 3>)", cfg, "PRO = %d" % pro, "EPI = %d" % epi), dump
-        # split weight gradients: hidden k-groups + a separate raw-input launch (HASX = true; the split kernel has no
-        # registers left to fold the raw-input tiles)
+        # round 5: the split weight gradient of the first hidden layer with the raw-input k-tiles folded in (no separate HASX
+        # launch any more); the second hidden layer's on the exact-fp32 eight-wave kernel (faster than its split ring kernel +
+        # raw-input launch; "fp32x3" is a contract on accuracy, not on the pipe)
         assert tr.has("k_wgrad_coop", "false, true, 3>)", cfg, "MODE = 1", "KC = 8"), dump
-        assert tr.has("k_wgrad_coop", "true, true, 3>)", cfg, "MODE = 1", "KC = 8"), dump
-        assert tr.has("k_wgrad_coop", "false, true, 3>)", cfg, "MODE = 0", "KC = 4"), dump
+        assert not tr.has("k_wgrad_coop", "true, true, 3>)", cfg, "MODE = 1"), dump
+        assert tr.has("k_wgrad_quad", "0, false, 8>)", cfg, "MODE = 0"), dump
     else:
         _assert_bf16_kernels(tr, cfg, dump)
     assert tr.has("k_tail_fwd") and tr.has("k_tail_bwd") and tr.has("k_wgrad_wave", cfg), dump
@@ -123,16 +124,20 @@ def _assert_mode_kernels(tr, prec):
 def _assert_bf16_kernels(tr, cfg, dump):
     # first hidden layer forward: the wave-specialised persistent kernel (csrc/jet_spec_bf16.h)
     assert tr.has("k_fc1_fwd_spec", cfg), dump
-    # ... and its input gradient (round 4: k_fc1_dgrad_spec; the cooperative kernel with STPDE_BF_SPEC_DGRAD=0)
-    assert tr.has("k_fc1_dgrad_spec", cfg) or tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 2"), dump
     for pro, epi in ((1, 0), (0, 1)):
         assert tr.has("k_layer_coop", "true", cfg, "PRO = %d" % pro, "EPI = %d" % epi), dump
-    # bf16 weight gradients with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
-    # (the packed-stash instantiations carry two more template arguments: ..., false, true, 1, PKA>)
-    assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1", "KC = 8"), dump
+    if tr.has("k_fc1_bwd_fused"):
+        # round 5 (default): input gradient + weight gradient of the first hidden layer in ONE kernel (csrc/jet_fc1_bwd.hip);
+        # neither of the two kernels it replaces is launched
+        assert not tr.has("k_fc1_dgrad_spec") and not tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1"), dump
+    else:
+        # STPDE_FC1_FUSED=0: k_fc1_dgrad_spec (round 4; the cooperative kernel with STPDE_BF_SPEC_DGRAD=0) + the ring kernel
+        # with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
+        assert tr.has("k_fc1_dgrad_spec", cfg) or tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 2"), dump
+        assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1", "KC = 8"), dump
+        assert not tr.has("k_wgrad_coop", "KC, true, true", cfg), dump
     assert tr.has("k_wgrad_oct_bf", "ACT>)", cfg), dump       # layer 2: eight waves on one row tile, bf16 blocks in LDS (round 4)
     assert tr.has("k_wgrad_oct_bf", "ACT, 4>)", cfg), dump    # fc3: four waves
-    assert not tr.has("k_wgrad_coop", "KC, true, true", cfg), dump
 
 
 @pytest.mark.parametrize("prec", ["fp32x3", "bf16"])
