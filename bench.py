@@ -508,8 +508,8 @@ def main(argv=None):
                 # so the bytes of a launch scale with its number of tiles
                 scale = rows_per_launch / 8.0 / float(tj["chunk"])
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"] * scale
-                traffic_src = tj.get("source").replace("r4_pmc_", "r4_c4_pmc_" if args.mlp_precision == "bf16" else "r4_pmc_") + ("" if scale == 1 else "; measured on a %d-point launch, scaled x%g to "
-                                                  "this launch's tile count" % (tj["chunk"], scale))
+                traffic_src = tj.get("source") + ("" if scale == 1 else "; measured on a %d-point launch, scaled x%g to "
+                                                      "this launch's tile count" % (tj["chunk"], scale))
         except (OSError, ValueError, KeyError):
             pass
         roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",

@@ -29,6 +29,24 @@
 #define STPDE_FC1F_ABL 0     // timing-only ablations (results WRONG): 1 = no activation jets, 2 = no weight-gradient MFMAs, 3 = no input-gradient MFMAs
 #endif
 
+// Phase timing (tools/micro/ablate_fc1_fused.py, private build with -DSTPDE_FC1F_STAMP=1): s_memtime stamps of every wave of the
+// first 8 workgroups at the phase boundaries of their 5th row tile, read back with stpde_fc1f_stamp_read.
+#ifndef STPDE_FC1F_STAMP
+#define STPDE_FC1F_STAMP 0
+#endif
+#if STPDE_FC1F_STAMP
+static __device__ unsigned long long g_fc1f_stamp[8 * 4 * 8];
+#define FSTAMP(i)                                                                                   \
+  do {                                                                                              \
+    if (it == 4 && blockIdx.x < 8 && lane == 0) g_fc1f_stamp[(blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int stpde_fc1f_stamp_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fc1f_stamp), sizeof(g_fc1f_stamp));
+}
+#else
+#define FSTAMP(i)
+#endif
+
 struct Fc1BwdArgs {
   const float* abar1;   // packed ADJOINT buffer of fc1's rows: [tile][S][16][64 lanes][4 bf16]
   const void* WT16;     // bf16 pack of W1h^T: [8 k-tile pairs][32 output tiles][64 lanes] x 8 bf16
@@ -245,20 +263,25 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     };
     // (one tile at a time: interleaving the evaluations multiplies their temporaries past the 256 registers the accumulators of
     // dW1h leave, and every spilled register is a scratch access inside the loop)
+    FSTAMP(0);
     dgrad2(0);
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(1);
     wring(2);
     epi(0);
     __builtin_amdgcn_sched_barrier(0);
     epi(1);
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(2);
     dgrad2(2);
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(3);
     epi(2);
     __builtin_amdgcn_sched_barrier(0);
     epi(3);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(4);
     // next row tile's z0 blocks / combination weights and the first stages of its weight ring (the same weights for every row
     // tile): they land while the weight-gradient MFMAs run
     fetch(tnext);
@@ -319,9 +342,12 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(5);
     // the staged row tile has landed (the only vector-memory wait of an iteration), every wave is done with this buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FSTAMP(6);
     FC1F_BARRIER();
+    FSTAMP(7);
   }
 
   const int g = lane >> 4, c = lane & 15;

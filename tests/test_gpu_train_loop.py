@@ -325,12 +325,13 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
         gim = [p.grad.double().norm().item() for p in net.parameters()]
         return float(loss), float(reg), float(pde), gn, gim, (tr.kernels if tr else None)
 
+    rc0 = lig_jet.stats["recompute_steps"]
     a = run(True, trace=True)
     kernels = a[5]
     for needle in ("k_fc1_fwd_spec", "k_wgrad_oct_bf", "k_tail_fwd_bf", "k_tail_bwd_bf", "k_conv_fused"):
         assert any(needle in k for k in kernels), (needle, kernels)
     assert any(("k_fc1_bwd_fused" in k) or ("k_fc1_dgrad_spec" in k) for k in kernels), kernels
-    assert lig_jet.stats["recompute_steps"] == 0 or torch.cuda.get_device_properties(0).total_memory < 200e9
+    assert lig_jet.stats["recompute_steps"] == rc0 or torch.cuda.get_device_properties(0).total_memory < 200e9   # stash kept
     a2 = run(True)
     b = run(False)
     for i, what in enumerate(("loss", "reg", "pde")):

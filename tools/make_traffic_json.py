@@ -5,6 +5,7 @@ FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes 
 WRITE_SIZE is taken as reported.  Usage: make_traffic_json.py fetch.txt write.txt chunk act out.json
 """
 import json
+import os
 import re
 import sys
 
@@ -23,6 +24,8 @@ def bench_name(sym):
         return "gather"
     if sym.startswith("k_fc1_fwd_spec<3,"):
         return "layer1_fwd"
+    if sym.startswith("k_fc1_bwd_fused<"):
+        return "layer1_bwd"
     if re.match(r"k_\w+<0,\d,", sym):      # value-only / value-tile kernels of bench.py's inference side figure, not the training step
         return None
     m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?(?:,[\w,]+)?>", sym)
@@ -57,5 +60,6 @@ if __name__ == "__main__":
             f, w = 2.0 * fetch.get(sym, 0.0), write.get(sym, 0.0)
             kernels[name] = dict(symbol=sym, fetch_bytes_corrected=f, write_bytes=w, hbm_bytes_per_launch=f + w)
     json.dump(dict(chunk=int(sys.argv[3]), act=sys.argv[4], kernels=kernels,
-                   source="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
-                          "profiles/r4_pmc_fetch_size*.txt / r4_pmc_write_size*.txt"), open(sys.argv[5], "w"), indent=1)
+                   source="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, profiles/%s / %s"
+                          % (os.path.basename(sys.argv[1]).replace("FETCH_SIZE", "fetch_size"),
+                             os.path.basename(sys.argv[2]).replace("WRITE_SIZE", "write_size"))), open(sys.argv[5], "w"), indent=1)

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "space_time_pde_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "micro", "_abl")
 VARIANTS = {0: "full kernel", 1: "no activation jets", 2: "no weight-gradient MFMAs", 3: "no input-gradient MFMAs",
-            4: "W1h^T fragments not re-fetched", 5: "B fragments not re-read", 6: "no LDS-DMA of the adjoint tile"}
+            7: "full kernel with phase stamps"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 
@@ -28,7 +28,8 @@ def build(extra):
     for n in VARIANTS:
         so = os.path.join(OUT, "libfc1f_%d.so" % n)
         srcs = [os.path.join(CSRC, f) for f in ("jet_fc1_bwd.hip", "api.cpp")]
-        cmd = ["hipcc"] + FLAGS + ["-DSTPDE_FC1F_ABL=%d" % n] + extra + ["-shared", "-o", so] + srcs + [stub]
+        defs = ["-DSTPDE_FC1F_STAMP=1"] if n == 7 else ["-DSTPDE_FC1F_ABL=%d" % n]
+        cmd = ["hipcc"] + FLAGS + defs + extra + ["-shared", "-o", so] + srcs + [stub]
         procs.append((n, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for n, p in procs:
         out, _ = p.communicate()
@@ -81,6 +82,15 @@ def run():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         print("variant %d  %-28s %7.3f ms per 2^18 row tiles  (x2 = %.2f ms per 2^20 points)" % (n, what, ms, 2 * ms))
+        if n == 7:
+            buf = (C.c_ulonglong * (8 * 4 * 8))()
+            L.stpde_fc1f_stamp_read(buf)
+            names = ["dgrad(0,1)", "epi 0,1", "dgrad(2,3)", "epi 2,3", "wgrad", "vmcnt(0)", "barrier"]
+            for blk in range(0, 8, 3):
+                for wv in range(4):
+                    t = [buf[(blk * 4 + wv) * 8 + i] for i in range(8)]
+                    print("   stamps block %d wave %d: " % (blk, wv) + "  ".join("%s %d" % (nm, t[i + 1] - t[i]) for i, nm in enumerate(names))
+                          + "   | total %d cycles" % (t[7] - t[0]))
 
 
 if __name__ == "__main__":
