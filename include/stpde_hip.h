@@ -87,8 +87,9 @@ typedef struct {
   float lo_c[3], hi_c[3], cube[3];
   float alpha[6]; /* combined second-order stream weights (only read when cw != NULL) */
 } stpde_gather_desc;
-/* XR (optional, may be NULL): the same augmented input in the row-major fragment image (lane 16g+c holds rows
- * 4g..4g+3 of feature c), consumed by stpde_jet_wgrad. */
+/* XR (optional, normally NULL since round 5): the same augmented input in the row-major fragment image (lane 16g+c holds
+ * rows 4g..4g+3 of feature c).  No kernel of the library reads it any more: the weight-gradient kernels take X and turn
+ * the fragments they need into the row-major image inside LDS (1.5 KiB per point less written and re-read). */
 int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, const float* latent, float* X, float* XR,
                      float* coef, int* cell, float* cw /* [P][8] or NULL */, void* stream);
 
@@ -208,13 +209,13 @@ int stpde_jet_layer_bwd_to(const stpde_layer_desc* d, const float* abar_out, con
  * same layer overwrites in_pre.  first_hidden: in_pre is the z0 stash [tile][KT][256] written by
  * stpde_jet_layer_fwd(first_hidden) (value stream of layer 0's pre-activations; the tangent streams are the constant
  * columns tanc0 [3][KT][256] = W0[:, d] in the column-major image, the second-order streams are zero) -- call it before
- * stpde_jet_layer_bwd(first_hidden) writes the layer-0 adjoint over the stash.  XR = row-major augmented input from
+ * stpde_jet_layer_bwd(first_hidden) writes the layer-0 adjoint over the stash.  X = the (column-major) augmented input from
  * stpde_lig_gather.  fp32 atomics; caller zero-fills dW_aug.  d->mfma_bf16: layers with MT >= 8 contract with
  * bf16-rounded operands (two derivative streams per v_mfma_f32_16x16x32_bf16), fp32 accumulation.  d->packed (bf16 mode,
  * bits 1 = in_pre is a packed stash, 4 = abar_out is a packed adjoint buffer): the narrow layers (MT < 8) and the raw-input
  * layer (KT = 0, mfma_bf16 = 1, packed = 4) then contract over the rows with bf16 MFMAs as well; the raw-input columns of
  * the hidden layers stay fp32. */
-int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* XR,
+int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre, const float* X,
                     const float* tanc0, float* dW_aug, const float* cw, void* stream);
 
 /* bf16 mode, first hidden layer of the reference width (round 5): stpde_jet_wgrad(first_hidden) + stpde_jet_layer_bwd(first_hidden)
@@ -223,13 +224,13 @@ int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, co
  * gradient's operand blocks (csrc/jet_fc1_bwd.hip; the backward of src/implicit_net.py:48-54 through fc1 that loss.backward(),
  * experiments/rb2d/train.py:77, performs).  d: the description stpde_jet_layer_bwd takes for this layer (first_hidden = 1,
  * KT = 32, MT = 16, mfma_bf16 = 1, packed bits 2 and 4, S1 = 3, S2 = 0 or the combined stream).  abar1: packed ADJOINT buffer
- * of fc1's rows; WhT_pack_bf16: bf16 pack of W1h^T; z0 / tanc0 / cw / XR as for the two calls it replaces; abar0 (packed
+ * of fc1's rows; WhT_pack_bf16: bf16 pack of W1h^T; z0 / tanc0 / cw / X as for the two calls it replaces; abar0 (packed
  * ADJOINT blocks of the value stream, must not alias z0), abar0_tan ([tile][32][3][16] row sums) as stpde_jet_layer_bwd writes
  * them; dW_aug: fc1's block of the flat gradient buffer (accumulated with fp32 atomics).
  * stpde_jet_fc1_bwd_supported(d) != 0 iff this call serves d (STPDE_FC1_FUSED=0 switches it off for A/B timing). */
 int stpde_jet_fc1_bwd_supported(const stpde_layer_desc* d);
 int stpde_jet_fc1_bwd(const stpde_layer_desc* d, const float* abar1, const void* WhT_pack_bf16, const float* z0,
-                      const float* tanc0, const float* cw, const float* XR, float* abar0, float* abar0_tan, float* dW_aug,
+                      const float* tanc0, const float* cw, const float* X, float* abar0, float* abar0_tan, float* dW_aug,
                       float* act_param_bar, void* stream);
 
 /* ---- a4: corner-weighted reduction (src/local_implicit_grid.py:59) on all streams ------------------
@@ -279,7 +280,7 @@ int stpde_lig_dlatent_reduce(int B, int n0, int n1, int n2, int C, const float* 
  * per-layer entry points above, issued in the same order; the per-layer entry points stay exported (profiling, tests).
  * All buffers are the caller's (stpde_lig_workspace); sizes in floats for a chunk of P points, nt = P / 2 row tiles,
  * S = 1 + S1 + S2 streams of cfg_mlp, block = 256 floats:
- *   X, XR [nt][3][block]   coef [P][16]   cw [P][8] (combined stream only, else NULL)   cell [P] int
+ *   X [nt][3][block] (XR: unused since round 5, may be NULL)   coef [P][16]   cw [P][8] (combined stream only, else NULL)   cell [P] int
  *   pre[0] = z0 stash [nt][MT_0][block] (training only)      pre[l], l >= 1: [nt][S][MT_l][block]
  *   backward scratch: abar2x / abar3x = sizes of pre[2] / pre[3] (fresh adjoint buffers of the fused tail), tan0
  *   [nt][MT_0][48], abar0 [nt][1 + S1][MT_0][block] (only when tan0 is NULL and S1 == 3), xrows [16 nt][CP], perm [P],
@@ -323,7 +324,7 @@ typedef struct {
                       ADJOINT buffers: nt * S * MT_l * 512 bytes) */
   void* act16[2];  /* bf16 mode, nullable: stpde_layer_desc.act16 of fc1 and fc2 (nt * KT_l * S * 512 bytes each) */
 } stpde_lig_workspace;
-#define STPDE_F_STASH 1          /* forward: keep what the backward needs (XR, z0) */
+#define STPDE_F_STASH 1          /* forward: keep what the backward needs (z0) */
 #define STPDE_F_VALUE_TILES 2    /* forward-only value queries: four row tiles per pass over the weights */
 #define STPDE_F_FUSED_TAIL 4     /* fc3 -> fc4 -> fc5 in one kernel each way (nf = 16 / 32) */
 #define STPDE_F_TAN0_ROWSUM 8    /* backward: layer-0 tangent adjoints as per-tile row sums (needs workspace.tan0) */

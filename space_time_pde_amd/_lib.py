@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("STPDE_LIB") or os.path.join(_HERE, "libstpde_hip.so")
 _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s34.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s34.hip", "jet_wgrad_s36.hip", "jet_fc1_bwd.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "conv3d_fused.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
-ABI_VERSION = 310   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 311   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint

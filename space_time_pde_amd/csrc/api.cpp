@@ -29,7 +29,7 @@ int stpde_check_launch(const char* what) {
 }
 
 // ABI version: bumped whenever a descriptor or a signature of include/stpde_hip.h changes (_lib.ABI_VERSION must match)
-extern "C" int stpde_version(void) { return 310; }
+extern "C" int stpde_version(void) { return 311; }
 
 extern "C" int stpde_last_error(char* buf, unsigned long n) {
   if (!buf || n == 0) return STPDE_E_BADARG;

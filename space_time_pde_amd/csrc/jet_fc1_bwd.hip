@@ -53,7 +53,7 @@ struct Fc1BwdArgs {
   const float* Z0;      // [tile][32][256] value stream of layer 0's pre-activations
   const float* tanc0;   // [3][32][256] tangent constants W0[:, d], column-major image
   const float* cw;      // [P][8] weights of the combined second-order stream (S2 == 1)
-  const float* XR;      // [tile][XT][256] augmented raw input, row-major image
+  const float* X;       // [tile][XT][256] augmented raw input, column-major image
   float* abar0;         // out: value-stream adjoint of layer 0, packed ADJOINT blocks [tile][32][64][4 bf16]
   float* Tan0;          // out: [tile][32][3][16] row sums of the tangent-stream adjoints of layer 0
   float* dW;            // [256][16 * (32 + XT)] fp32, atomically accumulated
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
       // after the hidden k-tiles' MFMAs)
       f32x4 xr[XT];
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) xr[xt] = ld4(a.XR + ((size_t)tile * XT + xt) * 256 + lo);
+      for (int xt = 0; xt < XT; ++xt) xr[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
       bf16x8 An[NP];
       rdA(0, An);
 #pragma unroll
@@ -328,6 +328,16 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
           for (int q = 0; q < NQ; ++q)
             if (STPDE_FC1F_ABL != 2) dw[m][q] = mfma_bf(A8[p], H8[q][p], dw[m][q]);
       }
+      // the raw-input fragments as row-major bf16 operands: through this wave's h0 patch (its blocks are in registers by now)
+      bf16x4 xb4[XT];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) *reinterpret_cast<bf16x4*>(&hp[w][0][xt][lane * 2]) = to_bf4(xr[xt]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt)
+        xb4[xt] = lds_read_tr16(reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(&hp[w][0][xt][0]) + trofs));
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const char* am = ab + (size_t)(mx + mi) * 512;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
                                 lds_read_tr16(reinterpret_cast<const __bf16*>(am + 3 * KT * 512)));
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt)
-          dwx[mi][xt] = mfma_bf(A01, cat8(to_bf4(xr[xt]), xt == 0 ? pat0 : zero4), dwx[mi][xt]);
+          dwx[mi][xt] = mfma_bf(A01, cat8(xb4[xt], xt == 0 ? pat0 : zero4), dwx[mi][xt]);
         dwx[mi][0] = mfma_bf(A23, pat12, dwx[mi][0]);
       }
     }
@@ -406,14 +416,14 @@ extern "C" int stpde_jet_fc1_bwd_supported(const stpde_layer_desc* d) {
 }
 
 extern "C" int stpde_jet_fc1_bwd(const stpde_layer_desc* d, const float* abar1, const void* WhT_pack_bf16, const float* z0,
-                                 const float* tanc0, const float* cw, const float* XR, float* abar0, float* abar0_tan,
+                                 const float* tanc0, const float* cw, const float* X, float* abar0, float* abar0_tan,
                                  float* dW_aug, float* act_param_bar, void* stream) {
   if (!stpde_jet_fc1_bwd_supported(d)) {
     stpde_set_error("jet_fc1_bwd: bf16 mode with packed buffers only (first hidden layer of the reference width: KT = 32, MT = 16, "
                     "S1 = 3, S2 = 0 or the combined stream, STPDE_FC1_FUSED != 0)");
     return STPDE_E_UNSUPPORTED;
   }
-  if (d->ntiles <= 0 || !abar1 || !WhT_pack_bf16 || !z0 || !tanc0 || !XR || !abar0 || !abar0_tan || !dW_aug || (d->cfg.S2 && !cw)) {
+  if (d->ntiles <= 0 || !abar1 || !WhT_pack_bf16 || !z0 || !tanc0 || !X || !abar0 || !abar0_tan || !dW_aug || (d->cfg.S2 && !cw)) {
     stpde_set_error("jet_fc1_bwd: bad argument");
     return STPDE_E_BADARG;
   }
@@ -423,7 +433,7 @@ extern "C" int stpde_jet_fc1_bwd(const stpde_layer_desc* d, const float* abar1, 
   a.Z0 = z0;
   a.tanc0 = tanc0;
   a.cw = cw;
-  a.XR = XR;
+  a.X = X;
   a.abar0 = abar0;
   a.Tan0 = abar0_tan;
   a.dW = dW_aug;

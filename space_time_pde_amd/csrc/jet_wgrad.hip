@@ -14,8 +14,8 @@ static int dispatch_streams(const WgradArgs& a, int mode, hipStream_t stream) {
 }
 
 extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, const float* in_pre,
-                               const float* XR, const float* tanc0, float* dW_aug, const float* cw, void* stream) {
-  if (!d || d->ntiles <= 0 || d->MT <= 0 || d->KT < 0 || !abar_out || !XR || !dW_aug || SP < 1 ||
+                               const float* X, const float* tanc0, float* dW_aug, const float* cw, void* stream) {
+  if (!d || d->ntiles <= 0 || d->MT <= 0 || d->KT < 0 || !abar_out || !X || !dW_aug || SP < 1 ||
       SP > 1 + d->cfg.S1 + d->cfg.S2) {
     stpde_set_error("jet_wgrad: bad argument");
     return STPDE_E_BADARG;
@@ -23,7 +23,7 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   WgradArgs a{};
   a.P = abar_out;
   a.Q = in_pre;
-  a.XR = XR;
+  a.X = X;
   a.tanc0 = tanc0;
   a.dW = dW_aug;
   a.cw = cw;

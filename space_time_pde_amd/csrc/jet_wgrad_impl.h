@@ -25,7 +25,9 @@ struct WgradArgs {
   const float* P;      // abar_out, column-major image [tile][SP][MT][256]
   const float* Q;      // pre-activations of the layer input, column-major image [tile][S][KT][256]   (MODE 0);
                        // MODE 1 (first hidden layer): the z0 stash [tile][KT][256] = value stream of layer 0's pre-activations
-  const float* XR;     // row-major augmented input [tile][XT][256]
+  const float* X;      // augmented raw input [tile][XT][256], COLUMN-major image (round 5: the row-major copy XR the gather kernel
+                       // used to write -- 1.5 KiB per point, re-read by six kernels -- is gone; every consumer turns the fragment
+                       // it needs into the row-major image through an LDS patch, as it does for every other operand)
   const float* tanc0;  // [3][KT][256] layer-0 tangent constants W0[:, d], column-major image (MODE 1)
   float* dW;           // [16*MT][16*(KT+XT)]
   const float* cw;     // [P][8] weights of the combined second-order stream (S2 == 1)
@@ -167,6 +169,26 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     return *reinterpret_cast<const bf16x4*>(b16 + (lane & 15) * 16 + 4 * (lane >> 4));
   };
 
+  // folded raw-input fragment (XF / XB / XS): the column-major block `v` of X -> this lane's row-major operand fragment (rows
+  // 4g .. 4g+3 of feature c) through the wave's private patch; bf16-pipe modes: SPL bf16 terms
+  auto x_rowmajor = [&](f32x4 v) -> f32x4 {
+    float* patch = pp[wv][0];
+    __builtin_amdgcn_wave_barrier();
+    lds_put_T<TP>(patch, lane, v);
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 r = lds_get_R<TP>(patch, lane);
+    __builtin_amdgcn_wave_barrier();
+    return r;
+  };
+  auto x_rowmajor16 = [&](f32x4 v, bf16x4* t) {
+    float* patch = pp[wv][0];
+    __builtin_amdgcn_wave_barrier();
+    put(patch, v, false);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < (BF ? SPL : 1); ++k) t[k] = get16(patch, k, true);
+    __builtin_amdgcn_wave_barrier();
+  };
   // produce ring slot `wv` (k-tile kq0 + wv) of row tile `tile` into buffer `buf`, in two halves: load_q ISSUES the stash
   // loads (before the MFMAs of the current tile), finish_q applies the activation jet and writes the ring slot (after them),
   // so the loads' latency hides behind the MFMAs instead of sitting in front of the barrier
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         for (int st = 0; st < S; ++st) pre[st] = ld_blk(a.Q, (PKM & 1) ? 1 : 0, tile, S, KT, st, kq, lane);
       }
     } else if (kq < KT + XT) {
-      pre[0] = ld4(a.XR + ((size_t)tile * XT + (kq - KT)) * 256 + lo);
+      pre[0] = ld4(a.X + ((size_t)tile * XT + (kq - KT)) * 256 + lo);
     }
   };
   auto finish_q = [&](const f32x4* pre, const float* cq, int buf) {
@@ -221,12 +243,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       for (int st = 0; st < S; ++st) put(&hl[buf][wv][st][0], H[st], false);
     } else if (kq < KT + XT) {
       const int xt = kq - KT;
-      put(&hl[buf][wv][0][0], pre[0], true);
+      put(&hl[buf][wv][0][0], pre[0], false);          // (column-major source, like every hidden k-tile)
       if (S1 == 3) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          const float v = (xt == 0 && c == d) ? 1.f : 0.f;     // tangent stream d sees the unit vector e_d
-          put(&hl[buf][wv][1 + d][0], f32x4{v, v, v, v}, true);
+          // tangent stream d sees the unit vector e_d: in the column-major image lane (g, row) holds features 4g .. 4g+3
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (xt == 0 && 4 * g + r == d) ? 1.f : 0.f;
+          put(&hl[buf][wv][1 + d][0], v, false);
         }
       }
     }
@@ -356,7 +381,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // value product with the raw-input tile + tangent columns (XB): part of the MFMA phase of a row tile
   auto xb_mma = [&]() {
     if constexpr (XB) {
-      const bf16x8 x8 = cat8(to_bf4(xr), S1 == 3 ? e0 : zero4);
+      bf16x4 xt1[1];
+      x_rowmajor16(xr, xt1);
+      const bf16x8 x8 = cat8(xt1[0], S1 == 3 ? e0 : zero4);
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) accx[mi] = mfma_bf(pa8[0][0][mi], x8, accx[mi]);
       if constexpr (S1 == 3) {
@@ -368,12 +395,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   auto xs_mma = [&]() {
     if constexpr (XS) {
       bf16x4 xt3[3];
-      f32x4 v = xr;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        xt3[t] = to_bf4(v);
-        if (t < 2) v -= bf4_to_f32(xt3[t]);
-      }
+      x_rowmajor16(xr, xt3);           // (put() splits into the three terms, the split commutes with the transposition)
       constexpr int TP[6] = {1, 0, 2, 0, 1, 0}, TH[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
       for (int q6 = 0; q6 < 6; ++q6) {
@@ -425,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     transpose_p(raw, pa);
     pack_p(raw);
     if constexpr (XF || XB || XS) {
-      if (a.xfold) xr = ld4(a.XR + ((size_t)tile * XT + xsel) * 256 + lo);
+      if (a.xfold) xr = ld4(a.X + ((size_t)tile * XT + xsel) * 256 + lo);
     }
   }
   __syncthreads();
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         const int nx0 = tile + stride < a.ntiles ? tile + stride : tile;
         load_p_raw(nx0, raw);
         load_q(nx0, preq, cqq);
-        if constexpr (XB) xrn = ld4(a.XR + ((size_t)nx0 * XT + xsel) * 256 + lo);
+        if constexpr (XB) xrn = ld4(a.X + ((size_t)nx0 * XT + xsel) * 256 + lo);
       }
       for (; tile < a.ntiles; tile += stride) {
         const int next = tile + stride;
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         const int nn = nx + stride < a.ntiles ? nx + stride : nx;
         load_p_raw(nn, raw);
         load_q(nn, preq, cqq);
-        if constexpr (XB) xrn = ld4(a.XR + ((size_t)nn * XT + xsel) * 256 + lo);
+        if constexpr (XB) xrn = ld4(a.X + ((size_t)nn * XT + xsel) * 256 + lo);
         // ---- the MFMAs of the current tile
         xb_mma();
         ring_mma(buf);
@@ -530,20 +552,21 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     if (EARLYQ && NBUF == 2 && STPDE_ABLATE_W != 3) load_q(nx, preq, cqq);
     f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (XB) {
-      xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
+      xrn = ld4(a.X + ((size_t)nx * XT + xsel) * 256 + lo);
       xb_mma();
     }
     if constexpr (XS) {
-      xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
+      xrn = ld4(a.X + ((size_t)nx * XT + xsel) * 256 + lo);
       xs_mma();
     }
     if constexpr (XF) {
       // branch-free: without xfold the pointer is this launch's own XR anyway and the results are simply not written
-      xrn = ld4(a.XR + ((size_t)nx * XT + xsel) * 256 + lo);
+      xrn = ld4(a.X + ((size_t)nx * XT + xsel) * 256 + lo);
+      const f32x4 xrr = x_rowmajor(xr);
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) accx[mi] = mfma4(pa[0][mi][r], xr[r], accx[mi]);
+        for (int r = 0; r < 4; ++r) accx[mi] = mfma4(pa[0][mi][r], xrr[r], accx[mi]);
       if constexpr (S1 == 3) {
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -626,9 +649,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
             bf16x4 t0[SPL], t1[SPL];
             bf16x8 H8[SPL];
 #pragma unroll
-            for (int k = 0; k < SPL; ++k) {         // raw-input k-tiles were written from the row-major image: plain read
-              t0[k] = get16(&hl[buf][q][2 * sp][0], k, false);
-              if (2 * sp + 1 < SX) t1[k] = get16(&hl[buf][q][2 * sp + 1 < SX ? 2 * sp + 1 : 0][0], k, false);
+            for (int k = 0; k < SPL; ++k) {         // (raw-input k-tiles come from the column-major image as well: transpose read)
+              t0[k] = get16(&hl[buf][q][2 * sp][0], k, true);
+              if (2 * sp + 1 < SX) t1[k] = get16(&hl[buf][q][2 * sp + 1 < SX ? 2 * sp + 1 : 0][0], k, true);
             }
 #pragma unroll
             for (int k = 0; k < SPL; ++k) H8[k] = cat8(t0[k], 2 * sp + 1 < SX ? t1[k] : zero4);
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
 #pragma unroll
     for (int st = 0; st < S; ++st) qn[st] = ld_blk_raw(a.Q, (PKW & 1) ? 1 : 0, tile, S, KTT, st, 0, lane);
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) xrp[xt] = ld4(a.XR + ((size_t)tile * XT + xt) * 256 + lo);   // already the row-major image
+    for (int xt = 0; xt < XT; ++xt) xrp[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);   // column-major: transposed at its use
 #pragma unroll
     for (int ki = 0; ki < KTT; ++ki) {
       f32x4 pre[S], H[S];
@@ -844,7 +867,7 @@ __global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
     }
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
-      const f32x4 xr = xrp[xt];
+      const f32x4 xr = transpose(xrp[xt]);
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi)
 #pragma unroll
@@ -944,7 +967,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
   auto load_p = [&](int t) {
 #pragma unroll
     for (int st = 0; st < S; ++st) praw[st] = ld_blk_raw(a.P, PM, t, S, MCW, st, wv, lane);
-    if (wv < XT) xr = ld4(a.XR + ((size_t)t * XT + wv) * 256 + lo);        // already the row-major image
+    if (wv < XT) xr = ld4(a.X + ((size_t)t * XT + wv) * 256 + lo);        // column-major image: transposed at its use
   };
   auto load_qk = [&](int t, int k) {
 #pragma unroll
@@ -1013,11 +1036,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
       }
     }
     if (wv < XT) {
+      const f32x4 xrr = transpose(xcur);
 #pragma unroll
       for (int mi = 0; mi < MCW; ++mi) {
         const f32x4 p0 = lds_get_R<TP>(&pshare[0][mi][0], lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mi][KW] = mfma4(p0[r], xcur[r], acc[mi][KW]);
+        for (int r = 0; r < 4; ++r) acc[mi][KW] = mfma4(p0[r], xrr[r], acc[mi][KW]);
       }
     } else if (S1 == 3) {
       // tangent stream d of a skip connection sees the unit vector e_d: column d of the raw-input block gets the sum over the
@@ -1099,7 +1123,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_oct_bf(Wgr
     const char* pb = reinterpret_cast<const char*>(a.P) + (size_t)t * (S * MCW * 512) + (size_t)wv * 512 + lane * 8;
 #pragma unroll
     for (int st = 0; st < S; ++st) praw[st] = *reinterpret_cast<const float2*>(pb + (size_t)st * MCW * 512);
-    if (wv < XT) xr = ld4(a.XR + ((size_t)t * XT + wv) * 256 + lo);
+    if (wv < XT) xr = ld4(a.X + ((size_t)t * XT + wv) * 256 + lo);
   };
   auto load_qk = [&](int t, int k) {
 #pragma unroll
@@ -1117,7 +1141,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_oct_bf(Wgr
     load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
 #pragma unroll
     for (int st = 0; st < S; ++st) *reinterpret_cast<float2*>(&pshare[st][wv][wofs]) = praw[st];
-    const f32x4 xcur = xr;
+    // raw-input tile of this wave (exact fp32 skip operand): column-major block -> row-major fragment through the wave's
+    // own patch area, before the activated blocks of this iteration go into it
+    f32x4 xcur = xr;
+    if (wv < XT) {
+      float* patch = reinterpret_cast<float*>(&ppriv[wv][0][0][0]);          // 5 KB per wave: room for a padded fp32 block
+      lds_put_T<20>(patch, lane, xr);
+      __builtin_amdgcn_wave_barrier();
+      xcur = lds_get_R<20>(patch, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
     load_p(tnext);
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
@@ -1251,7 +1284,7 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   constexpr bool SPLIT_OK = KC >= 4 && S1 + S2 <= 4;
   const int bfm = (a.bf16 == 3 && !SPLIT_OK) ? 0 : a.bf16;
   static const int x3fold_env = getenv("STPDE_X3_XFOLD") ? atoi(getenv("STPDE_X3_XFOLD")) : 1;
-  const bool xfold = xfold_env && !a.xonly && (!bfm || (bfm == 1 && KC >= 4) || (bfm == 3 && KC >= 4 && STPDE_X3_XFOLD && x3fold_env)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.XR;
+  const bool xfold = xfold_env && !a.xonly && (!bfm || (bfm == 1 && KC >= 4) || (bfm == 3 && KC >= 4 && STPDE_X3_XFOLD && x3fold_env)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.X;
   static const int swap_env = getenv("STPDE_WGRAD_SWAP") ? atoi(getenv("STPDE_WGRAD_SWAP")) : 1;
   a.swap = swap_env;
   for (int part = 0; part < 2; ++part) {
@@ -1329,7 +1362,7 @@ static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
       // for the split ring kernel and its separate raw-input launch; the mode is a contract on accuracy, not on the pipe
       // (STPDE_X3_FC2_QUAD=0: the split kernels)
       static const int x3quad = getenv("STPDE_X3_FC2_QUAD") ? atoi(getenv("STPDE_X3_FC2_QUAD")) : 1;
-      if (oct && a.KT == 16 && a.MT == 8 && XT == 3 && a.SP == 1 + S1 + S2 && a.XR &&
+      if (oct && a.KT == 16 && a.MT == 8 && XT == 3 && a.SP == 1 + S1 + S2 && a.X &&
           ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5) || (a.bf16 == 3 && a.pk == 0 && x3quad))) {
         int gx = 256;                          // one workgroup per CU, persistent
         if (gx > a.ntiles) gx = a.ntiles;

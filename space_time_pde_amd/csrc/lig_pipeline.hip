@@ -118,7 +118,7 @@ extern "C" int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* p, const stpde_je
   const bool stash = flags & STPDE_F_STASH;
   const int S = 1 + cfg_mlp->S1 + cfg_mlp->S2;
   Seq seq;
-  seq([&] { return stpde_lig_gather(gd, pts, latent, ws->X, stash ? ws->XR : nullptr, ws->coef, ws->cell, ws->cw, stream); });
+  seq([&] { return stpde_lig_gather(gd, pts, latent, ws->X, nullptr, ws->coef, ws->cell, ws->cw, stream); });
   // forward-only value queries: VALUE-TILE kernels (four consecutive row tiles share one pass over the weights)
   const bool vt = S == 1 && !stash && (flags & STPDE_F_VALUE_TILES) && nt % 4 == 0 && (!p->mfma_bf16 || p->mfma_bf16 == 3);
   stpde_jet_cfg lcfg = *cfg_mlp;
@@ -211,7 +211,7 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     dwg.packed = packed_flags(p, l, -1) & 5;
     dwg.act16 = (p->mfma_bf16 == 1 && l <= 2) ? ws->act16[l - 1] : nullptr;
     seq([&] {
-      return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->XR, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
+      return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->X, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
                              stream);
     });
   };
@@ -222,10 +222,10 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     float* dw0 = dW_flat + p->dw_off[0];
     if (split0) {
       d.cfg = *cfg_val;       // value stream x raw input (the S = 1 weight-gradient kernels)
-      seq([&] { return stpde_jet_wgrad(&d, 1, abar0, nullptr, ws->XR, nullptr, dw0, nullptr, stream); });
+      seq([&] { return stpde_jet_wgrad(&d, 1, abar0, nullptr, ws->X, nullptr, dw0, nullptr, stream); });
       seq([&] { return stpde_jet_tan0_reduce(nt, MT0, ws->tan0, dw0, 16 * STPDE_XT, stream); });
     } else {
-      seq([&] { return stpde_jet_wgrad(&d, SP0, abar0, nullptr, ws->XR, nullptr, dw0, ws->cw, stream); });
+      seq([&] { return stpde_jet_wgrad(&d, SP0, abar0, nullptr, ws->X, nullptr, dw0, ws->cw, stream); });
     }
   };
   auto tail_bwd = [&] {
@@ -266,7 +266,7 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     stpde_layer_desc d = layer_desc(nt, p, 1, cfg, p->mfma_bf16);
     d.packed = packed_flags(p, 1, 0);
     seq([&] {
-      return stpde_jet_fc1_bwd(&d, abar[1], p->WhT16[1], z0, p->tanc[0], ws->cw, ws->XR, abar0, ws->tan0,
+      return stpde_jet_fc1_bwd(&d, abar[1], p->WhT16[1], z0, p->tanc[0], ws->cw, ws->X, abar0, ws->tan0,
                                dW_flat + p->dw_off[1], act_param_bar, stream);
     });
   };

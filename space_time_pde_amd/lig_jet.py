@@ -461,7 +461,7 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     ws = LigWorkspace()
     s = dict(p0=p0, Pc=Pc, ws=ws)
     s["X"] = torch.empty(nt * XT * _FRAG, device=dev)
-    s["XR"] = torch.empty(nt * XT * _FRAG, device=dev) if need_grad else None
+    s["XR"] = None      # (round 5: no row-major copy of X any more -- the weight-gradient kernels transpose the fragments they need)
     s["cw"] = torch.empty(Pc * 8, device=dev) if meta.cfg_out.combo else None
     s["coef"] = torch.empty(Pc * 16, device=dev)
     s["cell"] = torch.empty(Pc, device=dev, dtype=torch.int32)
@@ -563,7 +563,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     nt = Pc // 2
     dev = pts_c.device
     X = torch.empty(nt * XT * _FRAG, device=dev)
-    XR = torch.empty(nt * XT * _FRAG, device=dev) if need_grad else None
+    XR = None           # (round 5: no row-major copy of X; the weight-gradient kernels read X)
     cw = torch.empty(Pc * 8, device=dev) if meta.cfg_out.combo else None
     coef = torch.empty(Pc * 16, device=dev)
     cell = torch.empty(Pc, device=dev, dtype=torch.int32)
@@ -625,7 +625,7 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     with _timed("reduce_fwd"):
         check(L.stpde_lig_reduce_fwd(C.byref(meta.cfg_out), S, Pc, plan.cout, ptr(bufs[5]), ptr(coef),
                                      C.c_void_p(jets.data_ptr() + 4 * p0), jets.shape[2], st))
-    return dict(X=X, XR=XR, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw, z0=z0)
+    return dict(X=X, XR=X, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw, z0=z0)
 
 
 def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None, side_stream=None):
@@ -810,7 +810,7 @@ def _per_point_bytes(meta):
     plan = meta.plan
     mt0 = plan.layers[0]["MT"]
     cp = (plan.cin + 3) // 4 * 4
-    fwd_tile = 4 * (sum(_buf_floats(meta, l, 1) for l in range(1, 6)) + mt0 * _FRAG + 2 * XT * _FRAG)
+    fwd_tile = 4 * (sum(_buf_floats(meta, l, 1) for l in range(1, 6)) + mt0 * _FRAG + XT * _FRAG)
     fwd_tile += sum(_act16_bytes(meta, l, 1) for l in (1, 2) if _act16_layers(meta, l))
     fwd = fwd_tile // 2 + 4 * 16 + (4 * 8 if meta.cfg_out.combo else 0) + 4
     bwd_tile = 4 * (_adj_floats(meta, 2, 1) + _adj_floats(meta, 3, 1) + mt0 * 48)

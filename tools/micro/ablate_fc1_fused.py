@@ -16,6 +16,7 @@ CSRC = os.path.join(ROOT, "space_time_pde_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "micro", "_abl")
 VARIANTS = {0: "full kernel", 1: "no activation jets", 2: "no weight-gradient MFMAs", 3: "no input-gradient MFMAs",
             7: "full kernel with phase stamps"}
+TAG = os.environ.get("FC1F_TAG", "")      # private builds with other compiler flags live side by side (FC1F_TAG=name)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 
@@ -26,7 +27,7 @@ def build(extra):
         "int stpde_wgrad_launch_%s(const WgradArgs&, int, hipStream_t) { return 0; }\n" % k for k in ("3_0", "3_1")))
     procs = []
     for n in VARIANTS:
-        so = os.path.join(OUT, "libfc1f_%d.so" % n)
+        so = os.path.join(OUT, "libfc1f%s_%d.so" % (TAG, n))
         srcs = [os.path.join(CSRC, f) for f in ("jet_fc1_bwd.hip", "api.cpp")]
         defs = ["-DSTPDE_FC1F_STAMP=1"] if n == 7 else ["-DSTPDE_FC1F_ABL=%d" % n]
         cmd = ["hipcc"] + FLAGS + defs + extra + ["-shared", "-o", so] + srcs + [stub]
@@ -60,7 +61,7 @@ def run():
     d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16, d.packed = nt, lay["KT"], lay["MT"], 1, cfg, 1, 6
     p = _lib.ptr
     for n, what in VARIANTS.items():
-        path = os.path.join(OUT, "libfc1f_%d.so" % n)
+        path = os.path.join(OUT, "libfc1f%s_%d.so" % (TAG, n))
         if not os.path.exists(path):
             continue
         L = C.CDLL(path)
@@ -81,7 +82,7 @@ def run():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        print("variant %d  %-28s %7.3f ms per 2^18 row tiles  (x2 = %.2f ms per 2^20 points)" % (n, what, ms, 2 * ms))
+        print(TAG, "variant %d  %-28s %7.3f ms per 2^18 row tiles  (x2 = %.2f ms per 2^20 points)" % (n, what, ms, 2 * ms))
         if n == 7:
             buf = (C.c_ulonglong * (8 * 4 * 8))()
             L.stpde_fc1f_stamp_read(buf)
