@@ -257,87 +257,223 @@ __device__ __forceinline__ ActD act_eval(int act, float prm, float a) {
 
 __device__ __forceinline__ float sel3(int d, float a0, float a1, float a2) { return d == 0 ? a0 : (d == 1 ? a1 : a2); }
 
+// ---- packed fp32 (round 5) ------------------------------------------------------------------------------------------
+// A wave64 VALU instruction occupies its SIMD for 4 cycles whether it is v_fma_f32 or v_pk_fma_f32 -- the packed forms
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 per lane) are how gfx950 reaches its fp32 vector peak -- and on the
+// fp32 MFMA kernels every VALU issue cycle is an MFMA cycle (tools/micro/mfma_valu_coissue.hip).  The compiler's SLP pass
+// packs almost nothing of the scalar jet code (phase stamps of the one-wave-per-SIMD kernel jet_fc1_bwd.hip: 4.7 cycles per
+// instruction of a pure vector phase = issue-bound), so the jets are written on pairs of elements: the four values a lane
+// holds of a fragment block go through as two f32x2.  Transcendentals, selects and max stay per component (no packed forms).
+#ifndef STPDE_JET_PACKED
+#define STPDE_JET_PACKED 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <class T>
+struct ActDT {
+  T s0, s1, s2, s3;
+};
+__device__ __forceinline__ f32x2 sel2(bool c0, bool c1, f32x2 a, f32x2 b) { return f32x2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+__device__ __forceinline__ f32x2 sel3(int d, f32x2 a0, f32x2 a1, f32x2 a2) { return d == 0 ? a0 : (d == 1 ? a1 : a2); }
+
+template <int ACT>
+__device__ __forceinline__ ActDT<f32x2> act_eval2_t(float prm, f32x2 a) {
+  STPDE_JET_FMA
+  ActDT<f32x2> r;
+  if (ACT == STPDE_ACT_SOFTPLUS) {
+    // the same expression sequence as act_eval_t<SOFTPLUS>, two elements at a time
+    const f32x2 t = f32x2{-fabsf(a.x), -fabsf(a.y)} * 1.44269504088896341f;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const f32x2 u = e + 1.f;
+    const f32x2 inv = f32x2{fast_rcp(u.x), fast_rcp(u.y)};
+    const f32x2 einv = e * inv;
+    const f32x2 s = sel2(a.x >= 0.f, a.y >= 0.f, inv, einv);
+    const f32x2 q = einv * inv;
+    const bool b0 = a.x > 20.f, b1 = a.y > 20.f;
+    const f32x2 lbig = f32x2{__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)} * 0.693147180559945309f;
+    const f32x2 lsmall = e * (1.f - e * (0.5f - e * 0.33333334f));
+    const f32x2 l1p = sel2(e.x < 9.765625e-4f, e.y < 9.765625e-4f, lsmall, lbig);
+    r.s0 = f32x2{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f)} + l1p;
+    const f32x2 one = f32x2{1.f, 1.f}, zero = f32x2{0.f, 0.f};
+    r.s1 = sel2(b0, b1, one, s);
+    r.s2 = sel2(b0, b1, zero, q);
+    r.s3 = sel2(b0, b1, zero, q * (1.f - 2.f * s));
+  } else {
+    const ActD x = act_eval_t<ACT>(prm, a.x), y = act_eval_t<ACT>(prm, a.y);
+    r.s0 = f32x2{x.s0, y.s0};
+    r.s1 = f32x2{x.s1, y.s1};
+    r.s2 = f32x2{x.s2, y.s2};
+    r.s3 = f32x2{x.s3, y.s3};
+  }
+  return r;
+}
+template <int ACT>
+__device__ __forceinline__ ActDT<f32x2> act_eval2(int act, float prm, f32x2 a) {
+  if (ACT >= 0) return act_eval2_t<(ACT >= 0 ? ACT : 0)>(prm, a);
+  const ActD x = act_eval<ACT>(act, prm, a.x), y = act_eval<ACT>(act, prm, a.y);
+  ActDT<f32x2> r;
+  r.s0 = f32x2{x.s0, y.s0};
+  r.s1 = f32x2{x.s1, y.s1};
+  r.s2 = f32x2{x.s2, y.s2};
+  r.s3 = f32x2{x.s3, y.s3};
+  return r;
+}
+// one evaluation interface for both widths
+template <int ACT>
+__device__ __forceinline__ ActDT<float> act_eval_w(int act, float prm, float a) {
+  const ActD s = act_eval<ACT>(act, prm, a);
+  return ActDT<float>{s.s0, s.s1, s.s2, s.s3};
+}
+template <int ACT>
+__device__ __forceinline__ ActDT<f32x2> act_eval_w(int act, float prm, f32x2 a) {
+  return act_eval2<ACT>(act, prm, a);
+}
+
 // Forward jet of the activation on one fragment block: pre[S] (a, adot_d, addot_p) -> h[S].
 // S2 == 1 is the COMBINED second-order stream: cq[0..5] = per-row weights of adot_a*adot_b over the canonical pairs
 // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2); otherwise cq is unused.
 // S1 == 0 && S2 > 0 is the VALUE-TILE mode of the forward-only (inference) kernels: the 1 + S2 "streams" are the value
 // streams of 1 + S2 independent, consecutive row tiles that share one pass over the weights.
+// (T = float: one element; T = f32x2: two elements of the lane's four, packed arithmetic)
+template <int S1, int S2, int ACT, class T>
+__device__ __forceinline__ void act_jet_fwd_w(const stpde_jet_cfg& cfg, const T* pre, T* h, const float* cq) {
+  STPDE_JET_FMA
+  const ActDT<T> s = act_eval_w<ACT>(cfg.act, cfg.act_param, pre[0]);
+  h[0] = s.s0;
+  if (S1 == 3) {
+    const T a0 = pre[1], a1 = pre[2], a2 = pre[3];
+    h[1] = s.s1 * a0;
+    h[2] = s.s1 * a1;
+    h[3] = s.s1 * a2;
+    if (S2 == 1) {
+      const T q = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
+      h[4] = s.s2 * q + s.s1 * pre[4];
+      return;
+    }
+#pragma unroll
+    for (int p = 0; p < S2; ++p) {
+      const T u = sel3(cfg.pair0[p], a0, a1, a2), v = sel3(cfg.pair1[p], a0, a1, a2);
+      h[4 + p] = s.s2 * u * v + s.s1 * pre[4 + p];
+    }
+  }
+}
 template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_fwd(const stpde_jet_cfg& cfg, const f32x4* pre, f32x4* h,
                                             const float* cq = nullptr) {
   STPDE_JET_FMA
+  constexpr int S = 1 + S1 + S2;
   if (S1 == 0 && S2 > 0) {
 #pragma unroll
-    for (int st = 0; st < 1 + S2; ++st)
+    for (int st = 0; st < 1 + S2; ++st) {
+#if STPDE_JET_PACKED
+      h[st].lo = act_eval_w<ACT>(cfg.act, cfg.act_param, (f32x2)pre[st].lo).s0;
+      h[st].hi = act_eval_w<ACT>(cfg.act, cfg.act_param, (f32x2)pre[st].hi).s0;
+#else
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[st][r] = act_eval<ACT>(cfg.act, cfg.act_param, pre[st][r]).s0;
+#endif
+    }
     return;
   }
+#if STPDE_JET_PACKED
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
-    h[0][r] = s.s0;
-    if (S1 == 3) {
-      float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
-      h[1][r] = s.s1 * a0;
-      h[2][r] = s.s1 * a1;
-      h[3][r] = s.s1 * a2;
-      if (S2 == 1) {
-        const float q = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
-        h[4][r] = s.s2 * q + s.s1 * pre[4][r];
-        continue;
-      }
+  for (int half = 0; half < 2; ++half) {
+    f32x2 p2[S], h2[S];
 #pragma unroll
-      for (int p = 0; p < S2; ++p) {
-        float u = sel3(cfg.pair0[p], a0, a1, a2), v = sel3(cfg.pair1[p], a0, a1, a2);
-        h[4 + p][r] = s.s2 * u * v + s.s1 * pre[4 + p][r];
-      }
+    for (int st = 0; st < S; ++st) p2[st] = half ? (f32x2)pre[st].hi : (f32x2)pre[st].lo;
+    act_jet_fwd_w<S1, S2, ACT, f32x2>(cfg, p2, h2, cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      if (half) h[st].hi = h2[st];
+      else h[st].lo = h2[st];
     }
   }
+#else
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float p1[S], h1[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) p1[st] = pre[st][r];
+    act_jet_fwd_w<S1, S2, ACT, float>(cfg, p1, h1, cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) h[st][r] = h1[st];
+  }
+#endif
 }
 
 // Adjoint: given pre[S] and hbar[S], produce abar[S] (adjoint of the pre-activation streams).
+template <int S1, int S2, int ACT, class T>
+__device__ __forceinline__ void act_jet_adj_w(const stpde_jet_cfg& cfg, const T* pre, const T* hbar, T* abar, const float* cq) {
+  STPDE_JET_FMA
+  const ActDT<T> s = act_eval_w<ACT>(cfg.act, cfg.act_param, pre[0]);
+  T ab = s.s1 * hbar[0];
+  if (S1 == 3) {
+    const T a0 = pre[1], a1 = pre[2], a2 = pre[3];
+    T d0 = s.s1 * hbar[1], d1 = s.s1 * hbar[2], d2 = s.s1 * hbar[3];
+    ab += s.s2 * (a0 * hbar[1] + a1 * hbar[2] + a2 * hbar[3]);
+    if (S2 == 1) {
+      const T hb = hbar[4];
+      const T q = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
+      ab += (s.s3 * q + s.s2 * pre[4]) * hb;
+      const T t = s.s2 * hb;
+      d0 += t * (2.f * cq[0] * a0 + cq[1] * a1 + cq[2] * a2);
+      d1 += t * (cq[1] * a0 + 2.f * cq[3] * a1 + cq[4] * a2);
+      d2 += t * (cq[2] * a0 + cq[4] * a1 + 2.f * cq[5] * a2);
+      abar[4] = s.s1 * hb;
+    }
+#pragma unroll
+    for (int p = 0; p < (S2 == 1 ? 0 : S2); ++p) {
+      const int e0 = cfg.pair0[p], e1 = cfg.pair1[p];
+      const T u = sel3(e0, a0, a1, a2), v = sel3(e1, a0, a1, a2);
+      const T hb = hbar[4 + p];
+      ab += (s.s3 * u * v + s.s2 * pre[4 + p]) * hb;
+      const T t0 = s.s2 * v * hb;  // d hdd / d adot_{e0}
+      const T t1 = s.s2 * u * hb;  // d hdd / d adot_{e1}
+      const T z = t0 * 0.f;
+      d0 += (e0 == 0 ? t0 : z) + (e1 == 0 ? t1 : z);
+      d1 += (e0 == 1 ? t0 : z) + (e1 == 1 ? t1 : z);
+      d2 += (e0 == 2 ? t0 : z) + (e1 == 2 ? t1 : z);
+      abar[4 + p] = s.s1 * hb;
+    }
+    abar[1] = d0;
+    abar[2] = d1;
+    abar[3] = d2;
+  }
+  abar[0] = ab;
+}
 template <int S1, int S2, int ACT>
 __device__ __forceinline__ void act_jet_adj(const stpde_jet_cfg& cfg, const f32x4* pre, const f32x4* hbar,
                                             f32x4* abar, const float* cq = nullptr) {
-  STPDE_JET_FMA
+  constexpr int S = 1 + S1 + S2;
+#if STPDE_JET_PACKED
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x2 p2[S], hb2[S], ab2[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      p2[st] = half ? (f32x2)pre[st].hi : (f32x2)pre[st].lo;
+      hb2[st] = half ? (f32x2)hbar[st].hi : (f32x2)hbar[st].lo;
+    }
+    act_jet_adj_w<S1, S2, ACT, f32x2>(cfg, p2, hb2, ab2, cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      if (half) abar[st].hi = ab2[st];
+      else abar[st].lo = ab2[st];
+    }
+  }
+#else
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    ActD s = act_eval<ACT>(cfg.act, cfg.act_param, pre[0][r]);
-    float ab = s.s1 * hbar[0][r];
-    if (S1 == 3) {
-      float a0 = pre[1][r], a1 = pre[2][r], a2 = pre[3][r];
-      float d0 = s.s1 * hbar[1][r], d1 = s.s1 * hbar[2][r], d2 = s.s1 * hbar[3][r];
-      ab += s.s2 * (a0 * hbar[1][r] + a1 * hbar[2][r] + a2 * hbar[3][r]);
-      if (S2 == 1) {
-        const float hb = hbar[4][r];
-        const float q = a0 * (cq[0] * a0 + cq[1] * a1 + cq[2] * a2) + a1 * (cq[3] * a1 + cq[4] * a2) + cq[5] * a2 * a2;
-        ab += (s.s3 * q + s.s2 * pre[4][r]) * hb;
-        const float t = s.s2 * hb;
-        d0 += t * (2.f * cq[0] * a0 + cq[1] * a1 + cq[2] * a2);
-        d1 += t * (cq[1] * a0 + 2.f * cq[3] * a1 + cq[4] * a2);
-        d2 += t * (cq[2] * a0 + cq[4] * a1 + 2.f * cq[5] * a2);
-        abar[4][r] = s.s1 * hb;
-      }
+    float p1[S], hb1[S], ab1[S];
 #pragma unroll
-      for (int p = 0; p < (S2 == 1 ? 0 : S2); ++p) {
-        int e0 = cfg.pair0[p], e1 = cfg.pair1[p];
-        float u = sel3(e0, a0, a1, a2), v = sel3(e1, a0, a1, a2);
-        float hb = hbar[4 + p][r];
-        ab += (s.s3 * u * v + s.s2 * pre[4 + p][r]) * hb;
-        float t0 = s.s2 * v * hb;  // d hdd / d adot_{e0}
-        float t1 = s.s2 * u * hb;  // d hdd / d adot_{e1}
-        d0 += (e0 == 0 ? t0 : 0.f) + (e1 == 0 ? t1 : 0.f);
-        d1 += (e0 == 1 ? t0 : 0.f) + (e1 == 1 ? t1 : 0.f);
-        d2 += (e0 == 2 ? t0 : 0.f) + (e1 == 2 ? t1 : 0.f);
-        abar[4 + p][r] = s.s1 * hb;
-      }
-      abar[1][r] = d0;
-      abar[2][r] = d1;
-      abar[3][r] = d2;
+    for (int st = 0; st < S; ++st) {
+      p1[st] = pre[st][r];
+      hb1[st] = hbar[st][r];
     }
-    abar[0][r] = ab;
+    act_jet_adj_w<S1, S2, ACT, float>(cfg, p1, hb1, ab1, cq);
+#pragma unroll
+    for (int st = 0; st < S; ++st) abar[st][r] = ab1[st];
   }
+#endif
 }
 
 // Adjoint of the learnable swish beta (reference nonlinearities.py:5-12): sum over the block of
