@@ -531,7 +531,7 @@ def main(argv=None):
             gs = dict(bound="hbm", achieved=round(1036.0 * g_pts / (g_ms * 1e-3) / 1e9, 1),
                       peak=8000.0, unit="GB/s", avg_launch_ms=round(g_ms, 3),
                       note="achieved = algorithmic 12 B coords + 8 x 32 x 4 B corner latents per point / launch time; the kernel "
-                           "also writes the fragment images of the MLP input (X and, for training, XR: 6 KiB per point); "
+                           "also writes the column-major fragment image X of the MLP input (1.5 KiB per point; no row-major copy XR since round 5); "
                            "measured_* = HBM bytes of the launch from the committed rocprofv3 FETCH_SIZE (x2) / WRITE_SIZE passes")
             try:
                 tj = json.load(open(args.traffic_json))

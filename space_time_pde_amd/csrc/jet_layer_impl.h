@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // faster.  The split of the activations is done once per workgroup in the produce stage, that of the weights on the host.
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1, bool WRING = false,
           int SPL = 1, int PKM = 0>
-__global__ __launch_bounds__(64 * NW, (!BF && PRO == PRO_ACT && EPI == EPI_FWD && MCg == 2 && NW == 4 && !WRING && S1 + S2 <= 4 && STPDE_FWD2_OCC3) ? 3 : 2) void k_layer_coop(LayerArgs a) {
+__global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EPI == EPI_FWD && MCg == 2 && NW == 4 && !WRING && S1 + S2 <= 4 && STPDE_FWD2_OCC3) ? 3 : 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, GK = NW * PK;
   static_assert(!WRING || (!BF && GK == 4), "the weight ring is written for 4 k-tiles per group, fp32");
   static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");

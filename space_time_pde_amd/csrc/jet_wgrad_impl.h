@@ -757,8 +757,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
 // contraction over the rows then runs on v_mfma_f32_16x16x16_bf16 (BFM): the four fp32 k-steps of a transposed block pair
 // are one bf16 MFMA on the rounded blocks (same (lane group, element) -> row map on both operands, so the sum is the same).
 // The raw-input columns (exact skip operand) stay on the fp32 MFMA.
+// (occupancy stated: with the packed jets of round 5 the allocator took 294 registers for the fc4 shape -- one wave per SIMD
+// instead of two, 2.2 -> 3.4 ms in bf16 mode -- where 219 had done)
 template <int S1, int S2, int ACT, int MCW, int KTT, int PKW = 0, bool BFM = false>
-__global__ __launch_bounds__(256) void k_wgrad_wave(WgradArgs a) {
+__global__ __launch_bounds__(256, (MCW * (KTT + XT) <= 8) ? 3 : ((MCW * (KTT + XT) <= 14) ? 2 : 1)) void k_wgrad_wave(WgradArgs a) {
   constexpr int S = 1 + S1 + S2, NK = KTT + XT;
   constexpr int TP = 24, TBLK = 16 * TP;
   __shared__ __attribute__((aligned(16))) float pp[4][2][TBLK];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of the U-Net alone (tools/unet_profile.py), fused residual blocks on / off, both grids
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-O=$PWD/gpurun_out/r4j
+O=$PWD/gpurun_out/r5_unet
 mkdir -p $O
 export TMPDIR=/tmp
 for g in "32 128 128" "64 256 256"; do
