@@ -274,8 +274,15 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
   // bias gradient (column sums of ybar) from the staged block: thread -> (channel, every (512 / Co)-th voxel)
   const int bc = threadIdx.x % Co, bv0 = threadIdx.x / Co;
   float bsum = 0.f;
-#pragma unroll 1
-  for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+  // Staging is software-pipelined through registers (round 5): the 16-byte loads of block n + 1 (halo tile + output-gradient
+  // tile: NXI + NYI per thread) are issued right after block n has been written to LDS and are in flight during its
+  // MFMA loop; they used to sit, NXI + NYI dependent round trips long, between two barriers with nothing to cover them but
+  // the other workgroup of the CU.
+  constexpr int NXQ = NH * (Ci / 4), NYQ = NV * (Co / 4);
+  constexpr int NXI = (NXQ + 511) / 512, NYI = NYQ / 512;
+  static_assert(NYQ % 512 == 0, "output-gradient tile: whole rounds of the workgroup");
+  f32x4 px[NXI], py[NYI];
+  auto fetch = [&](int bi) {
     int r = bi;
     const int x0 = (r % nbx) * TX;
     r /= nbx;
@@ -283,25 +290,48 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
     r /= nbz;
     const int t0 = (r % nbt) * TT;
     const int b = r / nbt;
-    __syncthreads();                                   // the readers of the previous block are done
-    for (int idx = threadIdx.x; idx < NH * (Ci / 4); idx += 512) {
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+      const int idx = threadIdx.x + 512 * it;
       const int q = idx % (Ci / 4), hv = idx / (Ci / 4);
       const int hx = hv % HX, hz = (hv / HX) % HZ, ht = hv / (HX * HZ);
       const int t = t0 + ht - 1, z = z0 + hz - 1, x = x0 + hx - 1;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t >= 0 && t < T && z >= 0 && z < Z && x >= 0 && x < X)
+      if (idx < NXQ && t >= 0 && t < T && z >= 0 && z < Z && x >= 0 && x < X)
         v = ld4(a.x + ((((size_t)b * T + t) * Z + z) * X + x) * Ci + 4 * q);
-      const int qs = CIT == 2 ? (q ^ ((hv & 1) << 2)) : q;
-      st4(xs + hv * Ci + 4 * qs, v);
+      px[it] = v;
     }
-    for (int idx = threadIdx.x; idx < NV * (Co / 4); idx += 512) {
+#pragma unroll
+    for (int it = 0; it < NYI; ++it) {
+      const int idx = threadIdx.x + 512 * it;
       const int q = idx % (Co / 4), vv = idx / (Co / 4);
       const int xx = vv % TX, zz = (vv / TX) % TZ, tt = vv / (TX * TZ);
-      const f32x4 v = ld4(a.ybar + ((((size_t)b * T + t0 + tt) * Z + z0 + zz) * X + x0 + xx) * Co + 4 * q);
-      const int qs = COT == 2 ? (q ^ ((vv & 1) << 2)) : q;
-      st4(ys + vv * Co + 4 * qs, v);
+      py[it] = ld4(a.ybar + ((((size_t)b * T + t0 + tt) * Z + z0 + zz) * X + x0 + xx) * Co + 4 * q);
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+      const int idx = threadIdx.x + 512 * it;
+      const int q = idx % (Ci / 4), hv = idx / (Ci / 4);
+      const int qs = CIT == 2 ? (q ^ ((hv & 1) << 2)) : q;
+      if (idx < NXQ) st4(xs + hv * Ci + 4 * qs, px[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < NYI; ++it) {
+      const int idx = threadIdx.x + 512 * it;
+      const int q = idx % (Co / 4), vv = idx / (Co / 4);
+      const int qs = COT == 2 ? (q ^ ((vv & 1) << 2)) : q;
+      st4(ys + vv * Co + 4 * qs, py[it]);
+    }
+  };
+  if ((int)blockIdx.x < nblk) fetch(blockIdx.x);
+#pragma unroll 1
+  for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+    __syncthreads();                                   // the readers of the previous block are done
+    stage();
     __syncthreads();
+    if (bi + (int)gridDim.x < nblk) fetch(bi + gridDim.x);
     if (a.dbias) {
       for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (COT == 2 ? (bc ^ ((vv & 1) << 4)) : bc)];
     }
@@ -337,7 +367,17 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       }
     }
   }
-  if (a.dbias) atomicAdd(a.dbias + bc, bsum);
+  if (a.dbias) {            // (block-uniform) one atomic per channel and workgroup: the 512 / Co partial sums of a channel meet
+    __syncthreads();        // in LDS first (round 5: 512 same-address atomics per workgroup serialised in L2 -- with the
+    xs[threadIdx.x] = bsum; // pipelined staging, 16 -> 16 channels on 4.2 M voxels: 1199 -> 591 us, 48 -> 98 TFLOP/s)
+    __syncthreads();
+    if (threadIdx.x < Co) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 512 / Co; ++k) sum += xs[threadIdx.x + Co * k];
+      atomicAdd(a.dbias + threadIdx.x, sum);
+    }
+  }
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
     if (ti >= ntap_w) continue;
@@ -349,6 +389,160 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
         for (int rr = 0; rr < 4; ++rr)
           atomicAdd(a.dW + ((size_t)(tap0 + ti) * Co + 16 * co + 4 * g + rr) * Ci + 16 * ci + j, acc[ti][co][ci][rr]);
   }
+}
+
+// Weight gradient of the 1x1x1 convolutions of the wide levels (round 5): dW[co][ci] = sum over voxels of ybar[v][co] x[v][ci]
+// is a GEMM whose contraction runs over the voxels, i.e. over the SLOW index of both channels-last operands.  The per-wave kernel
+// above fetches every MFMA operand element with a dword load (64-byte segments, ~2.5 TB/s on 16-channel tensors: these launches
+// are HBM bound and reached 40-50 % of the stream rate).  Here a persistent workgroup of 8 waves stages 256 consecutive voxels of
+// both operands with 16-byte loads -- software-pipelined through registers like the 3x3x3 kernel above, so a block's loads are
+// in flight while the previous block's MFMAs run -- and the waves read their fragments from LDS (ds_read_b32: lane 16 k + i ->
+// voxel 4 s + k, channel i; channel bit 4 is flipped on odd voxels when a voxel's row is a multiple of 32 banks long).
+// ONLOAD: x' = max(0, bn(x)) applied between the registers and LDS (conv3 of a residual block, see k_conv3d_wgrad).
+// Every wave owns two of the block's 16 voxel tiles and all COT x CIT accumulator tiles; the 8 waves meet in LDS at the end.
+template <int CIT, int COT, bool ONLOAD>
+__global__ __launch_bounds__(512) void k_conv1_wgrad_lds(ConvArgs a) {
+  constexpr int NV = 256, Ci = 16 * CIT, Co = 16 * COT;
+  constexpr bool SWX = CIT % 2 == 0, SWY = COT % 2 == 0;
+  __shared__ __attribute__((aligned(16))) float xs[NV * Ci];
+  __shared__ __attribute__((aligned(16))) float ys[NV * Co];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  f32x4 acc[COT][CIT];
+#pragma unroll
+  for (int co = 0; co < COT; ++co)
+#pragma unroll
+    for (int ci = 0; ci < CIT; ++ci) acc[co][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nblk = (a.nvox + NV - 1) / NV;
+  const int bc = threadIdx.x % Co, bv0 = threadIdx.x / Co;
+  float bsum = 0.f;
+  constexpr int NXI = NV * (Ci / 4) / 512, NYI = NV * (Co / 4) / 512;      // = 2 CIT, 2 COT
+  // 512 is a multiple of Ci / 4 and Co / 4: a thread stages the same channel quad in every round
+  const int qx = threadIdx.x % (Ci / 4), vx0 = threadIdx.x / (Ci / 4);
+  const int qy = threadIdx.x % (Co / 4), vy0 = threadIdx.x / (Co / 4);
+  f32x4 omean, oscale, obeta;
+  if (ONLOAD) {
+    omean = ld4(a.in_stat + 4 * qx);
+    oscale = ld4(a.in_stat + Ci + 4 * qx);
+    if (a.in_gamma) oscale = oscale * ld4(a.in_gamma + 4 * qx);
+    obeta = a.in_beta ? ld4(a.in_beta + 4 * qx) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 px[NXI], py[NYI];
+  auto fetch = [&](int bi) {
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+      const int v = bi * NV + vx0 + (512 / (Ci / 4)) * it;
+      px[it] = v < a.nvox ? ld4(a.x + (size_t)v * Ci + 4 * qx) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NYI; ++it) {
+      const int v = bi * NV + vy0 + (512 / (Co / 4)) * it;
+      py[it] = v < a.nvox ? ld4(a.ybar + (size_t)v * Co + 4 * qy) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stage = [&](int bi) {
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+      const int vv = vx0 + (512 / (Ci / 4)) * it;
+      f32x4 v = px[it];
+      if (ONLOAD) {
+        v = (v - omean) * oscale + obeta;
+        const bool in = bi * NV + vv < a.nvox;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (in && v[r] > 0.f) ? v[r] : 0.f;
+      }
+      st4(xs + vv * Ci + 4 * (SWX ? (qx ^ ((vv & 1) << 2)) : qx), v);
+    }
+#pragma unroll
+    for (int it = 0; it < NYI; ++it) {
+      const int vv = vy0 + (512 / (Co / 4)) * it;
+      st4(ys + vv * Co + 4 * (SWY ? (qy ^ ((vv & 1) << 2)) : qy), py[it]);
+    }
+  };
+  if ((int)blockIdx.x < nblk) fetch(blockIdx.x);
+#pragma unroll 1
+  for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+    __syncthreads();                                   // the readers of the previous block are done
+    stage(bi);
+    __syncthreads();
+    if (bi + (int)gridDim.x < nblk) fetch(bi + gridDim.x);
+    if (a.dbias) {
+      for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (SWY ? (bc ^ ((vv & 1) << 4)) : bc)];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int sk = 0; sk < 4; ++sk) {
+        const int vv = 16 * (2 * wv + t) + 4 * sk + g;
+        const int sw = (vv & 1) << 4;
+        float pa[COT], qb[CIT];
+#pragma unroll
+        for (int co = 0; co < COT; ++co) pa[co] = ys[vv * Co + ((16 * co + j) ^ (SWY ? sw : 0))];
+#pragma unroll
+        for (int ci = 0; ci < CIT; ++ci) qb[ci] = xs[vv * Ci + ((16 * ci + j) ^ (SWX ? sw : 0))];
+#pragma unroll
+        for (int co = 0; co < COT; ++co)
+#pragma unroll
+          for (int ci = 0; ci < CIT; ++ci) acc[co][ci] = mfma4(pa[co], qb[ci], acc[co][ci]);
+      }
+    }
+  }
+  // the 8 waves' partial tiles meet in LDS (tile by tile, xs is free now): one set of atomics per workgroup
+  float* red = xs;                                     // [8][256] floats = 8 KB <= NV * 16 * 4
+  if (a.dbias) {                                       // (block-uniform) the 512 / Co partial column sums of a channel first:
+    __syncthreads();                                   // 512 same-address atomics per workgroup serialise in L2
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < Co) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 512 / Co; ++k) sum += red[threadIdx.x + Co * k];
+      atomicAdd(a.dbias + threadIdx.x, sum);
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COT; ++co)
+#pragma unroll
+    for (int ci = 0; ci < CIT; ++ci) {
+      __syncthreads();
+      st4(red + wv * 256 + lane * 4, acc[co][ci]);
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        const int l = threadIdx.x >> 2, rr = threadIdx.x & 3;      // element rr of lane l's fragment
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += red[w * 256 + threadIdx.x];
+        atomicAdd(a.dW + ((size_t)(16 * co + 4 * (l >> 4) + rr)) * Ci + 16 * ci + (l & 15), sum);
+      }
+    }
+}
+
+template <bool ONLOAD>
+static bool launch_conv1_wgrad_lds(const ConvArgs& a, hipStream_t st) {
+  const int Ci = a.d.Ci, Co = a.d.Co;
+  static const int env = getenv("STPDE_CONV1_WGRAD_LDS") ? atoi(getenv("STPDE_CONV1_WGRAD_LDS")) : 1;
+  if (!env || a.d.ksize != 1 || (Ci != 16 && Ci != 32 && Ci != 64) || (Co != 16 && Co != 32 && Co != 64) || a.nvox < 65536)
+    return false;
+  const int nblk = (a.nvox + 255) / 256;
+  // persistent workgroups: as many per CU as their LDS tiles (1 KB per channel of x and ybar) and 32 wave slots allow
+  int per_cu = 160 / (Ci + Co + 1);
+  if (per_cu > 4) per_cu = 4;
+  static const int gx_env = getenv("STPDE_CONV1_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV1_WGRAD_LDS_GX")) : 0;
+  int gx = gx_env > 0 ? gx_env : 256 * per_cu;
+  if (gx > nblk) gx = nblk;
+#define STPDE_C1W(CIT, COT)                                                                              \
+  if (Ci == 16 * CIT && Co == 16 * COT) {                                                               \
+    if constexpr (ONLOAD)                                                                               \
+      STPDE_LAUNCH((k_conv1_wgrad_lds<CIT, COT, true>), dim3(gx), dim3(512), 0, st, a);                  \
+    else                                                                                                \
+      STPDE_LAUNCH((k_conv1_wgrad_lds<CIT, COT, false>), dim3(gx), dim3(512), 0, st, a);                 \
+    return true;                                                                                        \
+  }
+  STPDE_C1W(1, 1) STPDE_C1W(1, 2) STPDE_C1W(1, 4) STPDE_C1W(2, 1) STPDE_C1W(2, 2) STPDE_C1W(2, 4) STPDE_C1W(4, 1)
+  STPDE_C1W(4, 2) STPDE_C1W(4, 4)
+#undef STPDE_C1W
+  return false;
 }
 
 static int check_conv(const stpde_conv3d_desc* d) {
@@ -435,6 +629,7 @@ extern "C" int stpde_conv3d_wgrad_onload(const stpde_conv3d_desc* d, const float
   a.in_gamma = in_gamma;
   a.in_beta = in_beta;
   a.nvox = d->B * d->T * d->Z * d->X;
+  if (launch_conv1_wgrad_lds<true>(a, (hipStream_t)stream)) return stpde_check_launch("k_conv1_wgrad_lds");
   const int ntiles = (a.nvox + 15) / 16;
   const int KT = d->Ci / 16, MT = d->Co / 16;
   const int gy = ((MT + 1) / 2) * ((KT + 1) / 2);
@@ -469,6 +664,7 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
   a.dW = dW;
   a.dbias = dbias;
   a.nvox = d->B * d->T * d->Z * d->X;
+  if (launch_conv1_wgrad_lds<false>(a, (hipStream_t)stream)) return stpde_check_launch("k_conv1_wgrad_lds");
   const int ntiles = (a.nvox + 15) / 16;
   const int KT = d->Ci / 16, MT = d->Co / 16;
   // (tap group, co block, ci block) triples on blockIdx.y; voxel-tile stripes on blockIdx.x: ~2048 blocks in total

@@ -143,6 +143,40 @@ def test_batchnorm_relu_on_load_and_its_weight_gradient(hiplib, shape):
     assert _rel(dw[0], ref) < 2e-5 and _rel(db, gy.double().reshape(-1, co).sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("onload", [False, True])
+@pytest.mark.parametrize("ci,co", [(16, 16), (16, 32), (16, 64), (32, 16), (32, 32), (32, 64), (64, 16), (64, 32), (64, 64)])
+def test_conv1_weight_gradient_from_lds_tiles_ragged_volume(hiplib, ci, co, onload):
+    """k_conv1_wgrad_lds (csrc/conv3d.hip, round 5): the 1x1x1 weight / bias gradient of volumes >= 65,536 voxels from
+    256-voxel LDS tiles, every channel-tile combination it is compiled for, plain and with BatchNorm + ReLU on load, on a
+    volume that is NOT a whole number of tiles (the last tile is zero-filled -- also AFTER the on-load transform, whose
+    image of 0 is not 0)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11 + ci + 3 * co)
+    shape = (1, 5, 111, 119)                            # 66,045 voxels = 257 tiles + 253 voxels
+    x = 1.5 * torch.randn(*shape, ci, device=dev) + 0.4
+    gy = torch.randn(*shape, co, device=dev)
+    gam, bet = torch.rand(ci, device=dev) + 0.5, 0.3 * torch.randn(ci, device=dev) + 0.2
+    xs = x.double().reshape(-1, ci)
+    mean, rstd = xs.mean(0), 1 / torch.sqrt(xs.var(0, unbiased=False) + 1e-5)
+    stat = torch.cat([mean, rstd]).float().contiguous()
+    dw, db = torch.zeros(1, co, ci, device=dev), torch.zeros(co, device=dev)
+    d = unet3d._desc(x, ci, co, 1)
+    with _lib.dispatch_trace() as tr:
+        if onload:
+            _lib.check(hiplib.stpde_conv3d_wgrad_onload(C.byref(d), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), _lib.ptr(db),
+                                                        _lib.ptr(stat), _lib.ptr(gam), _lib.ptr(bet), _lib.stream_ptr()))
+        else:
+            _lib.check(hiplib.stpde_conv3d_wgrad_bias(C.byref(d), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), _lib.ptr(db),
+                                                      _lib.stream_ptr()))
+        torch.cuda.synchronize()
+    assert tr.has("k_conv1_wgrad_lds<%d, %d, %s>" % (ci // 16, co // 16, "true" if onload else "false")), "\n".join(tr.kernels)
+    h = x.double()
+    if onload:
+        h = torch.relu((h - stat[:ci].double()) * (stat[ci:].double() * gam.double()) + bet.double())
+    ref = gy.double().reshape(-1, co).t() @ h.reshape(-1, ci)
+    assert _rel(dw[0], ref) < 2e-5 and _rel(db, gy.double().reshape(-1, co).sum(0)) < 2e-5
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("k,c", [(1, 32), (3, 16), (3, 32)])
 def test_mask_and_batchnorm_backward_sums_epilogue(hiplib, shape, k, c):

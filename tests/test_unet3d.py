@@ -170,8 +170,10 @@ def test_conv3d_at_bench_volume_vs_torch_fp64(hiplib, ci, co, k):
         torch.cuda.synchronize()
     mt = co // 16
     assert tr.has("k_conv3d_fwd<%d, 4>" % min(mt, 4)), "\n".join(tr.kernels)     # forward: 4 voxel tiles per wave
-    # weight gradient: the LDS-tile kernel for the 3x3x3 convolutions of these levels, the per-wave kernel otherwise
-    assert tr.has("k_conv3d_wgrad_lds" if (k == 3 and ci >= 16) else "k_conv3d_wgrad<"), "\n".join(tr.kernels)
+    # weight gradient: the LDS-tile kernels of these levels (3x3x3: halo tiles; 1x1x1: 256-voxel tiles, round 5), the per-wave
+    # kernel for the 4-channel input layer (padded to one 16-channel tile by _conv_cl, and not worth a variant)
+    want = "k_conv3d_wgrad_lds" if k == 3 else "k_conv1_wgrad_lds<%d, %d, false>" % (max(ci, 16) // 16, co // 16)
+    assert tr.has(want), "\n".join(tr.kernels)
     c64 = torch.nn.Conv3d(ci, co, k, padding=(k - 1) // 2).double()
     c64.load_state_dict({kk: v.double().cpu() for kk, v in cd.state_dict().items()})
     x64 = x.double().requires_grad_(True)
