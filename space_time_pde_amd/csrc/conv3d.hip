@@ -250,9 +250,19 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
 // the two waves of a SIMD carry 7 7 7 6 taps), every wave keeps the accumulators of its taps for the whole launch and adds them
 // with one set of fp32 atomics at the end.  32-channel tiles: the two 16-channel halves of a voxel are swapped on odd voxels,
 // so that the two voxels a half-wave reads in one ds_read_b32 land in different banks.
-template <int CIT, int COT>
+// TX (round 5): 16-voxel rows for the 64-channel level (a 32-voxel halo tile of 64 channels would not fit), whose output
+// channels are additionally split over blockIdx.y in groups of COT tiles (COS = all of them): 4 taps x 4 x 4 accumulator
+// tiles would not fit the register file; the workgroups of one block stage the same halo tile (from L2).
+// 16-byte load at a uniform base + a 32-bit byte offset per lane (one address register instead of two; the dispatch keeps the
+// tensors below 4 GiB)
+__device__ __forceinline__ f32x4 ld4_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int CIT, int COT, int TX = 32, int COS = COT>
 __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
-  constexpr int TT = 2, TZ = 4, TX = 32, HT = TT + 2, HZ = TZ + 2, HX = TX + 2;
+  constexpr int TT = 2, TZ = 4, HT = TT + 2, HZ = TZ + 2, HX = TX + 2, NXH = TX / 16;
+  constexpr int CoF = 16 * COS;                        // channels of a voxel of ybar in memory
+  const int coh = COS == COT ? 0 : blockIdx.y * COT;   // first output tile of this workgroup
   constexpr int Ci = 16 * CIT, Co = 16 * COT, NH = HT * HZ * HX, NV = TT * TZ * TX;
   __shared__ __attribute__((aligned(16))) float xs[NH * Ci];
   __shared__ __attribute__((aligned(16))) float ys[NV * Co];
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       const int t = t0 + ht - 1, z = z0 + hz - 1, x = x0 + hx - 1;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (idx < NXQ && t >= 0 && t < T && z >= 0 && z < Z && x >= 0 && x < X)
-        v = ld4(a.x + ((((size_t)b * T + t) * Z + z) * X + x) * Ci + 4 * q);
+        v = ld4_off(a.x, (unsigned)((((b * T + t) * Z + z) * X + x) * Ci + 4 * q) * 4u);
       px[it] = v;
     }
 #pragma unroll
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       const int idx = threadIdx.x + 512 * it;
       const int q = idx % (Co / 4), vv = idx / (Co / 4);
       const int xx = vv % TX, zz = (vv / TX) % TZ, tt = vv / (TX * TZ);
-      py[it] = ld4(a.ybar + ((((size_t)b * T + t0 + tt) * Z + z0 + zz) * X + x0 + xx) * Co + 4 * q);
+      py[it] = ld4_off(a.ybar, (unsigned)((((b * T + t0 + tt) * Z + z0 + zz) * X + x0 + xx) * CoF + 16 * coh + 4 * q) * 4u);
     }
   };
   auto stage = [&]() {
@@ -314,14 +324,14 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
     for (int it = 0; it < NXI; ++it) {
       const int idx = threadIdx.x + 512 * it;
       const int q = idx % (Ci / 4), hv = idx / (Ci / 4);
-      const int qs = CIT == 2 ? (q ^ ((hv & 1) << 2)) : q;
+      const int qs = CIT % 2 == 0 ? (q ^ ((hv & 1) << 2)) : q;
       if (idx < NXQ) st4(xs + hv * Ci + 4 * qs, px[it]);
     }
 #pragma unroll
     for (int it = 0; it < NYI; ++it) {
       const int idx = threadIdx.x + 512 * it;
       const int q = idx % (Co / 4), vv = idx / (Co / 4);
-      const int qs = COT == 2 ? (q ^ ((vv & 1) << 2)) : q;
+      const int qs = COT % 2 == 0 ? (q ^ ((vv & 1) << 2)) : q;
       st4(ys + vv * Co + 4 * qs, py[it]);
     }
   };
@@ -333,36 +343,50 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
     __syncthreads();
     if (bi + (int)gridDim.x < nblk) fetch(bi + gridDim.x);
     if (a.dbias) {
-      for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (COT == 2 ? (bc ^ ((vv & 1) << 4)) : bc)];
+      for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (COT % 2 == 0 ? (bc ^ ((vv & 1) << 4)) : bc)];
     }
 #pragma unroll 1
     for (int vt = 0; vt < NV / 16; ++vt) {             // 16-voxel tiles along x: (tt, zz, half of the 32-voxel row)
-      const int xh = vt & 1, zz = (vt >> 1) & 3, tt = vt >> 3;
+      const int xh = vt % NXH, zz = (vt / NXH) % TZ, tt = vt / (NXH * TZ);
       const int vv = (tt * TZ + zz) * TX + 16 * xh + g;           // this lane's voxel of k-step 0 (k-step s: + 4 s)
       float pa[COT][4];
 #pragma unroll
       for (int co = 0; co < COT; ++co)
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk)
-          pa[co][sk] = ys[(vv + 4 * sk) * Co + 16 * (COT == 2 ? (co ^ (vv & 1)) : co) + j];
+          pa[co][sk] = ys[(vv + 4 * sk) * Co + 16 * (COT % 2 == 0 ? (co ^ (vv & 1)) : co) + j];
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         if (ti < ntap_w) {                             // wave-uniform
           const int tap = tap0 + ti;
           const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
           const int hv = ((tt + 1 + dt) * HZ + (zz + 1 + dz)) * HX + 16 * xh + 1 + dx + g;
-          float qb[CIT][4];
+          if constexpr (CIT <= 2) {
+            float qb[CIT][4];
 #pragma unroll
-          for (int ci = 0; ci < CIT; ++ci)
+            for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+              for (int sk = 0; sk < 4; ++sk)
+                qb[ci][sk] = xs[(hv + 4 * sk) * Ci + 16 * (CIT % 2 == 0 ? (ci ^ (hv & 1)) : ci) + j];
 #pragma unroll
             for (int sk = 0; sk < 4; ++sk)
-              qb[ci][sk] = xs[(hv + 4 * sk) * Ci + 16 * (CIT == 2 ? (ci ^ (hv & 1)) : ci) + j];
 #pragma unroll
-          for (int sk = 0; sk < 4; ++sk)
+              for (int co = 0; co < COT; ++co)
 #pragma unroll
-            for (int co = 0; co < COT; ++co)
+                for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = mfma4(pa[co][sk], qb[ci][sk], acc[ti][co][ci]);
+          } else {                                     // many input tiles: fragments k-step by k-step (register budget)
 #pragma unroll
-              for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = mfma4(pa[co][sk], qb[ci][sk], acc[ti][co][ci]);
+            for (int sk = 0; sk < 4; ++sk) {
+              float qb[CIT];
+#pragma unroll
+              for (int ci = 0; ci < CIT; ++ci) qb[ci] = xs[(hv + 4 * sk) * Ci + 16 * (ci ^ (hv & 1)) + j];
+#pragma unroll
+              for (int co = 0; co < COT; ++co)
+#pragma unroll
+                for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = mfma4(pa[co][sk], qb[ci], acc[ti][co][ci]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
       }
     }
@@ -375,7 +399,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int k = 0; k < 512 / Co; ++k) sum += xs[threadIdx.x + Co * k];
-      atomicAdd(a.dbias + threadIdx.x, sum);
+      atomicAdd(a.dbias + 16 * coh + threadIdx.x, sum);
     }
   }
 #pragma unroll
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       for (int ci = 0; ci < CIT; ++ci)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          atomicAdd(a.dW + ((size_t)(tap0 + ti) * Co + 16 * co + 4 * g + rr) * Ci + 16 * ci + j, acc[ti][co][ci][rr]);
+          atomicAdd(a.dW + ((size_t)(tap0 + ti) * CoF + 16 * (coh + co) + 4 * g + rr) * Ci + 16 * ci + j, acc[ti][co][ci][rr]);
   }
 }
 
@@ -687,9 +711,10 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
     // on half of the CUs it is neutral there and still 2x the per-wave kernel when it runs alone.  STPDE_CONV_WGRAD_LDS_GX
     // overrides.
     static const int gx_env = getenv("STPDE_CONV_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_GX")) : 0;
+    static const int half_below = getenv("STPDE_CONV_WGRAD_LDS_HALF_BELOW") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_HALF_BELOW")) : 8192;
     if (gx_env > 0)
       gx = gx_env;
-    else if (nblk < 8192)
+    else if (nblk < half_below)
       gx = 128;
     if (gx > nblk) gx = nblk;
     if (KT == 1 && MT == 1)
@@ -700,6 +725,17 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
       STPDE_LAUNCH((k_conv3d_wgrad_lds<1, 2>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
     else
       STPDE_LAUNCH((k_conv3d_wgrad_lds<2, 1>), dim3(gx), dim3(512), 0, (hipStream_t)stream, a);
+    return stpde_check_launch("k_conv3d_wgrad_lds");
+  }
+  // 64 -> 64 channels (third level): 2 x 4 x 16 blocks, one 16-channel output tile per workgroup on blockIdx.y (round 5; two
+  // tiles per workgroup spill: 4 taps x 2 x 4 accumulator tiles + the staging registers)
+  const int nblk16 = d->B * (d->T / 2) * (d->Z / 4) * (d->X / 16);
+  static const int lds64_env = getenv("STPDE_CONV_WGRAD_LDS64") ? atoi(getenv("STPDE_CONV_WGRAD_LDS64")) : 1;
+  if (lds_env && lds64_env && d->ksize == 3 && KT == 4 && MT == 4 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 16 == 0 &&
+      nblk16 >= 256) {
+    int gx = 64;                             // x 4 output tiles: one workgroup (116 KB of LDS) per CU
+    if (gx > nblk16) gx = nblk16;
+    STPDE_LAUNCH((k_conv3d_wgrad_lds<4, 1, 16, 4>), dim3(gx, 4), dim3(512), 0, (hipStream_t)stream, a);
     return stpde_check_launch("k_conv3d_wgrad_lds");
   }
   if (d->ksize == 3 && KT == 1 && MT == 1) {

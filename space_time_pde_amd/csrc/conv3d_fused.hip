@@ -16,6 +16,7 @@
 //                    activation exactly as the forward pass did, stores dz = y * [act > 0] and adds sum(dz), sum(dz * xhat) to the
 //                    BatchNorm-backward sums (the reduction pass of stpde_bn_bwd, and the mask read of its elementwise pass)
 // Per ResBlock3D: forward 5 launches and 11 tensor passes instead of 10 and 18, backward 7 + 4 launches instead of 17 + 4.
+#include <type_traits>
 #include "common.h"
 #include "conv_common.h"
 
@@ -249,6 +250,289 @@ __global__ __launch_bounds__(256) void k_conv_fused(FusedArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 3x3x3 convolutions of the wide levels from LDS halo tiles (round 5).  k_conv_fused above fetches every B fragment of every
+// tap from global memory: a voxel's channels are read 27 times through the 32 KB L1 (TA-bound: 74 TFLOP/s on 16 -> 16 channels,
+// 100 on 32 -> 32).  Here a persistent workgroup of 4 waves owns a block of output voxels at a time (KT = channel tiles of the
+// square convolution: 2 x 4 x 32 voxels for 16 channels, 2 x 2 x 32 for 32, 2 x 2 x 16 for 64); the block's input WITH its
+// one-voxel halo goes to LDS once (zero outside the volume), 16-byte loads software-pipelined through registers so that block
+// n + 1 is in flight during the MFMAs of block n, and all 27 taps read their B fragments from there with one ds_read_b128 per
+// tile and tap at an immediate offset (voxel rows padded by 4 floats: at most 2-way bank conflicts).  A wave owns 4 voxel
+// tiles x ONE output tile (wave = voxel group x output tile); weight fragments come from L1 / L2 as above (27 of them in
+// registers for the whole launch was tried for 16 channels: 108 registers next to the staging registers spill).
+// Same MFMA order per output element as k_conv_fused (tap, k-tile, k-step): results are bit-identical.
+// EPI 1 / 2 (statistics, mask + BatchNorm-backward sums): per block as above, but the per-wave sums stay in fp64 registers
+// across the blocks of the launch and meet in LDS once at the end: one set of atomics per workgroup and launch.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int KT, int EPI>
+__global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
+  constexpr int TT = 2, TZ = KT == 1 ? 4 : 2, TX = KT == 4 ? 16 : 32;
+  constexpr int HZ = TZ + 2, HX = TX + 2, NH = (TT + 2) * HZ * HX, NV = TT * TZ * TX, NXH = TX / 16;
+  constexpr int C = 16 * KT, SV = C + 4, Q = C / 4;
+  static_assert(NV == 64 * (4 / KT), "a block = (4 / KT) voxel groups of 4 tiles");
+  __shared__ __attribute__((aligned(16))) float xs[NH * SV];
+  __shared__ double red[EPI ? 4 * 16 * 2 : 1];
+  const stpde_conv3d_desc& d = a.f.d;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int mt = wv % KT, vg = wv / KT;
+  const int T = d.T, Z = d.Z, X = d.X;
+  const int nbx = X / TX, nbz = Z / TZ, nbt = T / TT;
+  const int nblk = d.B * nbt * nbz * nbx;
+  const int ch = 16 * mt + 4 * g;                        // this lane's 4 output channels
+  // tile t of this wave inside the block, and the LDS address of its lane's centre voxel (tap offsets are immediates)
+  int tt_[4], zz_[4], xo_[4];
+  const float* xc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ti = vg * 4 + t;
+    tt_[t] = ti / (NXH * TZ);
+    zz_[t] = (ti / NXH) % TZ;
+    xo_[t] = 16 * (ti % NXH);
+    xc[t] = xs + ((tt_[t] * HZ + zz_[t]) * HX + xo_[t] + j) * SV + 4 * g;     // tap (-1, -1, -1) of this lane's voxel
+  }
+  const float* wp = a.f.w_pack + (size_t)mt * 256 + lane * 4;
+  f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.f.bias) bv = ld4(a.f.bias + ch);
+  f32x4 mmean, mrstd, mscale, mbeta;
+  if constexpr (EPI == 2) {
+    mmean = ld4(a.f.m_stat + ch);
+    mrstd = ld4(a.f.m_stat + C + ch);
+    mscale = a.f.m_gamma ? mrstd * ld4(a.f.m_gamma + ch) : mrstd;
+    mbeta = a.f.m_beta ? ld4(a.f.m_beta + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // lanes j == 15: this wave's channel sums over its blocks (statistics: fp64; mask sums: fp32 like the atomics they end in)
+  using SumT = typename std::conditional<EPI == 2, float, double>::type;
+  SumT sd1[4] = {0, 0, 0, 0}, sd2[4] = {0, 0, 0, 0};
+
+  // Staging by halo ROWS (fixed t, z: HX voxels x C channels, contiguous in memory): a wave owns RPW rows, a lane the quads
+  // lane + 64 k of a row.  Row validity and the row's base are wave-uniform (scalar), what a lane adds -- its byte offset in
+  // the row, its LDS address, whether its voxel is the row's first / last one (outside the volume on the x faces) -- does
+  // not depend on the block and is computed once.  A request costs ~5 vector instructions (the voxel-indexed version spent
+  // ~60, 64-bit multiplies among them, per 16-byte load: 1000 instructions per block and wave in front of the MFMA loop);
+  // invalid requests go to the buffer descriptor's out-of-range offset and return zeros.
+  constexpr int NR = (TT + 2) * HZ, RPW = NR / 4, RQ = HX * Q, NK = (RQ + 63) / 64;
+  static_assert(NR % 4 == 0, "halo rows: whole rounds of the 4 waves");
+  const auto xr = load_rsrc(a.f.x, (unsigned)((size_t)d.B * T * Z * X * C * 4));
+  int loff[NK];                       // lane's byte offset relative to voxel x0 of the row (negative for the x0 - 1 halo voxel)
+  const float* lds_k[NK];             // where it goes: row wv * RPW of the tile, (+ i rows: immediate)
+  unsigned f_first = 0u, f_last = 0u, f_none = 0u;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int kq = lane + 64 * k, hx = kq / Q, q = kq % Q;
+    loff[k] = (kq - Q) * 16;
+    lds_k[k] = xs + ((wv * RPW) * HX + hx) * SV + 4 * q;
+    f_first |= (hx == 0 ? 1u : 0u) << k;
+    f_last |= (hx == HX - 1 ? 1u : 0u) << k;
+    f_none |= (kq >= RQ ? 1u : 0u) << k;
+  }
+  f32x4 px[RPW][NK];
+  auto fetch = [&](int bi) {
+    int r = bi;
+    const int x0 = (r % nbx) * TX;
+    r /= nbx;
+    const int z0 = (r % nbz) * TZ;
+    r /= nbz;
+    const int t0 = (r % nbt) * TT;
+    const int b = r / nbt;
+    const unsigned bad = f_none | (x0 == 0 ? f_first : 0u) | (x0 + TX == X ? f_last : 0u);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wv * RPW + i;                      // wave-uniform
+      const int t = t0 + row / HZ - 1, z = z0 + row % HZ - 1;
+      const bool rowok = t >= 0 && t < T && z >= 0 && z < Z;
+      const int rbase = ((((b * T + t) * Z + z) * X + x0) * C) * 4;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const bool ok = rowok && !((bad >> k) & 1u);
+        px[i][k] = __builtin_bit_cast(f32x4, buf_ld16(xr, ok ? rbase + loff[k] : (int)0x80000000, 0));
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (!((f_none >> k) & 1u)) st4(const_cast<float*>(lds_k[k]) + i * HX * SV, px[i][k]);
+  };
+  if ((int)blockIdx.x < nblk) fetch(blockIdx.x);
+#pragma unroll 1
+  for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+    __syncthreads();                                     // the readers of the previous block are done
+    stage();
+    __syncthreads();
+    if (bi + (int)gridDim.x < nblk) fetch(bi + gridDim.x);
+    int r = bi;
+    const int x0 = (r % nbx) * TX;
+    r /= nbx;
+    const int z0 = (r % nbz) * TZ;
+    r /= nbz;
+    const int t0 = (r % nbt) * TT;
+    const int b = r / nbt;
+    size_t vo[4];                                        // element offset of this lane's output voxel / channels
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      vo[t] = ((((size_t)b * T + t0 + tt_[t]) * Z + z0 + zz_[t]) * X + x0 + xo_[t] + j) * C + ch;
+    // mask epilogue: the pre-activation values it needs are requested behind the MFMAs (in front of them: 16 more live
+    // registers than the staging registers leave room for)
+    constexpr bool MV_EARLY = false;
+    f32x4 mv[EPI == 2 ? 4 : 1];
+    if constexpr (EPI == 2 && MV_EARLY) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mv[t] = ld4(a.f.m + vo[t]);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // 9 (dt, dz) rows at run time, the NS = 3 dx taps x KT k-tiles of a row unrolled (immediate offsets).  Explicit software
+      // pipeline across the steps AND the rows: the B fragments of step s + 1 and the weight fragment of step s + 2 are
+      // requested in front of the 16 MFMAs of step s (left to the scheduler inside one row, the first steps of every row
+      // waited for their LDS / L2 round trips: 16 -> 16 channels 97 -> ... TFLOP/s)
+      constexpr int NS = 3 * KT;
+      auto ldB = [&](f32x4* B, int roff, int s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) B[t] = ld4(xc[t] + roff + (s / KT) * SV + 16 * (s % KT));
+      };
+      auto roff_of = [&](int row) { return ((row / 3) * HZ + row % 3) * HX * SV; };
+      f32x4 Bc[4], Bn[4], wc, wn, wnn;
+      ldB(Bc, roff_of(0), 0);
+      wc = ld4(wp);
+      wn = ld4(wp + (size_t)1 * (KT * 256));
+#pragma unroll 1
+      for (int row = 0; row < 9; ++row) {
+        const int roff = roff_of(row);
+        const int rown = row < 8 ? row + 1 : 8;        // (the last row requests its own fragments again: branch-free)
+        const int roffn = roff_of(rown);
+        const float* wrow = wp + (size_t)(row * NS) * (KT * 256);
+        const float* wrown = wp + (size_t)(rown * NS) * (KT * 256);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+          if (sI + 1 < NS)
+            ldB(Bn, roff, sI + 1);
+          else
+            ldB(Bn, roffn, 0);
+          if (sI + 2 < NS)
+            wnn = ld4(wrow + (size_t)(sI + 2) * (KT * 256));
+          else
+            wnn = ld4(wrown + (size_t)(sI + 2 - NS) * (KT * 256));
+          __builtin_amdgcn_sched_barrier(0);             // (else the scheduler sinks the requests below the MFMAs to reuse
+#pragma unroll                                           //  the registers of the current fragments: no prefetch at all)
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma4(wc[rr], Bc[t][rr], acc[t]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Bc[t] = Bn[t];
+          wc = wn;
+          wn = wnn;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- epilogue of the block ----------------------------------------------------------------------------
+    if constexpr (EPI == 2 && !MV_EARLY) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mv[t] = ld4(a.f.m + vo[t]);
+    }
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1, sh = s1;
+    if constexpr (EPI == 1) {
+      const f32x4 o0 = acc[0] + bv;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sh[rr] = __shfl(o0[rr], lane & 48, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 o = acc[t] + bv;
+      if constexpr (EPI == 1) {
+        const f32x4 dd = o - sh;
+        s1 += dd;
+        s2 += dd * dd;
+      }
+      if constexpr (EPI == 2) {
+        const f32x4 xm = mv[t] - mmean;
+        const f32x4 h = xm * mscale + mbeta;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (!(h[rr] > 0.f)) o[rr] = 0.f;
+        s1 += o;
+        s2 += o * xm * mrstd;
+      }
+      st4(a.f.y + vo[t], o);
+    }
+    if constexpr (EPI != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        SumT t1 = row_sum16(s1[rr]), t2 = row_sum16(s2[rr]);
+        if constexpr (EPI == 1) {                        // sums around the block's shift -> plain sums, in fp64
+          const double s = sh[rr], n = 64.;
+          t2 = t2 + 2. * s * t1 + n * s * s;
+          t1 = t1 + n * s;
+        }
+        sd1[rr] += t1;
+        sd2[rr] += t2;
+      }
+    }
+  }
+  if constexpr (EPI != 0) {
+    if (j == 15) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        red[(wv * 16 + 4 * g + rr) * 2] = sd1[rr];
+        red[(wv * 16 + 4 * g + rr) * 2 + 1] = sd2[rr];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < KT * 16) {                         // the (4 / KT) waves that share an output tile: waves mt, mt + KT, ...
+      const int m = threadIdx.x >> 4, c = threadIdx.x & 15;
+      double t1 = 0., t2 = 0.;
+      for (int w = m; w < 4; w += KT) {
+        t1 += red[(w * 16 + c) * 2];
+        t2 += red[(w * 16 + c) * 2 + 1];
+      }
+      const int rep = blockIdx.x % STPDE_BN_REP;
+      if (EPI == 1) {
+        atomicAdd(a.f.out_sums + (size_t)(2 * rep) * C + 16 * m + c, t1);
+        atomicAdd(a.f.out_sums + (size_t)(2 * rep + 1) * C + 16 * m + c, t2);
+      } else {
+        atomicAdd(a.f.m_bsum + (size_t)(2 * rep) * C + 16 * m + c, (float)t1);
+        atomicAdd(a.f.m_bsum + (size_t)(2 * rep + 1) * C + 16 * m + c, (float)t2);
+      }
+    }
+  }
+}
+
+// the LDS-tile kernel serves square 16 / 32 / 64-channel 3x3x3 convolutions on volumes made of whole blocks, enough of them
+template <int EPI>
+static bool launch_conv3_lds(const FusedArgs& a, hipStream_t st) {
+  // (the switches are read per call, not once per process: tests/test_gpu_conv_fused.py compares the two kernels in one run)
+  const char* e = getenv("STPDE_CONV3_LDS");
+  const int env = e ? atoi(e) : 1;
+  const stpde_conv3d_desc& d = a.f.d;
+  if (!env || d.ksize != 3 || d.Ci != d.Co || (d.Ci != 16 && d.Ci != 32 && d.Ci != 64)) return false;
+  const int KT = d.Ci / 16;
+  const int TZ = KT == 1 ? 4 : 2, TX = KT == 4 ? 16 : 32;
+  if (d.T % 2 || d.Z % TZ || d.X % TX) return false;
+  const int nblk = d.B * (d.T / 2) * (d.Z / TZ) * (d.X / TX);
+  e = getenv("STPDE_CONV3_LDS_MINBLK");
+  const int minblk = e ? atoi(e) : 1024;
+  if (nblk < minblk) return false;
+  e = getenv("STPDE_CONV3_LDS_GX");
+  const int gx_env = e ? atoi(e) : 0;
+  int gx = gx_env > 0 ? gx_env : 512;                    // two persistent workgroups (64 - 77 KB of LDS) per CU
+  if (gx > nblk) gx = nblk;
+#define STPDE_C3L(K)                                                                  \
+  if (KT == K) {                                                                     \
+    if constexpr (EPI == 0) STPDE_LAUNCH((k_conv3_lds<K, 0>), dim3(gx), dim3(256), 0, st, a); \
+    if constexpr (EPI == 1) STPDE_LAUNCH((k_conv3_lds<K, 1>), dim3(gx), dim3(256), 0, st, a); \
+    if constexpr (EPI == 2) STPDE_LAUNCH((k_conv3_lds<K, 2>), dim3(gx), dim3(256), 0, st, a); \
+  }
+  STPDE_C3L(1) STPDE_C3L(2) STPDE_C3L(4)
+#undef STPDE_C3L
+  return true;
+}
+
 template <bool K3, int DUAL, bool ONLOAD, int EPI>
 static void launch_fused(const FusedArgs& a, int MT, bool big, dim3 grid, hipStream_t st) {
   if (big) {
@@ -319,6 +603,8 @@ extern "C" int stpde_conv3d_fused(const stpde_conv3d_fused_args* f, int* epilogu
     grid = dim3(gx, gy);
   }
   if (d->ksize == 3) {
+    if (stats ? launch_conv3_lds<1>(a, st) : (mask ? launch_conv3_lds<2>(a, st) : launch_conv3_lds<0>(a, st)))
+      return stpde_check_launch("k_conv3_lds");
     if (stats)
       launch_fused<true, 0, false, 1>(a, MT, big, grid, st);
     else if (mask)

@@ -215,3 +215,64 @@ def test_mask_and_batchnorm_backward_sums_epilogue(hiplib, shape, k, c):
     e2 = (tot[1] - (dz * xhat).reshape(-1, c).sum(0)).abs()
     scale = dz.abs().reshape(-1, c).sum(0)
     assert (e1 <= 2e-6 * scale + slack).all() and (e2 <= 1e-5 * scale * (1 + xhat.abs().max()) + slack).all()
+
+
+@pytest.mark.parametrize("c", [16, 32, 64])
+@pytest.mark.parametrize("epi", ["plain", "stats", "mask"])
+def test_conv3_from_lds_halo_tiles_equals_the_per_wave_kernel(hiplib, monkeypatch, c, epi):
+    """k_conv3_lds (csrc/conv3d_fused.hip, round 5): the square 3x3x3 convolutions of the wide levels from LDS halo tiles,
+    on a batch of TWO samples (a block's halo must stop at the sample boundary and at every face of the volume) with more
+    blocks than workgroups (2 x 8 x 32 x 64 voxels = 128 .. 512 blocks on STPDE_CONV3_LDS_GX = 24 persistent workgroups: 5 - 22
+    blocks each through the register-pipelined staging; MINBLK = 1 puts the kernel on this small volume).  Same MFMA order per output element as k_conv_fused: the outputs must be bit-identical;
+    the epilogue sums (fp64 per wave over its blocks, one set of atomics per workgroup) against torch fp64."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(40 + c)
+    shape = (2, 8, 32, 64)
+    x = torch.randn(*shape, c, device=dev) + 0.3
+    w = 0.2 * torch.randn(c, c, 3, 3, 3, device=dev)
+    b = torch.randn(c, device=dev)
+    m = torch.randn(*shape, c, device=dev) + 0.3
+    gam, bet = torch.rand(c, device=dev) + 0.5, 0.3 * torch.randn(c, device=dev)
+    ms = m.double().reshape(-1, c)
+    stat = torch.cat([ms.mean(0), 1 / torch.sqrt(ms.var(0, unbiased=False) + 1e-5)]).float().contiguous()
+    fp = _packs(w, dev)[0]
+    out = {}
+    for lds in ("1", "0"):
+        monkeypatch.setenv("STPDE_CONV3_LDS", lds)
+        monkeypatch.setenv("STPDE_CONV3_LDS_MINBLK", "1")
+        monkeypatch.setenv("STPDE_CONV3_LDS_GX", "24")
+        y = torch.full((*shape, c), float("nan"), device=dev)
+        sums = torch.zeros(R * 2 * c, device=dev, dtype=torch.float64)
+        bsum = torch.zeros(R * 2 * c, device=dev)
+        a = _args(shape, c, c, 3)
+        a.x, a.w_pack, a.y = _lib.ptr(x), _lib.ptr(fp), _lib.ptr(y)
+        if epi != "mask":
+            a.bias = _lib.ptr(b)
+        if epi == "stats":
+            a.out_sums = _lib.ptr(sums)
+        if epi == "mask":
+            a.m, a.m_stat, a.m_gamma, a.m_beta, a.m_bsum = _lib.ptr(m), _lib.ptr(stat), _lib.ptr(gam), _lib.ptr(bet), _lib.ptr(bsum)
+        done = C.c_int(1)
+        with _lib.dispatch_trace() as tr:
+            _lib.check(hiplib.stpde_conv3d_fused(C.byref(a), C.byref(done), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+        assert done.value == 1
+        assert tr.has("k_conv3_lds<%d, %d>" % (c // 16, ("plain", "stats", "mask").index(epi))) == (lds == "1"), "\n".join(tr.kernels)
+        assert tr.has("k_conv_fused<") == (lds == "0"), "\n".join(tr.kernels)
+        out[lds] = (y, sums.clone(), bsum.clone())
+    assert torch.equal(out["1"][0], out["0"][0])
+    conv = _conv64(x, w, None if epi == "mask" else b)
+    if epi == "plain":
+        assert _rel(out["1"][0], conv) < 2e-6
+    if epi == "stats":
+        s1, s2 = _sums(out["1"][1])
+        r = conv.reshape(-1, c)
+        assert _rel(s1, r.sum(0)) < 2e-6 and _rel(s2, (r * r).sum(0)) < 2e-6
+    if epi == "mask":
+        t1, t0 = out["1"][2].view(R, 2, c).sum(0).double(), out["0"][2].view(R, 2, c).sum(0).double()
+        dz = out["1"][0].double().reshape(-1, c)            # (the stored, masked gradient: identical in both kernels)
+        xhat = ((m.double() - stat[:c].double()) * stat[c:].double()).reshape(-1, c)
+        scale = dz.abs().sum(0)
+        assert ((t1[0] - dz.sum(0)).abs() <= 2e-6 * scale + 1e-4).all()
+        assert ((t1[1] - (dz * xhat).sum(0)).abs() <= 1e-5 * scale * (1 + xhat.abs().max()) + 1e-4).all()
+        assert ((t1 - t0).abs() <= 1e-5 * scale * (1 + xhat.abs().max()) + 1e-4).all()

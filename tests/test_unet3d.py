@@ -191,7 +191,7 @@ def test_conv3d_at_bench_volume_vs_torch_fp64(hiplib, ci, co, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ci,co", [(16, 32), (32, 16), (32, 32), (16, 16)])
+@pytest.mark.parametrize("ci,co", [(16, 32), (32, 16), (32, 32), (16, 16), (64, 64)])
 def test_conv3d_wgrad_lds_tiles_two_samples_vs_torch_fp64(hiplib, ci, co):
     """The LDS-tile weight-gradient kernel (csrc/conv3d.hip, k_conv3d_wgrad_lds) on a batch of TWO samples (the halo of a
     block must stop at the sample boundary) and on every channel-tile combination it is compiled for."""
@@ -208,7 +208,9 @@ def test_conv3d_wgrad_lds_tiles_two_samples_vs_torch_fp64(hiplib, ci, co):
         y = unet3d._conv_cl(xd, cd)
         (y * cot.to(dev)).sum().backward()
         torch.cuda.synchronize()
-    assert tr.has("k_conv3d_wgrad_lds<%d, %d>" % (ci // 16, co // 16)), "\n".join(tr.kernels)
+    # (64 channels, round 5: 16-voxel rows, one output tile per workgroup)
+    want = "k_conv3d_wgrad_lds<4, 1, 16, 4>" if ci == 64 else "k_conv3d_wgrad_lds<%d, %d>" % (ci // 16, co // 16)
+    assert tr.has(want), "\n".join(tr.kernels)
     c64 = torch.nn.Conv3d(ci, co, 3, padding=1).double()
     c64.load_state_dict({kk: v.double().cpu() for kk, v in cd.state_dict().items()})
     x64 = x.double().requires_grad_(True)
