@@ -23,6 +23,7 @@
 struct FusedArgs {
   stpde_conv3d_fused_args f;
   int nvox;
+  int phase;       // k_conv3_lds: start delay of the second half of the grid, in units of s_sleep 127 (~8k cycles)
 };
 
 // MC output tiles per pass, VT voxel tiles per wave, K3: 3x3x3 (else 1x1x1)
@@ -305,6 +306,29 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
   // lanes j == 15: this wave's channel sums over its blocks (statistics: fp64; mask sums: fp32 like the atomics they end in)
   using SumT = typename std::conditional<EPI == 2, float, double>::type;
   SumT sd1[4] = {0, 0, 0, 0}, sd2[4] = {0, 0, 0, 0};
+  constexpr int FLUSH = 16;
+  f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1, sh = s1;
+  int nacc = 0;
+  bool have_sh = false;
+  auto flush = [&]() {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      SumT t1 = row_sum16(s1[rr]), t2 = row_sum16(s2[rr]);
+      if constexpr (EPI == 1) {                          // sums around the wave's shift -> plain sums, in fp64
+        const double s = sh[rr], n = 64. * nacc;
+        t2 = t2 + 2. * s * t1 + n * s * s;
+        t1 = t1 + n * s;
+      }
+      sd1[rr] += t1;
+      sd2[rr] += t2;
+    }
+    s1 = s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    nacc = 0;
+  };
+  // output (and mask operand) through buffer descriptors: 32-bit byte offsets per lane
+  const unsigned ybytes = (unsigned)((size_t)d.B * T * Z * X * C * 4);
+  const auto yr = opt_store_rsrc(a.f.y, ybytes);
+  const auto mr = load_rsrc(EPI == 2 ? (const void*)a.f.m : (const void*)a.f.x, ybytes);
 
   // Staging by halo ROWS (fixed t, z: HX voxels x C channels, contiguous in memory): a wave owns RPW rows, a lane the quads
   // lane + 64 k of a row.  Row validity and the row's base are wave-uniform (scalar), what a lane adds -- its byte offset in
@@ -358,6 +382,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
         if (!((f_none >> k) & 1u)) st4(const_cast<float*>(lds_k[k]) + i * HX * SV, px[i][k]);
   };
   if ((int)blockIdx.x < nblk) fetch(blockIdx.x);
+  // Experiment switch (STPDE_CONV3_LDS_PHASE, default 0): the second half of the grid (the second workgroup of every CU)
+  // starts phase x 8k cycles late, so that the staging / epilogue phases of the two workgroups of a CU cannot coincide.
+  // Measured on the configs[3] volume: no difference (32 -> 32 channels 1935 / 1926 / 1948 us for 0 / 2 / 8) -- the two
+  // workgroups do not run in lockstep.
+  if (a.phase > 0 && blockIdx.x >= gridDim.x / 2) {
+    for (int i = 0; i < a.phase; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 #pragma unroll 1
   for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
     __syncthreads();                                     // the readers of the previous block are done
@@ -371,17 +402,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
     r /= nbz;
     const int t0 = (r % nbt) * TT;
     const int b = r / nbt;
-    size_t vo[4];                                        // element offset of this lane's output voxel / channels
+    int vo[4];                                           // byte offset of this lane's output voxel / channels
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      vo[t] = ((((size_t)b * T + t0 + tt_[t]) * Z + z0 + zz_[t]) * X + x0 + xo_[t] + j) * C + ch;
+      vo[t] = (((((b * T + t0 + tt_[t]) * Z + z0 + zz_[t]) * X + x0 + xo_[t] + j) * C) + ch) * 4;
     // mask epilogue: the pre-activation values it needs are requested behind the MFMAs (in front of them: 16 more live
     // registers than the staging registers leave room for)
     constexpr bool MV_EARLY = false;
     f32x4 mv[EPI == 2 ? 4 : 1];
     if constexpr (EPI == 2 && MV_EARLY) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mv[t] = ld4(a.f.m + vo[t]);
+      for (int t = 0; t < 4; ++t) mv[t] = __builtin_bit_cast(f32x4, buf_ld16(mr, vo[t], 0));
     }
     f32x4 acc[4];
 #pragma unroll
@@ -390,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
       // 9 (dt, dz) rows at run time, the NS = 3 dx taps x KT k-tiles of a row unrolled (immediate offsets).  Explicit software
       // pipeline across the steps AND the rows: the B fragments of step s + 1 and the weight fragment of step s + 2 are
       // requested in front of the 16 MFMAs of step s (left to the scheduler inside one row, the first steps of every row
-      // waited for their LDS / L2 round trips: 16 -> 16 channels 97 -> ... TFLOP/s)
+      // waited for their LDS / L2 round trips)
       constexpr int NS = 3 * KT;
       auto ldB = [&](f32x4* B, int roff, int s) {
 #pragma unroll
@@ -432,15 +463,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
       }
     }
     // ---- epilogue of the block ----------------------------------------------------------------------------
+    // (statistics / mask sums: per LANE in fp32 across FLUSH blocks -- 4 * FLUSH terms, around a shift the wave takes from its
+    //  first block -- then the 16-lane row sums and the fp64 arithmetic once per FLUSH blocks, not per block: the epilogue
+    //  runs while the matrix pipe of this wave idles)
     if constexpr (EPI == 2 && !MV_EARLY) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mv[t] = ld4(a.f.m + vo[t]);
+      for (int t = 0; t < 4; ++t) mv[t] = __builtin_bit_cast(f32x4, buf_ld16(mr, vo[t], 0));
     }
-    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1, sh = s1;
     if constexpr (EPI == 1) {
-      const f32x4 o0 = acc[0] + bv;
+      if (!have_sh) {
+        const f32x4 o0 = acc[0] + bv;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) sh[rr] = __shfl(o0[rr], lane & 48, 64);
+        for (int rr = 0; rr < 4; ++rr) sh[rr] = __shfl(o0[rr], lane & 48, 64);
+        have_sh = true;
+      }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -459,21 +495,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
         s1 += o;
         s2 += o * xm * mrstd;
       }
-      st4(a.f.y + vo[t], o);
+      buf_st16(yr, vo[t], 0, o);
     }
     if constexpr (EPI != 0) {
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        SumT t1 = row_sum16(s1[rr]), t2 = row_sum16(s2[rr]);
-        if constexpr (EPI == 1) {                        // sums around the block's shift -> plain sums, in fp64
-          const double s = sh[rr], n = 64.;
-          t2 = t2 + 2. * s * t1 + n * s * s;
-          t1 = t1 + n * s;
-        }
-        sd1[rr] += t1;
-        sd2[rr] += t2;
-      }
+      if (++nacc == FLUSH) flush();
     }
+  }
+  if constexpr (EPI != 0) {
+    if (nacc) flush();
   }
   if constexpr (EPI != 0) {
     if (j == 15) {
@@ -505,15 +534,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
 
 // the LDS-tile kernel serves square 16 / 32 / 64-channel 3x3x3 convolutions on volumes made of whole blocks, enough of them
 template <int EPI>
-static bool launch_conv3_lds(const FusedArgs& a, hipStream_t st) {
+static bool launch_conv3_lds(const FusedArgs& a0, hipStream_t st) {
   // (the switches are read per call, not once per process: tests/test_gpu_conv_fused.py compares the two kernels in one run)
   const char* e = getenv("STPDE_CONV3_LDS");
   const int env = e ? atoi(e) : 1;
-  const stpde_conv3d_desc& d = a.f.d;
+  const stpde_conv3d_desc& d = a0.f.d;
   if (!env || d.ksize != 3 || d.Ci != d.Co || (d.Ci != 16 && d.Ci != 32 && d.Ci != 64)) return false;
   const int KT = d.Ci / 16;
   const int TZ = KT == 1 ? 4 : 2, TX = KT == 4 ? 16 : 32;
   if (d.T % 2 || d.Z % TZ || d.X % TX) return false;
+  if ((size_t)d.B * d.T * d.Z * d.X * d.Ci * 4 >= (1u << 31)) return false;      // 32-bit byte offsets into x / y / m
   const int nblk = d.B * (d.T / 2) * (d.Z / TZ) * (d.X / TX);
   e = getenv("STPDE_CONV3_LDS_MINBLK");
   const int minblk = e ? atoi(e) : 1024;
@@ -522,6 +552,9 @@ static bool launch_conv3_lds(const FusedArgs& a, hipStream_t st) {
   const int gx_env = e ? atoi(e) : 0;
   int gx = gx_env > 0 ? gx_env : 512;                    // two persistent workgroups (64 - 77 KB of LDS) per CU
   if (gx > nblk) gx = nblk;
+  e = getenv("STPDE_CONV3_LDS_PHASE");
+  FusedArgs a = a0;
+  a.phase = e ? atoi(e) : 0;
 #define STPDE_C3L(K)                                                                  \
   if (KT == K) {                                                                     \
     if constexpr (EPI == 0) STPDE_LAUNCH((k_conv3_lds<K, 0>), dim3(gx), dim3(256), 0, st, a); \
