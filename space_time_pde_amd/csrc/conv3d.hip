@@ -253,17 +253,18 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
 // TX (round 5): 16-voxel rows for the 64-channel level (a 32-voxel halo tile of 64 channels would not fit), whose output
 // channels are additionally split over blockIdx.y in groups of COT tiles (COS = all of them): 4 taps x 4 x 4 accumulator
 // tiles would not fit the register file; the workgroups of one block stage the same halo tile (from L2).
-// 16-byte load at a uniform base + a 32-bit byte offset per lane (one address register instead of two; the dispatch keeps the
-// tensors below 4 GiB)
-__device__ __forceinline__ f32x4 ld4_off(const float* base, unsigned byte_off) {
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
+// Address arithmetic (round 5, after an SQ counter pass: 3 scalar + 1.7 vector instructions per MFMA in the 16-channel
+// instantiation, matrix pipe 61 % busy): staging goes by halo ROWS (fixed t, z: contiguous in memory) through buffer loads --
+// row base and validity are wave-uniform, a lane's offset in the row, its LDS address and its swizzle do not depend on the
+// block and are computed once; out-of-volume requests hit the descriptor's range check and return zeros.  The fragment reads
+// of the MFMA loop use per-tap lane addresses computed once per launch + one add per (t, z) row of the block + immediates.
 template <int CIT, int COT, int TX = 32, int COS = COT>
 __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
   constexpr int TT = 2, TZ = 4, HT = TT + 2, HZ = TZ + 2, HX = TX + 2, NXH = TX / 16;
   constexpr int CoF = 16 * COS;                        // channels of a voxel of ybar in memory
   const int coh = COS == COT ? 0 : blockIdx.y * COT;   // first output tile of this workgroup
   constexpr int Ci = 16 * CIT, Co = 16 * COT, NH = HT * HZ * HX, NV = TT * TZ * TX;
+  constexpr bool SWX = CIT % 2 == 0, SWY = COT % 2 == 0;
   __shared__ __attribute__((aligned(16))) float xs[NH * Ci];
   __shared__ __attribute__((aligned(16))) float ys[NV * Co];
   const int lane = threadIdx.x & 63;
@@ -284,14 +285,35 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
   // bias gradient (column sums of ybar) from the staged block: thread -> (channel, every (512 / Co)-th voxel)
   const int bc = threadIdx.x % Co, bv0 = threadIdx.x / Co;
   float bsum = 0.f;
-  // Staging is software-pipelined through registers (round 5): the 16-byte loads of block n + 1 (halo tile + output-gradient
-  // tile: NXI + NYI per thread) are issued right after block n has been written to LDS and are in flight during its
-  // MFMA loop; they used to sit, NXI + NYI dependent round trips long, between two barriers with nothing to cover them but
-  // the other workgroup of the CU.
-  constexpr int NXQ = NH * (Ci / 4), NYQ = NV * (Co / 4);
-  constexpr int NXI = (NXQ + 511) / 512, NYI = NYQ / 512;
-  static_assert(NYQ % 512 == 0, "output-gradient tile: whole rounds of the workgroup");
-  f32x4 px[NXI], py[NYI];
+
+  // ---- staging: 3 halo rows of x and (waves 0 .. TT * TZ - 1) one row of ybar per wave ----------------------------------
+  constexpr int QX = Ci / 4, QY = Co / 4, RPW = HT * HZ / 8, RQX = HX * QX, NKX = (RQX + 63) / 64, RQY = TX * QY,
+                NKY = (RQY + 63) / 64;
+  static_assert(HT * HZ == 8 * RPW && TT * TZ == 8, "24 halo rows / 8 output rows over 8 waves");
+  const size_t nvox = (size_t)a.d.B * T * Z * X;
+  const auto xr = load_rsrc(a.x, (unsigned)(nvox * Ci * 4));
+  const auto yr = load_rsrc(a.ybar, (unsigned)(nvox * CoF * 4));
+  int xoff[NKX], yoff[NKY];
+  float* xl[NKX];
+  float* yl[NKY];
+  unsigned f_first = 0u, f_last = 0u, f_none = 0u, fy_none = 0u;
+#pragma unroll
+  for (int k = 0; k < NKX; ++k) {
+    const int kq = lane + 64 * k, hx = kq / QX, q = kq % QX;
+    xoff[k] = (kq - QX) * 16;                          // relative to voxel x0 of the row (the halo voxel x0 - 1: negative)
+    xl[k] = xs + ((wv * RPW) * HX + hx) * Ci + 4 * (SWX ? (q ^ ((hx & 1) << 2)) : q);      // (HX is even: parity of hv = of hx)
+    f_first |= (hx == 0 ? 1u : 0u) << k;
+    f_last |= (hx == HX - 1 ? 1u : 0u) << k;
+    f_none |= (kq >= RQX ? 1u : 0u) << k;
+  }
+#pragma unroll
+  for (int k = 0; k < NKY; ++k) {
+    const int kq = lane + 64 * k, xx = kq / QY, q = kq % QY;
+    yoff[k] = (xx * CoF + 16 * coh + 4 * q) * 4;
+    yl[k] = ys + (wv * TX + xx) * Co + 4 * (SWY ? (q ^ ((xx & 1) << 2)) : q);
+    fy_none |= (kq >= RQY ? 1u : 0u) << k;
+  }
+  f32x4 px[RPW][NKX], py[NKY];
   auto fetch = [&](int bi) {
     int r = bi;
     const int x0 = (r % nbx) * TX;
@@ -300,41 +322,51 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
     r /= nbz;
     const int t0 = (r % nbt) * TT;
     const int b = r / nbt;
+    const unsigned bad = f_none | (x0 == 0 ? f_first : 0u) | (x0 + TX == X ? f_last : 0u);
 #pragma unroll
-    for (int it = 0; it < NXI; ++it) {
-      const int idx = threadIdx.x + 512 * it;
-      const int q = idx % (Ci / 4), hv = idx / (Ci / 4);
-      const int hx = hv % HX, hz = (hv / HX) % HZ, ht = hv / (HX * HZ);
-      const int t = t0 + ht - 1, z = z0 + hz - 1, x = x0 + hx - 1;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < NXQ && t >= 0 && t < T && z >= 0 && z < Z && x >= 0 && x < X)
-        v = ld4_off(a.x, (unsigned)((((b * T + t) * Z + z) * X + x) * Ci + 4 * q) * 4u);
-      px[it] = v;
-    }
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wv * RPW + i;                    // wave-uniform
+      const int t = t0 + row / HZ - 1, z = z0 + row % HZ - 1;
+      const bool rowok = t >= 0 && t < T && z >= 0 && z < Z;
+      const int rbase = ((((b * T + t) * Z + z) * X + x0) * Ci) * 4;
 #pragma unroll
-    for (int it = 0; it < NYI; ++it) {
-      const int idx = threadIdx.x + 512 * it;
-      const int q = idx % (Co / 4), vv = idx / (Co / 4);
-      const int xx = vv % TX, zz = (vv / TX) % TZ, tt = vv / (TX * TZ);
-      py[it] = ld4_off(a.ybar, (unsigned)((((b * T + t0 + tt) * Z + z0 + zz) * X + x0 + xx) * CoF + 16 * coh + 4 * q) * 4u);
+      for (int k = 0; k < NKX; ++k) {
+        const bool ok = rowok && !((bad >> k) & 1u);
+        px[i][k] = __builtin_bit_cast(f32x4, buf_ld16(xr, ok ? rbase + xoff[k] : (int)0x80000000, 0));
+      }
     }
+    const int ybase = ((((b * T + t0 + wv / TZ) * Z + z0 + wv % TZ) * X + x0) * CoF) * 4;
+#pragma unroll
+    for (int k = 0; k < NKY; ++k)
+      py[k] = __builtin_bit_cast(f32x4, buf_ld16(yr, ((fy_none >> k) & 1u) ? (int)0x80000000 : ybase + yoff[k], 0));
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int it = 0; it < NXI; ++it) {
-      const int idx = threadIdx.x + 512 * it;
-      const int q = idx % (Ci / 4), hv = idx / (Ci / 4);
-      const int qs = CIT % 2 == 0 ? (q ^ ((hv & 1) << 2)) : q;
-      if (idx < NXQ) st4(xs + hv * Ci + 4 * qs, px[it]);
-    }
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
-    for (int it = 0; it < NYI; ++it) {
-      const int idx = threadIdx.x + 512 * it;
-      const int q = idx % (Co / 4), vv = idx / (Co / 4);
-      const int qs = COT % 2 == 0 ? (q ^ ((vv & 1) << 2)) : q;
-      st4(ys + vv * Co + 4 * qs, py[it]);
-    }
+      for (int k = 0; k < NKX; ++k)
+        if (!((f_none >> k) & 1u)) st4(xl[k] + i * HX * Ci, px[i][k]);
+#pragma unroll
+    for (int k = 0; k < NKY; ++k)
+      if (!((fy_none >> k) & 1u)) st4(yl[k], py[k]);
   };
+
+  // ---- fragment addresses: lane part per tap, computed once ---------------------------------------------------------------
+  // x fragment of tap (dt, dz, dx), 16-voxel tile at (tt, zz, xh), k-step sk, input tile ci:
+  //   xs[(((tt + 1 + dt) * HZ + zz + 1 + dz) * HX + 16 xh + 1 + dx + g + 4 sk) * Ci + 16 (ci ^ parity) + j],  parity = (1 + dx + g) & 1
+  const float* ax[4][2];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int tap = tap0 + (ti < ntap_w ? ti : 0);
+    const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    const int par = SWX ? ((1 + dx + g) & 1) : 0;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) ax[ti][p2] = xs + ((dt * HZ + dz) * HX + 1 + dx + g) * Ci + 16 * (p2 ^ par) + j;
+  }
+  const float* ay[2];
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2) ay[p2] = ys + g * Co + 16 * (p2 ^ (SWY ? (g & 1) : 0)) + j;
+
   if ((int)blockIdx.x < nblk) fetch(blockIdx.x);
 #pragma unroll 1
   for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
@@ -343,48 +375,39 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
     __syncthreads();
     if (bi + (int)gridDim.x < nblk) fetch(bi + gridDim.x);
     if (a.dbias) {
-      for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (COT % 2 == 0 ? (bc ^ ((vv & 1) << 4)) : bc)];
+      for (int vv = bv0; vv < NV; vv += 512 / Co) bsum += ys[vv * Co + (SWY ? (bc ^ ((vv & 1) << 4)) : bc)];
     }
 #pragma unroll 1
-    for (int vt = 0; vt < NV / 16; ++vt) {             // 16-voxel tiles along x: (tt, zz, half of the 32-voxel row)
-      const int xh = vt % NXH, zz = (vt / NXH) % TZ, tt = vt / (NXH * TZ);
-      const int vv = (tt * TZ + zz) * TX + 16 * xh + g;           // this lane's voxel of k-step 0 (k-step s: + 4 s)
-      float pa[COT][4];
+    for (int rz = 0; rz < TT * TZ; ++rz) {             // (t, z) rows of the block
+      const int tt = rz / TZ, zz = rz % TZ;
+      const int rowx = ((tt + 1) * HZ + zz + 1) * HX * Ci, rowy = rz * TX * Co;
+      const float* axr[4][2];
 #pragma unroll
-      for (int co = 0; co < COT; ++co)
+      for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-        for (int sk = 0; sk < 4; ++sk)
-          pa[co][sk] = ys[(vv + 4 * sk) * Co + 16 * (COT % 2 == 0 ? (co ^ (vv & 1)) : co) + j];
+        for (int p2 = 0; p2 < (CIT > 1 ? 2 : 1); ++p2) axr[ti][p2] = ax[ti][p2] + rowx;
+      const float* ayr[2];
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        if (ti < ntap_w) {                             // wave-uniform
-          const int tap = tap0 + ti;
-          const int dt = tap / 9 - 1, dz = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-          const int hv = ((tt + 1 + dt) * HZ + (zz + 1 + dz)) * HX + 16 * xh + 1 + dx + g;
-          if constexpr (CIT <= 2) {
-            float qb[CIT][4];
+      for (int p2 = 0; p2 < (COT > 1 ? 2 : 1); ++p2) ayr[p2] = ay[p2] + rowy;
 #pragma unroll
-            for (int ci = 0; ci < CIT; ++ci)
+      for (int xh = 0; xh < NXH; ++xh) {
+        float pa[COT][4];
 #pragma unroll
-              for (int sk = 0; sk < 4; ++sk)
-                qb[ci][sk] = xs[(hv + 4 * sk) * Ci + 16 * (CIT % 2 == 0 ? (ci ^ (hv & 1)) : ci) + j];
+        for (int co = 0; co < COT; ++co)
 #pragma unroll
-            for (int sk = 0; sk < 4; ++sk)
+          for (int sk = 0; sk < 4; ++sk) pa[co][sk] = ayr[co & 1][(16 * xh + 4 * sk) * Co + 16 * (co & ~1)];
 #pragma unroll
-              for (int co = 0; co < COT; ++co)
-#pragma unroll
-                for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = mfma4(pa[co][sk], qb[ci][sk], acc[ti][co][ci]);
-          } else {                                     // many input tiles: fragments k-step by k-step (register budget)
+        for (int ti = 0; ti < 4; ++ti) {
+          if (ti < ntap_w) {                           // wave-uniform
 #pragma unroll
             for (int sk = 0; sk < 4; ++sk) {
               float qb[CIT];
 #pragma unroll
-              for (int ci = 0; ci < CIT; ++ci) qb[ci] = xs[(hv + 4 * sk) * Ci + 16 * (ci ^ (hv & 1)) + j];
+              for (int ci = 0; ci < CIT; ++ci) qb[ci] = axr[ti][ci & 1][(16 * xh + 4 * sk) * Ci + 16 * (ci & ~1)];
 #pragma unroll
               for (int co = 0; co < COT; ++co)
 #pragma unroll
                 for (int ci = 0; ci < CIT; ++ci) acc[ti][co][ci] = mfma4(pa[co][sk], qb[ci], acc[ti][co][ci]);
-              __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
@@ -702,7 +725,9 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
   // full-resolution levels (16 / 32 channels, volume made of whole 2 x 4 x 32 blocks, enough of them): the LDS-tile kernel
   static const int lds_env = getenv("STPDE_CONV_WGRAD_LDS") ? atoi(getenv("STPDE_CONV_WGRAD_LDS")) : 1;
   const int nblk = d->B * (d->T / 2) * (d->Z / 4) * (d->X / 32);
-  if (lds_env && d->ksize == 3 && KT <= 2 && MT <= 2 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 32 == 0 && nblk >= 256) {
+  // (the LDS kernels address x / ybar with 32-bit byte offsets)
+  const bool off32 = (size_t)a.nvox * (d->Ci > d->Co ? d->Ci : d->Co) * 4 < (1u << 31);
+  if (lds_env && off32 && d->ksize == 3 && KT <= 2 && MT <= 2 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 32 == 0 && nblk >= 256) {
     const int wide = (KT == 2 || MT == 2);
     int gx = wide ? 256 : 512;               // persistent workgroups: one (137 KB of LDS) or two (68 KB) per CU
     // Volumes below ~2 M voxels: the training step runs this kernel on a side stream next to the input-gradient chain
@@ -731,7 +756,7 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
   // tiles per workgroup spill: 4 taps x 2 x 4 accumulator tiles + the staging registers)
   const int nblk16 = d->B * (d->T / 2) * (d->Z / 4) * (d->X / 16);
   static const int lds64_env = getenv("STPDE_CONV_WGRAD_LDS64") ? atoi(getenv("STPDE_CONV_WGRAD_LDS64")) : 1;
-  if (lds_env && lds64_env && d->ksize == 3 && KT == 4 && MT == 4 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 16 == 0 &&
+  if (lds_env && lds64_env && off32 && d->ksize == 3 && KT == 4 && MT == 4 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 16 == 0 &&
       nblk16 >= 256) {
     int gx = 64;                             // x 4 output tiles: one workgroup (116 KB of LDS) per CU
     if (gx > nblk16) gx = nblk16;
