@@ -21,6 +21,10 @@ cp $G/prof_r5/pmc_traffic_c4_bf16.json $P/pmc_traffic_c4_bf16.json
 # SQ counters of the bf16 mode (tools/micro/pmc_bf16.sh)
 : > $P/r5_bf16_pmc_sq_counters.txt
 for f in $G/prof_bf16_r5/*.txt; do cat $f >> $P/r5_bf16_pmc_sq_counters.txt; done
+# SQ counters of the U-Net convolution kernels on the configs[3] volume (tools/r5_o.sh)
+: > $P/r5_unet_pmc_sq_counters.txt
+for c in GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM; do [ -s $G/pmc_unet/$c.txt ] && cat $G/pmc_unet/$c.txt >> $P/r5_unet_pmc_sq_counters.txt; done
+[ -s $G/pmc_unet/trace.txt ] && cp $G/pmc_unet/trace.txt $P/r5_unet_pmc_kernel_trace.txt
 python - <<PY
 import json
 rows = {}

@@ -19,6 +19,8 @@ python tools/bench_next_rows.py > $O/r5_next_rows.json 2> /dev/null
 python tools/unet_profile.py 64 256 256 > $O/r5_unet_profile_c4.txt 2> /dev/null
 python tools/unet_profile.py 32 128 128 > $O/r5_unet_profile_c2.txt 2> /dev/null
 FUSED_LIST=1 bash tools/r5_unet_trace.sh > $O/r5_unet_trace.log 2>&1
+bash tools/r5_o.sh > $O/r5_unet_pmc.log 2>&1
+cd $R
 for f in r5_bench r5_bench_c5 r5_bench_leakyrelu r5_bench_fp32x3 r5_bench_bf16_mode_c2grid r5_bench_config4_bf16 r5_proxy_524288 r5_proxy_262144 r5_proxy_131072 r5_bench_2rank_gloo; do python - <<PY
 import json
 try:
