@@ -161,14 +161,40 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
 // packs (lig_jet.ImNetPlan.pack_bf16: fp32 blocks (2q, mt) and (2q + 1, mt) lane by lane; [2][KT/2][MT][64] = hi, lo).  The
 // skip GEMM with the raw input stays on the exact fp32 MFMA (63 per tile), as in the wide bf16 layers.  The packed stores
 // round the derivative streams for the BACKWARD pass only: the chain itself runs on the unrounded accumulators.
-template <int S1, int S2, int ACT>
-__global__ __launch_bounds__(256, 2) void k_tail_fwd_bf(TailArgs a) {
+// LDSW (round 5): one wave per row tile with two waves per SIMD is a chain of ~15 exposed L2 round trips per tile -- the
+// skip-weight / tangent-constant fragments of the seven epilogues and the bf16 weight fragments are loaded right where they
+// are used (a tile took 64k cycles per wave for ~20k cycles of issued work; 3.9 TB/s of HBM traffic).  All of these operands
+// are the same for every row tile: 84 KB.  The LDSW kernel is persistent (one workgroup of 8 waves per CU, every wave walks
+// over row tiles), copies them into LDS once and reads them from there (~100 cycles instead of an L2 round trip).
+template <int S1, int S2, int ACT, bool LDSW>
+__global__ __launch_bounds__(LDSW ? 512 : 256, LDSW ? 1 : 2) void k_tail_fwd_bf(TailArgs a) {
   constexpr int S = 1 + S1 + S2;
   constexpr int KT3 = 8, MT3 = 4, MT4 = 2;
+  // LDS image of the tile-independent operands (floats): Ws[3], tanc[3] (XT or 3 x MT_l x 256 each), then the bf16 packs
+  constexpr int NWS = XT * (MT3 + MT4 + 1) * 256, NTC = 3 * (MT3 + MT4 + 1) * 256;
+  constexpr int NW3 = 2 * (KT3 / 2) * MT3 * 64 * 4, NW4 = 2 * (MT3 / 2) * MT4 * 64 * 4, NW5 = 2 * 64 * 4;     // in floats (16 B per lane)
+  __shared__ __attribute__((aligned(16))) float sm[LDSW ? NWS + NTC + NW3 + NW4 + NW5 : 4];
+  constexpr int OWS[3] = {0, XT * MT3 * 256, XT * (MT3 + MT4) * 256};
+  constexpr int OTC[3] = {NWS, NWS + 3 * MT3 * 256, NWS + 3 * (MT3 + MT4) * 256};
+  constexpr int OW3 = NWS + NTC, OW4 = OW3 + NW3, OW5 = OW4 + NW4;
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= a.ntiles) return;
-  const int lo = lane * 4;
+  if constexpr (LDSW) {
+    auto copy = [&](int off, const void* src, int nfloat) {
+      for (int i = threadIdx.x * 4; i < nfloat; i += 512 * 4) st4(sm + off + i, ld4(reinterpret_cast<const float*>(src) + i));
+    };
+    const int mts[3] = {MT3, MT4, 1};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      copy(OWS[l], a.Ws[l], XT * mts[l] * 256);
+      copy(OTC[l], a.tanc[l], 3 * mts[l] * 256);
+    }
+    copy(OW3, a.Wh16[0], NW3);
+    copy(OW4, a.Wh16[1], NW4);
+    copy(OW5, a.Wh16[2], NW5);
+    __syncthreads();
+  }
+  // one row tile (lo = lane * 4, handed in: the persistent loop launders it per iteration, see below)
+  auto run_tile = [&](const int tile, const int lo) {
   float cq[6];
   load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
   f32x4 xb[XT];
@@ -179,12 +205,13 @@ __global__ __launch_bounds__(256, 2) void k_tail_fwd_bf(TailArgs a) {
   auto finish = [&](int l, int MT, int mt, f32x4* acc, bool pk) {
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
-      const f32x4 w = ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
+      const f32x4 w = LDSW ? ld4(sm + OWS[l] + (xt * MT + mt) * 256 + lo) : ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
 #pragma unroll
       for (int r = 0; r < x_live(xt); ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) acc[1 + d] += ld4(a.tanc[l] + ((size_t)d * MT + mt) * 256 + lo);
+    for (int d = 0; d < 3; ++d)
+      acc[1 + d] += LDSW ? ld4(sm + OTC[l] + (d * MT + mt) * 256 + lo) : ld4(a.tanc[l] + ((size_t)d * MT + mt) * 256 + lo);
     if (!pk) {
 #pragma unroll
       for (int st = 0; st < S; ++st) st4(a.out[l] + (((size_t)tile * S + st) * MT + mt) * 256 + lo, acc[st]);
@@ -222,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_fwd_bf(TailArgs a) {
 #pragma unroll
     for (int st = 0; st < S; ++st) acc3[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const bf16x8* W3 = reinterpret_cast<const bf16x8*>(a.Wh16[0]) + lane;      // [2][KT3 / 2][MT3][64]
+    const bf16x8* W3 = (LDSW ? reinterpret_cast<const bf16x8*>(sm + OW3) : reinterpret_cast<const bf16x8*>(a.Wh16[0])) + lane;      // [2][KT3 / 2][MT3][64]
     f32x4 raw[2][S];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void k_tail_fwd_bf(TailArgs a) {
 #pragma unroll
     for (int st = 0; st < S; ++st) acc4[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const bf16x8* W4 = reinterpret_cast<const bf16x8*>(a.Wh16[1]) + lane;      // [2][MT3 / 2][MT4][64]
+    const bf16x8* W4 = (LDSW ? reinterpret_cast<const bf16x8*>(sm + OW4) : reinterpret_cast<const bf16x8*>(a.Wh16[1])) + lane;      // [2][MT3 / 2][MT4][64]
 #pragma unroll
     for (int q = 0; q < MT3 / 2; ++q) {
       bf16x8 B8[S][2];
@@ -291,12 +318,26 @@ __global__ __launch_bounds__(256, 2) void k_tail_fwd_bf(TailArgs a) {
   {
     bf16x8 B8[S][2];
     pair_b(acc4[0], acc4[1], B8);
-    const bf16x8 w8[2] = {reinterpret_cast<const bf16x8*>(a.Wh16[2])[lane],         // [2][1][1][64]
-                          reinterpret_cast<const bf16x8*>(a.Wh16[2])[64 + lane]};
+    const bf16x8* W5 = LDSW ? reinterpret_cast<const bf16x8*>(sm + OW5) : reinterpret_cast<const bf16x8*>(a.Wh16[2]);
+    const bf16x8 w8[2] = {W5[lane], W5[64 + lane]};                                 // [2][1][1][64]
 #pragma unroll
     for (int st = 0; st < S; ++st) acc5[st] = mma3(w8, B8[st], acc5[st]);
   }
   finish(2, 1, 0, acc5, false);
+  };  // run_tile
+  if constexpr (!LDSW) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile < a.ntiles) run_tile(tile, lane * 4);
+  } else {
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + (threadIdx.x >> 6); tile < a.ntiles; tile += gridDim.x * 8) {
+      // an opaque zero per iteration: without it every tile-independent address of the body (dozens of 64-bit pointers)
+      // is hoisted out of the loop and the body spills ~1 KB
+      int zero;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+      run_tile(tile, lane * 4 + zero);
+    }
+  }
 }
 
 template <int S1, int S2, int ACT>
@@ -305,7 +346,16 @@ static int launch_tail_nft(const TailArgs& a, int nft, hipStream_t stream) {
   if (a.packed || a.Wh16[0]) {
     if constexpr (S1 == 3) {       // bf16 mode: the training stream sets, reference width, every layer buffer packed
       if (nft == 2 && a.packed == 3 && a.Wh16[0] && a.Wh16[1] && a.Wh16[2]) {
-        STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT>), grid, dim3(256), 0, stream, a);
+        // persistent, tile-independent operands in LDS (STPDE_TAIL_FWD_LDS=0: one wave per tile, operands from L2)
+        static const int ldsw = getenv("STPDE_TAIL_FWD_LDS") ? atoi(getenv("STPDE_TAIL_FWD_LDS")) : 1;
+        if (ldsw && a.cfg.S1 == 3) {
+          static const int gx_env = getenv("STPDE_TAIL_FWD_LDS_GX") ? atoi(getenv("STPDE_TAIL_FWD_LDS_GX")) : 0;
+          int gx = gx_env > 0 ? gx_env : 256;
+          if (gx > (a.ntiles + 7) / 8) gx = (a.ntiles + 7) / 8;
+          STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT, true>), dim3(gx), dim3(512), 0, stream, a);
+        } else {
+          STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT, false>), grid, dim3(256), 0, stream, a);
+        }
         return stpde_check_launch("k_tail_fwd_bf");
       }
     }
