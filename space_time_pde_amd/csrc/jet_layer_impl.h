@@ -623,6 +623,12 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
     if (a.Wp16 && a.nsplit == 1 && dspec_env && a.pk == 3 && a.MT == 32 && a.KT == 16 && a.Tan0 && a.Z0)
       return launch_fc1_dgrad_spec<S1, S2, ACT>(a, stream);
   }
+  // ... and the forward of the second hidden layer (round 5): k_fc2_fwd_bf; STPDE_FC2_FWD_SPEC=0 keeps the cooperative kernel
+  if constexpr (PRO == PRO_ACT && EPI == EPI_FWD && NW == 4 && MCg == 2 && S1 == 3 && S2 <= 1) {
+    static const int f2_env = getenv("STPDE_FC2_FWD_SPEC") ? atoi(getenv("STPDE_FC2_FWD_SPEC")) : 1;
+    if (a.Wp16 && a.nsplit == 1 && f2_env && a.pk == 3 && a.KT == 16 && a.MT == 8 && !a.H16)
+      return launch_fc2_fwd_bf<S1, S2, ACT>(a, stream);
+  }
   if (EPI == EPI_FWD && a.H16) {
     stpde_set_error("jet_layer_fwd: act16 is written by the wave-specialised bf16 forward of the first hidden layer only "
                     "(S1 = 3, S2 <= 2, 16 output tiles, 16 / 32 input tiles, STPDE_BF_SPEC != 0)");

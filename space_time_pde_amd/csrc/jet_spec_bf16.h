@@ -575,3 +575,151 @@ static int launch_fc1_fwd_spec(const LayerArgs& a, hipStream_t stream) {
     STPDE_LAUNCH((k_fc1_fwd_spec<S1, S2, ACT, 2>), dim3(grid), dim3(512), 0, stream, a);
   return stpde_check_launch("k_fc1_fwd_spec");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 mode, SECOND hidden layer forward (reference width: KT = 16 input tiles, MT = 8 output tiles, packed stash in and out;
+// round 5).  In k_layer_coop<..., BF> a row tile is 6k cycles of issued work per wave inside 41k cycles of wave life: phase
+// stamps (tools/micro/ablate_layer.py run2 bf16) show the two 8-k-tile groups at 6-7k cycles each for 640 cycles of MFMAs
+// -- stash loads, activation jets, ring stores and a barrier in series per group -- and the timing ablations put a third of the
+// launch on the loads and a quarter on the stores: the kernel streams 41 GB at 3.5 TB/s, not because it computes.
+// Here ONE persistent workgroup of 8 waves per CU:
+//   * the packed stash tile of a row tile (48 KB, contiguous in HBM) lands in LDS by global_load_lds, 6 x 1 KiB pieces per
+//     wave, requested when the buffer's previous tile has been consumed -- a tile time ahead of its use (double buffer): no
+//     registers, no wait at a use;
+//   * wave w activates input tiles 2w, 2w + 1 (one activation-jet evaluation per element and workgroup) into a 40 KB bf16 block
+//     image, barrier, then owns OUTPUT tile w: 8 k-tile pairs x S bf16 MFMAs with its 8 weight fragments, skip-weight and
+//     tangent-constant fragments resident in registers for the whole launch (no weight traffic in the loop);
+//   * combined-stream weights and the raw-input tile of a row tile arrive the same way, together with its pieces.
+// Two barriers per row tile; the only vector-memory wait is one counted s_waitcnt per tile for requests made a whole tile
+// earlier (the tile's stores leave a tile late, behind that wait).  Operand rounding, accumulation order over the k-tile pairs and epilogue are those of
+// k_layer_coop<..., BF = true, PK = 2, PKM = 3>: bit-identical output.
+// ------------------------------------------------------------------------------------------------------------
+template <int S1, int S2, int ACT>
+__global__ __launch_bounds__(512, 1) void k_fc2_fwd_bf(LayerArgs a) {
+  constexpr int S = 1 + S1 + S2, KT = 16, MT = 8, KP = KT / 2;
+  constexpr int TILE_IN = KT * (1024 + (S - 1) * 512);                     // bytes of a packed stash tile (49152 at S = 5)
+  constexpr int NQ = TILE_IN / 1024 / 8;                                   // 1 KiB pieces per wave and row tile
+  static_assert(TILE_IN % 8192 == 0, "whole pieces per wave");
+  __shared__ __attribute__((aligned(16))) float raw[2][TILE_IN / 4];       // the tile as it lies in HBM
+  __shared__ __attribute__((aligned(16))) float act[KT][S][128];           // activated blocks: [kt][stream][lane][4 bf16]
+  __shared__ __attribute__((aligned(16))) float xs[3][XT][256];            // raw-input tiles (skip GEMM of the epilogue)
+  __shared__ float cqs[3][16];                                             // combined-stream weights of the two points of a tile
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lo = lane * 4;
+  const int ntl = ((int)blockIdx.x < a.ntiles) ? (a.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (ntl == 0) return;
+  // launch-resident operands of output tile w
+  bf16x8 wk[KP];
+#pragma unroll
+  for (int q = 0; q < KP; ++q) wk[q] = reinterpret_cast<const bf16x8*>(a.Wp16)[((size_t)q * MT + w) * 64 + lane];
+  f32x4 wsk[XT], tck[3];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) wsk[xt] = ld4(a.Wsp + ((size_t)xt * MT + w) * 256 + lo);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) tck[d] = S1 == 3 ? ld4(a.tanc + ((size_t)d * MT + w) * 256 + lo) : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](int tile, int buf) {
+    const char* src = reinterpret_cast<const char*>(a.Bin) + (size_t)tile * TILE_IN + lane * 16;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int c = __builtin_amdgcn_readfirstlane(w + 8 * q);
+      STPDE_GLDS16(src + (size_t)c * 1024, reinterpret_cast<char*>(&raw[buf][0]) + c * 1024);
+    }
+  };
+  // requests of one row tile, all by LDS-DMA: its stash pieces (every wave), its raw-input tile (waves 0-2, one KiB each), its
+  // 16 combined-stream weights (wave 3, lanes 0-15, 4 bytes each).  The loop has NO ordinary global load, so the compiler
+  // places no vector-memory wait of its own; the raw-input / weight slots rotate through three buffers (a slot is rewritten
+  // two tiles after its last reader, with two barriers in between).
+  auto request = [&](int tile, int buf, int b3) {
+    stage(tile, buf);
+    if (w < XT) STPDE_GLDS16(a.X + ((size_t)tile * XT + w) * 256 + lo, &xs[b3][w][0]);
+    if (S2 == 1 && w == 3 && lane < 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.cw + (size_t)tile * 16 + lane),
+                                       (__attribute__((address_space(3))) void*)(&cqs[b3][0]), 4, 0, 0);
+  };
+  request(blockIdx.x, 0, 0);
+  if (ntl > 1) request(blockIdx.x + gridDim.x, 1, 1);
+  f32x4 hold[S];                                                           // output blocks of the previous tile, stored a tile late
+  int b3 = 0;                                                              // i % 3
+#pragma unroll 1
+  for (int i = 0; i < ntl; ++i) {
+    const int tile = blockIdx.x + i * gridDim.x, buf = i & 1;
+    // The ONE vector-memory wait of the tile.  Vector-memory loads return in order, so "at most NREQ outstanding" (NREQ = this
+    // wave's requests per tile) means: everything older than the requests of tile i + 1 -- i.e. the requests of tile i -- has
+    // arrived.  The previous tile's stores are issued BEHIND this point (from `hold`), so nothing younger than a tile time
+    // is ever waited for; stores still in flight can only make the count larger.
+    if (i + 1 < ntl) {
+      if (w < XT || (S2 == 1 && w == 3))
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ + 1) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SPEC_BARRIER();                                                        // all requests of tile i landed; act free
+    if (i > 0) {
+#pragma unroll
+      for (int st = 0; st < S; ++st) st_blk(a.Out, 1, tile - gridDim.x, S, MT, st, w, lane, hold[st]);
+    }
+    float cq[6];
+    if (S2 == 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cq[k] = cqs[b3][8 * ((lane & 15) >> 3) + k];
+    }
+    // ---- activation jets of input tiles 2w, 2w + 1
+    const char* rb = reinterpret_cast<const char*>(&raw[buf][0]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int kt = 2 * w + e;
+      f32x4 rv[S], B[S];
+      rv[0] = *reinterpret_cast<const f32x4*>(rb + kt * 1024 + lane * 16);
+#pragma unroll
+      for (int st = 1; st < S; ++st)
+        rv[st] = bf4_to_f32(*reinterpret_cast<const bf16x4*>(rb + KT * 1024 + ((st - 1) * KT + kt) * 512 + lane * 8));
+      act_jet_fwd<S1, S2, ACT>(a.cfg, rv, B, cq);
+#pragma unroll
+      for (int st = 0; st < S; ++st) *reinterpret_cast<bf16x4*>(&act[kt][st][lane * 2]) = to_bf4(B[st]);
+    }
+    SPEC_BARRIER();                                                        // block image complete; raw[buf] consumed
+    // ---- tile i + 2 into the stash buffer this tile has consumed
+    if (i + 2 < ntl) request(tile + 2 * gridDim.x, buf, b3 == 0 ? 2 : b3 - 1);
+    // ---- output tile w
+    f32x4 acc[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) acc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        const bf16x8 B8 = cat8(*reinterpret_cast<const bf16x4*>(&act[2 * q][st][lane * 2]),
+                               *reinterpret_cast<const bf16x4*>(&act[2 * q + 1][st][lane * 2]));
+        acc[st] = mfma_bf(wk[q], B8, acc[st]);
+      }
+    }
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+      const f32x4 xv = ld4(&xs[b3][xt][lo]);
+#pragma unroll
+      for (int r = 0; r < x_live(xt); ++r) acc[0] = mfma4(wsk[xt][r], xv[r], acc[0]);
+    }
+    if (S1 == 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[1 + d] += tck[d];
+    }
+#pragma unroll
+    for (int st = 0; st < S; ++st) hold[st] = acc[st];
+    b3 = b3 == 2 ? 0 : b3 + 1;
+  }
+#pragma unroll
+  for (int st = 0; st < S; ++st) st_blk(a.Out, 1, blockIdx.x + (ntl - 1) * gridDim.x, S, MT, st, w, lane, hold[st]);
+}
+
+template <int S1, int S2, int ACT>
+static int launch_fc2_fwd_bf(const LayerArgs& a, hipStream_t stream) {
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = ncu < a.ntiles ? ncu : a.ntiles;
+  STPDE_LAUNCH((k_fc2_fwd_bf<S1, S2, ACT>), dim3(grid), dim3(512), 0, stream, a);
+  return stpde_check_launch("k_fc2_fwd_bf");
+}

@@ -88,6 +88,24 @@ def test_round4_bf16_kernels_equal_the_ones_they_replaced(hiplib, tmp_path, comb
             assert err < 2e-5, (tag, k, err)
 
 
+def test_fc2_forward_on_lds_dma_equals_the_cooperative_kernel(hiplib, tmp_path):
+    """Round 5: k_fc2_fwd_bf (csrc/jet_spec_bf16.h -- persistent, stash tiles by LDS-DMA, launch-resident weights) against
+    k_layer_coop<..., BF> (STPDE_FC2_FWD_SPEC=0) on the combined-stream set it is compiled for: same operand rounding, same
+    accumulation order over the k-tile pairs, same epilogue -- loss and d latent must be bit-identical (6000 points x 8
+    corners = 3000 row tiles on 256 persistent workgroups: 11-12 tiles each through the double buffer)."""
+    base = _run(tmp_path, "fc2spec", True)
+    other = _run(tmp_path, "fc2coop", True, STPDE_FC2_FWD_SPEC="0")
+    kb, ko = str(base["kernels"]), str(other["kernels"])
+    assert "k_fc2_fwd_bf" in kb and "k_fc2_fwd_bf" not in ko, kb
+    # the forward pass and the deterministic d latent: bit for bit; the weight gradients behind atomics: to summation rounding
+    assert np.array_equal(base["loss"], other["loss"]) and np.array_equal(base["dlat"], other["dlat"])
+    for k in base.files:
+        if k in ("kernels", "loss", "dlat"):
+            continue
+        a, b = base[k].astype(np.float64), other[k].astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-30), k
+
+
 def test_fused_fc1_backward_equals_the_two_kernel_path(hiplib, monkeypatch):
     """Round 5: k_fc1_bwd_fused (csrc/jet_fc1_bwd.hip -- input gradient + weight gradient of the first hidden layer in one
     kernel, one activation-jet evaluation per z0 element) against the two kernels it replaces (STPDE_FC1_FUSED=0:

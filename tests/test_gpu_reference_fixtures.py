@@ -124,8 +124,10 @@ def _assert_mode_kernels(tr, prec):
 def _assert_bf16_kernels(tr, cfg, dump):
     # first hidden layer forward: the wave-specialised persistent kernel (csrc/jet_spec_bf16.h)
     assert tr.has("k_fc1_fwd_spec", cfg), dump
-    for pro, epi in ((1, 0), (0, 1)):
-        assert tr.has("k_layer_coop", "true", cfg, "PRO = %d" % pro, "EPI = %d" % epi), dump
+    # second hidden layer: forward on the persistent LDS-DMA kernel (round 5; STPDE_FC2_FWD_SPEC=0: the cooperative kernel),
+    # input gradient on the cooperative kernel
+    assert tr.has("k_fc2_fwd_bf", cfg) or tr.has("k_layer_coop", "true", cfg, "PRO = 1", "EPI = 0"), dump
+    assert tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 1"), dump
     if tr.has("k_fc1_bwd_fused"):
         # round 5 (default): input gradient + weight gradient of the first hidden layer in ONE kernel (csrc/jet_fc1_bwd.hip);
         # neither of the two kernels it replaces is launched

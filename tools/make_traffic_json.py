@@ -26,6 +26,8 @@ def bench_name(sym):
         return "layer1_fwd"
     if sym.startswith("k_fc1_bwd_fused<"):
         return "layer1_bwd"
+    if sym.startswith("k_fc2_fwd_bf<"):
+        return "layer2_fwd"
     if re.match(r"k_\w+<0,\d,", sym):      # value-only / value-tile kernels of bench.py's inference side figure, not the training step
         return None
     m = re.match(r"k_layer_coop<(\d+),(\d+),(\d+),(\d+),(\d+),(-?\d+),(\d+)(?:,(\w+))?(?:,[\w,]+)?>", sym)
