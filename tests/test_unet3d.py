@@ -278,7 +278,12 @@ def test_resample_at_bench_volume(hiplib):
         xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
         y = unet3d._pool_cl(xa, factors)
         yr = F.max_pool3d(xb.permute(0, 4, 1, 2, 3), factors).permute(0, 2, 3, 4, 1).contiguous()
-        assert torch.equal(y, yr)
+        if not torch.equal(y, yr):          # say WHICH side is off (host reference) and whether the input survived
+            ref = F.max_pool3d(x.cpu().permute(0, 4, 1, 2, 3), factors).permute(0, 2, 3, 4, 1).contiguous()
+            bad_y, bad_r = (y.detach().cpu() != ref), (yr.detach().cpu() != ref)
+            raise AssertionError("pool %s: hip kernel wrong in %d elements (first %s), torch in %d, inputs intact: %s / %s" % (
+                factors, int(bad_y.sum()), bad_y.nonzero()[:3].tolist(), int(bad_r.sum()),
+                torch.equal(xa.detach(), x), torch.equal(xb.detach(), x)))
         cot = torch.randn(y.shape, generator=g).to(dev)
         (y * cot).sum().backward()
         (yr * cot).sum().backward()
