@@ -395,7 +395,7 @@ def main(argv=None):
     # per-kernel HIP-event timings: a SECOND pass outside the timed region (the event pairs around ~70 launches per
     # step would otherwise sit inside it)
     lig_jet.profile = {}
-    nprof = 2
+    nprof = 4          # (2 until round 5: one slow launch in one of two steps moved the dominant kernel's average by 9 %)
     unet.register_forward_pre_hook(lambda m, i: pending.append(torch.cuda.Event(enable_timing=True)) or pending[-1].record())
     unet.register_forward_hook(_post)
     for _ in range(nprof):
@@ -486,7 +486,7 @@ def main(argv=None):
         prof["unet_fwd"] = uev[-nprof:]
         for name, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            kern[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
+            kern[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), min_ms=min(ms), max_ms=max(ms))
         dom = max(kern, key=lambda k: kern[k]["total_ms"])
         # A kernel may take several launches per step (launch chunks; with the U-Net backward overlapped, a separate last
         # chunk of lig_jet.tail_chunk points): achieved = its algorithmic FLOPs per STEP / its time per step, which is also
@@ -517,7 +517,8 @@ def main(argv=None):
                         note="achieved = SURVEY 8(d) algorithmic FLOPs (value + 3 first + 2 second-order streams) / "
                              "launch time; executed_* = the MFMA work actually issued (combined second-order stream)",
                         executed_tflops=round(exe, 2), executed_frac=round(exe / PEAK_F32_TFLOPS, 4),
-                        flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3), launches_per_step=lps,
+                        flop_per_launch=flop_launch, avg_launch_ms=round(kern[dom]["avg_ms"], 3),
+                        launch_ms_min_max=[round(kern[dom]["min_ms"], 3), round(kern[dom]["max_ms"], 3)], launches_per_step=lps,
                         step_algorithmic_tflops=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world, 2),
                         step_frac_per_gpu=round(step_flop_pt * args.points / (dt / args.steps) / 1e12 / world
                                                 / PEAK_F32_TFLOPS, 4),
