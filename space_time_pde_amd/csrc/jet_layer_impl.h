@@ -32,6 +32,9 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #ifndef STPDE_FWD2_OCC3
 #define STPDE_FWD2_OCC3 1    // fp32 forward of the 2-output-tiles-per-wave shapes (second hidden layer), S <= 5: 168-register budget
 #endif
+#ifndef STPDE_FWD2_OCC_N
+#define STPDE_FWD2_OCC_N 3    // (4: 128 registers -- see profiles/r5_ablate_first_barrier.txt)
+#endif
 #ifndef STPDE_EARLY_L0
 #define STPDE_EARLY_L0 1
 #endif
@@ -40,6 +43,13 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #endif
 #ifndef STPDE_EPI_PF_BF
 #define STPDE_EPI_PF_BF 1
+#endif
+#ifndef STPDE_EPI_PF_DEPTH
+#define STPDE_EPI_PF_DEPTH 1     // output tiles whose stashed pre-activation blocks are in flight ahead of the adjoint being computed
+                                 // (2: +-0, 3 / 4: fc2 dgrad +7 % -- the epilogue is not waiting for these loads; same file)
+#endif
+#ifndef STPDE_SKIP_FIRST_BAR
+#define STPDE_SKIP_FIRST_BAR 1   // no "ring free" barrier in front of a workgroup's FIRST pass (nobody has read the ring yet)
 #endif
 #if STPDE_STAMP
 #define STPDE_STAMP_B0 8192
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 // faster.  The split of the activations is done once per workgroup in the produce stage, that of the weights on the host.
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW, bool BF = false, int PK = 1, bool WRING = false,
           int SPL = 1, int PKM = 0>
-__global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EPI == EPI_FWD && MCg == 2 && NW == 4 && !WRING && S1 + S2 <= 4 && STPDE_FWD2_OCC3) ? 3 : 2) void k_layer_coop(LayerArgs a) {
+__global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EPI == EPI_FWD && MCg == 2 && NW == 4 && !WRING && S1 + S2 <= 4 && STPDE_FWD2_OCC3) ? STPDE_FWD2_OCC_N : 2) void k_layer_coop(LayerArgs a) {
   constexpr int S = 1 + S1 + S2, GK = NW * PK;
   static_assert(!WRING || (!BF && GK == 4), "the weight ring is written for 4 k-tiles per group, fp32");
   static_assert(SPL == 1 || (BF && SPL == 3), "operand splitting is a bf16-pipe mode");
@@ -403,6 +413,7 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
   };
 
   const int ngroups = KT / GK;
+  bool first_pass = true;
   for (int mt0 = (pass0 * NW + wv) * MCg; mt0 < MT; mt0 += pstep * NW * MCg) {
     f32x4 acc[MCg][S];
 #pragma unroll
@@ -424,7 +435,12 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
 #pragma unroll
         for (int mi = 0; mi < MCg; ++mi) wr[q][mi] = ld4(wp + ((size_t)q * MT + mi) * 256);
     }
-    __syncthreads();              // ring free (previous pass fully consumed)
+    // ring free (previous pass fully consumed).  Not in front of the FIRST pass (round 5): __syncthreads() carries a
+    // vmcnt(0), so the barrier made the first group's operand loads wait for the round trip of the loads above (raw input,
+    // combination weights, weight ring, z0 blocks) instead of travelling with them.  Measured (profiles/r5_ablate_first_barrier.txt,
+    // 2^18 points): exact-fp32 fc1 forward 22.19 -> 22.01 ms, every other kernel of the template within +-0.3 %.
+    if (!STPDE_SKIP_FIRST_BAR || !first_pass) __syncthreads();
+    first_pass = false;
     STAMP(1);
     produce_group(0, 0);
     STAMP(2);
@@ -579,19 +595,21 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
     constexpr bool EPF = EPI == EPI_ADJ && (!BF || (SPL == 1 && STPDE_EPI_PF_BF)) && MCg > 1 && STPDE_EPI_PF;
     if constexpr (EPF) {
       constexpr int PMD = (PKM & 4) ? 1 : 0;
-      f32x4 prc[S], prn[S];
+      // PFD tiles ahead (STPDE_EPI_PF_DEPTH, clamped to what the pass has; 1 = round 4's one-ahead order)
+      constexpr int PFD = STPDE_EPI_PF_DEPTH < 1 ? 1 : (STPDE_EPI_PF_DEPTH > MCg ? MCg : STPDE_EPI_PF_DEPTH);
+      f32x4 pr[MCg][S];
 #pragma unroll
-      for (int st = 0; st < S; ++st) prc[st] = ld_blk(a.Pre, PMD, tile, S, MT, st, mt0, lane);
+      for (int mi = 0; mi < PFD; ++mi)
+#pragma unroll
+        for (int st = 0; st < S; ++st) pr[mi][st] = ld_blk(a.Pre, PMD, tile, S, MT, st, mt0 + mi, lane);
 #pragma unroll
       for (int mi = 0; mi < MCg; ++mi) {
-        if (mi + 1 < MCg) {
+        if (mi + PFD < MCg) {
 #pragma unroll
-          for (int st = 0; st < S; ++st) prn[st] = ld_blk(a.Pre, PMD, tile, S, MT, st, mt0 + mi + 1, lane);
+          for (int st = 0; st < S; ++st) pr[mi + PFD][st] = ld_blk(a.Pre, PMD, tile, S, MT, st, mt0 + mi + PFD, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, nullptr, prc);
-#pragma unroll
-        for (int st = 0; st < S; ++st) prc[st] = prn[st];
+        layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, nullptr, pr[mi]);
       }
     } else {
 #pragma unroll

@@ -162,7 +162,7 @@ def stamp_spec(tag="stamp"):
                 print("  %-28s %9.1f" % (nm, v[ok].mean()))
 
 
-def run(bf16=False):
+def run(bf16=False, tags=None):
     import torch
     from space_time_pde_amd import _lib
     from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
@@ -181,8 +181,8 @@ def run(bf16=False):
     pv = plan.pack_view
     p16 = plan.pack_bf16(packs, 1) if bf16 else {}
     res = {}
-    for n in VARIANTS:
-        so = os.path.join(OUT, "libabl_%d.so" % n)
+    for n in (tags or VARIANTS):                  # tags: private builds of build_flags (plain timings of fc1 fwd / dgrad)
+        so = os.path.join(OUT, "libabl_%s.so" % n)
         if not os.path.exists(so):
             continue
         L = C.CDLL(so)
@@ -214,9 +214,9 @@ def run(bf16=False):
             res[(n, name)] = e0.elapsed_time(e1) / 3
     names = {0: "baseline", 1: "no activation jet in produce", 2: "no barrier in main loop", 3: "weights L1-resident",
              4: "no epilogue", 5: "no produce stage in loop"}
-    for n in VARIANTS:
+    for n in (tags or VARIANTS):
         if (n, "fwd") in res:
-            print("%-32s fwd %7.3f ms   dgrad %7.3f ms" % (names[n], res[(n, "fwd")], res[(n, "dgrad")]))
+            print("fc1 %-28s fwd %7.3f ms   dgrad %7.3f ms" % (names.get(n, n), res[(n, "fwd")], res[(n, "dgrad")]))
 
 
 def run2(stamp_too=True, tags=None, bf16=False):
@@ -333,5 +333,7 @@ if __name__ == "__main__":
         build_stamp(extra=["-DSTPDE_STAMP=0"] + sys.argv[3:], tag=sys.argv[2])
     elif sys.argv[1] == "stamp":
         stamp(bf16="bf16" in sys.argv[2:])
+    elif sys.argv[1] == "run1":                   # run1 TAG ... [bf16]: the first hidden layer on private builds
+        run(bf16="bf16" in sys.argv[2:], tags=[t for t in sys.argv[2:] if t != "bf16"])
     else:
         run(bf16="bf16" in sys.argv[2:])
