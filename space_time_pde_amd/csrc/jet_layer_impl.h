@@ -19,7 +19,8 @@ enum { PRO_NONE = 0, PRO_ACT = 1, PRO_L0 = 2 };
 enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 // Timing-only ablations of the cooperative kernel (tools/micro/ablate_layer.py builds a private library with
 // -DSTPDE_ABLATE=n; results are WRONG by construction): 1 = no activation jet in the produce stage, 2 = no barrier in the
-// main loop, 3 = weight fragments always from k-tile 0 (L1-resident), 4 = no epilogue, 5 = no produce stage in the loop.
+// main loop, 3 = weight fragments always from k-tile 0 (L1-resident), 4 = no epilogue, 5 = no produce stage in the loop,
+// 6 = (three-term split mode) one of the six partial products only.
 #ifndef STPDE_ABLATE
 #define STPDE_ABLATE 0
 #endif
@@ -47,6 +48,13 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
 #ifndef STPDE_EPI_PF_DEPTH
 #define STPDE_EPI_PF_DEPTH 1     // output tiles whose stashed pre-activation blocks are in flight ahead of the adjoint being computed
                                  // (2: +-0, 3 / 4: fc2 dgrad +7 % -- the epilogue is not waiting for these loads; same file)
+#endif
+#ifndef STPDE_EPI_OPF
+#define STPDE_EPI_OPF 3          // cooperative kernel, tile-independent-of-the-rows operands of the epilogues requested ahead: bit 0 = first
+                                 // hidden layer's input gradient (z0 blocks where they are not fetched at the start of the pass,
+                                 // layer-0 tangent constants), bit 1 = forward (skip weights / tangent constants one output tile ahead),
+                                 // bit 2 = also in the three-term split mode (measured slower there: profiles/r5_ablate_fc1_fp32x3.txt).
+                                 // Stream sets with S <= 5 only: at S = 8 the extra fragments spill (12 -> 68 B in the fc2 forward)
 #endif
 #ifndef STPDE_SKIP_FIRST_BAR
 #define STPDE_SKIP_FIRST_BAR 1   // no "ring free" barrier in front of a workgroup's FIRST pass (nobody has read the ring yet)
@@ -114,7 +122,8 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
 template <int S1, int S2, int EPI, int ACT, int PKM = 0>
 __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int mt, int MT, int lane, f32x4* accm,
                                                const f32x4 (*xbv)[XT], const float* cq, float& pacc,
-                                               const f32x4* z0pre = nullptr, const f32x4* prepf = nullptr) {
+                                               const f32x4* z0pre = nullptr, const f32x4* prepf = nullptr,
+                                               const f32x4* wspf = nullptr, const f32x4* tcpf = nullptr) {
   constexpr int S = 1 + S1 + S2;
   constexpr bool VT = S1 == 0 && S2 > 0;     // value-tile mode: every stream is the value stream of its own row tile
   const int lo = lane * 4;
@@ -123,7 +132,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
     if (EPI == EPI_FWD) {
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) {
-        f32x4 w = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
+        f32x4 w = wspf ? wspf[xt] : ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
 #pragma unroll
         for (int sv = 0; sv < (VT ? S : 1); ++sv)
 #pragma unroll
@@ -131,7 +140,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
       }
       if (S1 == 3) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) acc[mi][1 + d] += ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
+        for (int d = 0; d < 3; ++d) acc[mi][1 + d] += tcpf ? tcpf[d] : ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
       }
 #pragma unroll
       for (int st = 0; st < S; ++st) st_blk(a.Out, (PKM & 2) ? 1 : 0, tile, S, MT, st, mt, lane, acc[mi][st]);
@@ -145,7 +154,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         pre[0] = z0pre ? *z0pre : ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
         if (S1 == 3) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) pre[1 + d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
+          for (int d = 0; d < 3; ++d) pre[1 + d] = tcpf ? tcpf[d] : ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
 #pragma unroll
           for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -490,12 +499,12 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
           for (int mi = 0; mi < MCg; ++mi)
 #pragma unroll
             for (int t = 0; t < SPL; ++t)
-              w8[mi][t] = wp16[(((size_t)t * (KT / 2) + kp) * MT + mi) * 64];
+              w8[mi][t] = wp16[(((size_t)t * (KT / 2) + (STPDE_ABLATE == 3 ? q : kp)) * MT + mi) * 64];
           if constexpr (SPL == 3) {
             // six partial products, smallest first: (weight term, activation term)
             constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
+            for (int c = 0; c < (STPDE_ABLATE == 6 ? 1 : 6); ++c)
 #pragma unroll
               for (int mi = 0; mi < MCg; ++mi)
 #pragma unroll
@@ -610,6 +619,67 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
         }
         __builtin_amdgcn_sched_barrier(0);
         layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, nullptr, pr[mi]);
+      }
+    } else if constexpr (EPI == EPI_ADJ_L0 && S1 == 3 && S <= 5 && (STPDE_EPI_OPF & 1) && (SPL == 1 || (STPDE_EPI_OPF & 4))) {
+      // first hidden layer's input gradient (round 5): the layer-0 tangent constants (and, where they are not requested at
+      // the start of the pass, the z0 blocks) of the output tiles are requested ahead of the adjoint that needs them -- they
+      // were loaded tile by tile right in front of their use, one exposed L2 (+ HBM) round trip per output tile.  SPL == 1:
+      // all tiles of the pass in one batch; three-term split mode (behind bit 2 of the switch): one tile ahead, pinned.
+      if constexpr (SPL == 1) {
+        f32x4 z0l[MCg], tcl[MCg][3];
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi) {
+          z0l[mi] = Z0P ? z0p[Z0P ? mi : 0] : ld4(a.Z0 + ((size_t)tile * MT + mt0 + mi) * 256 + lo);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) tcl[mi][d] = ld4(a.tanc0 + ((size_t)d * MT + mt0 + mi) * 256 + lo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi)
+          layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, &z0l[mi], nullptr, nullptr,
+                                                  tcl[mi]);
+      } else {
+        f32x4 zc, zn, tcc[3], tcn2[3];
+        auto fetch = [&](int mt, f32x4& z, f32x4* t) {
+          z = ld4(a.Z0 + ((size_t)tile * MT + mt) * 256 + lo);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) t[d] = ld4(a.tanc0 + ((size_t)d * MT + mt) * 256 + lo);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(mt0, zc, tcc);
+#pragma unroll
+        for (int mi = 0; mi < MCg; ++mi) {
+          if (mi + 1 < MCg) fetch(mt0 + mi + 1, zn, tcn2);
+          __builtin_amdgcn_sched_barrier(0);
+          layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, &zc, nullptr, nullptr, tcc);
+          __builtin_amdgcn_sched_barrier(0);
+          zc = zn;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) tcc[d] = tcn2[d];
+        }
+      }
+    } else if constexpr (EPI == EPI_FWD && S1 == 3 && !VT && S <= 5 && (STPDE_EPI_OPF & 2) && (SPL == 1 || (STPDE_EPI_OPF & 4))) {
+      // forward: skip weights and tangent constants of output tile mi + 1 requested before the epilogue of tile mi (one
+      // exposed L2 round trip per output tile otherwise)
+      f32x4 wsc[XT], tcc[3], wsn[XT], tcn2[3];
+      auto fetch = [&](int mt, f32x4* w, f32x4* t) {
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) w[xt] = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) t[d] = ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
+      };
+      if (SPL != 1) __builtin_amdgcn_sched_barrier(0);
+      fetch(mt0, wsc, tcc);
+#pragma unroll
+      for (int mi = 0; mi < MCg; ++mi) {
+        if (mi + 1 < MCg) fetch(mt0 + mi + 1, wsn, tcn2);
+        __builtin_amdgcn_sched_barrier(0);
+        layer_epilogue<S1, S2, EPI, ACT, PKM>(a, tile, mt0 + mi, MT, lane, acc[mi], xb, cq, pacc, nullptr, nullptr, wsc, tcc);
+        if (SPL != 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) wsc[xt] = wsn[xt];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) tcc[d] = tcn2[d];
       }
     } else {
 #pragma unroll

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "space_time_pde_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "micro", "_abl")
-VARIANTS = [0, 1, 2, 3, 4, 5]
+VARIANTS = [0, 1, 2, 3, 4, 5, 6]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 
@@ -49,7 +49,7 @@ def build_stamp(extra=(), tag="stamp"):
     print("stamp build rc", r.returncode, r.stdout.decode()[-300:] if r.returncode else "")
 
 
-def stamp(bf16=False):
+def stamp(bf16=False, x3=False):
     """Phase timeline of k_layer_coop (first hidden layer, forward and dgrad): mean cycles between the s_memtime stamps of
     256 mid-launch workgroups (all waves)."""
     import numpy as np
@@ -69,12 +69,12 @@ def stamp(bf16=False):
     abar0 = torch.empty(nt * 4 * plan.layers[0]["MT"] * 256, device=dev)
     tan0 = torch.empty(nt * plan.layers[0]["MT"] * 48, device=dev)
     pv = plan.pack_view
-    p16 = plan.pack_bf16(packs, 1) if bf16 else {}
+    p16 = plan.pack_bf16(packs, 3 if x3 else 1) if (bf16 or x3) else {}
     L = C.CDLL(os.path.join(OUT, "libabl_stamp.so"))
     L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
     L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 13
     d = _lib.LayerDesc()
-    d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, int(bf16)
+    d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, (3 if x3 else int(bf16))
     st = _lib.stream_ptr()
     p = _lib.ptr
 
@@ -97,7 +97,7 @@ def stamp(bf16=False):
         assert L.stpde_stamp_read(host) == 0
         a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, 16).astype(np.int64)
         print("== %s (%s): mean cycles per phase over the waves that recorded it; 100 MHz s_memtime ticks x 24 = shader cycles at 2.4 GHz"
-              % (name, "bf16" if bf16 else "fp32"))
+              % (name, "fp32x3" if x3 else "bf16" if bf16 else "fp32"))
         idx = [0, 1, 2, 3] + list(range(4, 12)) + [12, 13]
         prev = 0
         for k, i in enumerate(idx[1:]):
@@ -162,7 +162,7 @@ def stamp_spec(tag="stamp"):
                 print("  %-28s %9.1f" % (nm, v[ok].mean()))
 
 
-def run(bf16=False, tags=None):
+def run(bf16=False, tags=None, x3=False):
     import torch
     from space_time_pde_amd import _lib
     from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
@@ -179,7 +179,7 @@ def run(bf16=False, tags=None):
     abar0 = torch.empty(nt * 4 * plan.layers[0]["MT"] * 256, device=dev)
     tan0 = torch.empty(nt * plan.layers[0]["MT"] * 48, device=dev)
     pv = plan.pack_view
-    p16 = plan.pack_bf16(packs, 1) if bf16 else {}
+    p16 = plan.pack_bf16(packs, 3 if x3 else 1) if (bf16 or x3) else {}
     res = {}
     for n in (tags or VARIANTS):                  # tags: private builds of build_flags (plain timings of fc1 fwd / dgrad)
         so = os.path.join(OUT, "libabl_%s.so" % n)
@@ -189,7 +189,7 @@ def run(bf16=False, tags=None):
         L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
         L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 13
         d = _lib.LayerDesc()
-        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, int(bf16)
+        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 1, cfg, (3 if x3 else int(bf16))
         st = _lib.stream_ptr()
         p = _lib.ptr
 
@@ -332,8 +332,8 @@ if __name__ == "__main__":
     elif sys.argv[1] == "build_flags":            # build_flags TAG -DFOO=1 ...  (a plain private build, no stamps)
         build_stamp(extra=["-DSTPDE_STAMP=0"] + sys.argv[3:], tag=sys.argv[2])
     elif sys.argv[1] == "stamp":
-        stamp(bf16="bf16" in sys.argv[2:])
+        stamp(bf16="bf16" in sys.argv[2:], x3="x3" in sys.argv[2:])
     elif sys.argv[1] == "run1":                   # run1 TAG ... [bf16]: the first hidden layer on private builds
-        run(bf16="bf16" in sys.argv[2:], tags=[t for t in sys.argv[2:] if t != "bf16"])
+        run(bf16="bf16" in sys.argv[2:], tags=[t for t in sys.argv[2:] if t not in ("bf16", "x3")], x3="x3" in sys.argv[2:])
     else:
-        run(bf16="bf16" in sys.argv[2:])
+        run(bf16="bf16" in sys.argv[2:], x3="x3" in sys.argv[2:])
