@@ -61,6 +61,9 @@ struct WgradArgs {
 #ifndef STPDE_X3_XFOLD
 #define STPDE_X3_XFOLD 1     // fp32x3: raw-input k-tiles folded into the hidden-group launch of the split kernel (round 5)
 #endif
+#ifndef STPDE_WG_RPIPE
+#define STPDE_WG_RPIPE 1     // exact-fp32 cooperative kernel: ring blocks read ONE BLOCK AHEAD of their MFMAs (round 5)
+#endif
 #ifndef STPDE_X3_EARLYP
 #define STPDE_X3_EARLYP 0
 #endif
@@ -603,6 +606,33 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       }
     } else if constexpr (BF && SPL == 1 && !HASX && STPDE_ABLATE_W == 0) {
       ring_mma(buf);
+    } else if constexpr (!BF && !HASX && STPDE_WG_RPIPE) {
+      // Exact fp32, hidden k-groups (round 5).  The loop below reads the S ring blocks of a k-slot and issues its MCW * 4 * S
+      // MFMAs stream-innermost, and the compiler emitted `2 x ds_read_b128 ; s_waitcnt lgkmcnt(1) ; 4 MFMAs ; s_waitcnt
+      // lgkmcnt(0) ; ...` -- 19 waits to zero per iteration, each with at most one 32-cycle MFMA in flight to cover an LDS round
+      // trip (tools/micro/isa_waits.py; both waves of a SIMD are in this phase at the same time).  Here the block of
+      // (k-slot, stream) n + 1 is requested before the MCW * 4 MFMAs of block n (256 cycles of matrix work per block), the
+      // order of ring reads and MFMAs pinned; everything else may move across the pins.  (The sums of a dW element are
+      // accumulated stream by stream instead of k-step by k-step: same terms, another fp32 rounding order.)
+      constexpr int PIN = 0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x200;      // VALU, SALU, VMEM and DS writes may cross; MFMA / DS reads not
+      f32x4 Hc = get(&hl[buf][ks * KC][0][0]);
+#pragma unroll
+      for (int ki = 0; ki < KC; ++ki) {
+        const int q = ks * KC + ki;
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+          f32x4 Hn = Hc;
+          if (st + 1 < S) Hn = get(&hl[buf][q][st + 1][0]);
+          else if (ki + 1 < KC) Hn = get(&hl[buf][q + 1][0][0]);
+          __builtin_amdgcn_sched_barrier(PIN);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mi = 0; mi < MCW; ++mi) acc[mi][ki] = mfma4(pa[st][mi][r], Hc[r], acc[mi][ki]);
+          __builtin_amdgcn_sched_barrier(PIN);
+          Hc = Hn;
+        }
+      }
     } else {
 #pragma unroll
     for (int ki = 0; ki < KC; ++ki) {

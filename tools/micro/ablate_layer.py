@@ -219,7 +219,7 @@ def run(bf16=False, tags=None, x3=False):
             print("fc1 %-28s fwd %7.3f ms   dgrad %7.3f ms" % (names.get(n, n), res[(n, "fwd")], res[(n, "dgrad")]))
 
 
-def run2(stamp_too=True, tags=None, bf16=False):
+def run2(stamp_too=True, tags=None, bf16=False, x3=False):
     """The SECOND hidden layer (fc2: 256 -> 128 features, exact fp32): ablation timings of its forward and input-gradient
     kernels, then the phase stamps of both (round 5: where do the 30 % idle matrix-pipe cycles of these two kernels go?)."""
     import numpy as np
@@ -240,13 +240,13 @@ def run2(stamp_too=True, tags=None, bf16=False):
     abar2 = torch.randn(nt * S * lay["MT"] * 256, device=dev)
     pv = plan.pack_view
     p = _lib.ptr
-    p16 = plan.pack_bf16(packs, 1) if bf16 else {}       # (unpacked layer buffers: the timeline, not the bytes, is the point)
+    p16 = plan.pack_bf16(packs, 3 if x3 else 1) if (bf16 or x3) else {}       # (unpacked layer buffers: the timeline, not the bytes, is the point)
 
     def calls(L):
         L.stpde_jet_layer_fwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 12
         L.stpde_jet_layer_bwd.argtypes = [C.POINTER(_lib.LayerDesc)] + [C.c_void_p] * 13
         d = _lib.LayerDesc()
-        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 0, cfg, int(bf16)
+        d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg, d.mfma_bf16 = nt, lay["KT"], lay["MT"], 0, cfg, (3 if x3 else int(bf16))
         st = _lib.stream_ptr()
         work = pre1.clone()
 
@@ -328,7 +328,7 @@ if __name__ == "__main__":
     elif sys.argv[1] == "stamp_spec":
         stamp_spec(sys.argv[2] if len(sys.argv) > 2 else "stamp")
     elif sys.argv[1] == "run2":
-        run2(tags=[t for t in sys.argv[2:] if t != "bf16"] or None, bf16="bf16" in sys.argv[2:])
+        run2(tags=[t for t in sys.argv[2:] if t not in ("bf16", "x3")] or None, bf16="bf16" in sys.argv[2:], x3="x3" in sys.argv[2:])
     elif sys.argv[1] == "build_flags":            # build_flags TAG -DFOO=1 ...  (a plain private build, no stamps)
         build_stamp(extra=["-DSTPDE_STAMP=0"] + sys.argv[3:], tag=sys.argv[2])
     elif sys.argv[1] == "stamp":

@@ -34,7 +34,20 @@ def build():
         print("variant", n, "rc", p.returncode, out.decode()[-300:] if p.returncode else "")
 
 
-def run():
+def build_flags(tag, extra):
+    """private build libablw_<tag>.so with extra compiler flags (A/B of a compile-time switch)"""
+    os.makedirs(OUT, exist_ok=True)
+    stub = os.path.join(OUT, "stubw.cpp")
+    open(stub, "w").write('#include <hip/hip_runtime.h>\nstruct WgradArgs;\n' + "".join(
+        "int stpde_wgrad_launch_%s(const WgradArgs&, int, hipStream_t) { return 2; }\n" % k
+        for k in ("0_0", "3_0", "3_2", "3_4", "3_6")))
+    srcs = [os.path.join(CSRC, f) for f in ("jet_wgrad.hip", "jet_wgrad_s31.hip", "api.cpp")]
+    r = subprocess.run(["hipcc"] + FLAGS + list(extra) + ["-shared", "-o", os.path.join(OUT, "libablw_%s.so" % tag)] + srcs + [stub],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    print("build", tag, "rc", r.returncode, r.stdout.decode()[-400:] if r.returncode else "")
+
+
+def run(tags=None):
     import torch
     from space_time_pde_amd import _lib
     from space_time_pde_amd.lig_jet import ImNetPlan, make_cfg
@@ -56,9 +69,9 @@ def run():
     names = {0: "baseline", 1: "one partial product instead of six", 2: "abar transposed / split for the first tile only",
              3: "no produce stage in the loop", 4: "consumer operands not read from LDS", 5: "no barrier in the loop"}
     for mode, tag in ((3, "fp32x3"), (1, "bf16"), (0, "fp32")):
-        for n in VARIANTS:
-            so = os.path.join(OUT, "libablw_%d.so" % n)
-            if not os.path.exists(so) or (mode != 3 and n not in (0, 2, 3, 5)):
+        for n in (tags or VARIANTS):
+            so = os.path.join(OUT, "libablw_%s.so" % n)
+            if not os.path.exists(so) or (not tags and mode != 3 and n not in (0, 2, 3, 5)):
                 continue
             L = C.CDLL(so)
             L.stpde_jet_wgrad.argtypes = [C.POINTER(_lib.LayerDesc), C.c_int] + [C.c_void_p] * 7
@@ -78,8 +91,13 @@ def run():
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            print("%-7s %-50s %7.3f ms" % (tag, names[n], e0.elapsed_time(e1) / 3))
+            print("%-7s %-50s %7.3f ms" % (tag, names.get(n, n), e0.elapsed_time(e1) / 3))
 
 
 if __name__ == "__main__":
-    (build if sys.argv[1:] == ["build"] else run)()
+    if sys.argv[1:] == ["build"]:
+        build()
+    elif sys.argv[1] == "build_flags":            # build_flags TAG -DFOO=1 ...
+        build_flags(sys.argv[2], sys.argv[3:])
+    else:
+        run(tags=sys.argv[2:] or None)            # run [TAG ...]
