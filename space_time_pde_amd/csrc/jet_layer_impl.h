@@ -54,7 +54,18 @@ enum { EPI_FWD = 0, EPI_ADJ = 1, EPI_ADJ_L0 = 2 };
                                  // hidden layer's input gradient (z0 blocks where they are not fetched at the start of the pass,
                                  // layer-0 tangent constants), bit 1 = forward (skip weights / tangent constants one output tile ahead),
                                  // bit 2 = also in the three-term split mode (measured slower there: profiles/r5_ablate_fc1_fp32x3.txt).
+                                 // (value-tile mode of the lattice inference: not offered -- its kernels run at 3-4 waves per SIMD and the
+                                 // extra fragments would cost one of them.)
                                  // Stream sets with S <= 5 only: at S = 8 the extra fragments spill (12 -> 68 B in the fc2 forward)
+#endif
+#ifndef STPDE_X3_STREAM_OUTER
+#define STPDE_X3_STREAM_OUTER 1  // three-term split mode: one stream's B fragments live at a time in the MFMA loop (see there)
+#endif
+#ifndef STPDE_X3_EARLY
+#define STPDE_X3_EARLY 0         // three-term split mode, input-gradient kernels: stash loads of the next group issued before the MFMAs
+#endif
+#ifndef STPDE_X3_Z0P
+#define STPDE_X3_Z0P 0           // three-term split mode, first hidden layer's input gradient: z0 blocks requested at the start of the pass
 #endif
 #ifndef STPDE_SKIP_FIRST_BAR
 #define STPDE_SKIP_FIRST_BAR 1   // no "ring free" barrier in front of a workgroup's FIRST pass (nobody has read the ring yet)
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
 #pragma unroll
       for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
     // first hidden layer's input gradient: the z0 blocks its epilogue takes the adjoint against, fetched now
-    constexpr bool Z0P = EPI == EPI_ADJ_L0 && SPL == 1;      // (not in the three-term split mode: register pressure)
+    constexpr bool Z0P = EPI == EPI_ADJ_L0 && (SPL == 1 || STPDE_X3_Z0P);      // (three-term split mode: behind a switch)
     f32x4 z0p[Z0P ? MCg : 1];
     if constexpr (Z0P) {
 #pragma unroll
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
       const int gnext = gi + 1 < ngroups ? gi + 1 : gi;
       // B blocks are plain loads from the stash: issue them now (not in the three-term split mode: the registers the
       // early blocks occupy cost that mode more than the hidden latency gives, fp32x3 dgrad 64.5 -> 71.3 ms)
-      constexpr bool EARLY = PRO == PRO_NONE && SPL == 1;
+      constexpr bool EARLY = PRO == PRO_NONE && (SPL == 1 || STPDE_X3_EARLY);
       constexpr bool EARLY0 = PRO == PRO_L0 && !VT && STPDE_EARLY_L0;   // layer 0 on the fly: its weight / tangent fragments
       f32x4 rawn[EARLY ? PK : 1][S];
       if constexpr (EARLY) {
@@ -483,7 +494,47 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
           }
         }
       }
-      if constexpr (BF) {
+      if constexpr (BF && SPL == 3 && STPDE_X3_STREAM_OUTER) {
+        // Three-term split mode, stream-outer (round 5, last session).  The loop below holds the B fragments of ALL S streams
+        // (S x 3 terms x 4 registers = 60) next to the 48 weight-fragment registers and the 80 accumulators: 256 registers
+        // and 76-108 B of scratch inside the loop.  Here one stream's three terms are live at a time (the next stream's
+        // requested before the 6 x MCg MFMAs of the current one, order pinned); every accumulator still receives its six
+        // partial products smallest first, k-pair by k-pair: bit-identical sums.
+        const bf16x8* wp16 = reinterpret_cast<const bf16x8*>(a.Wp16) + (size_t)mt0 * 64 + lane;
+        constexpr int PIN = 0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x200;    // VALU, SALU, VMEM, DS writes may cross; MFMA / DS reads not
+        auto ldB = [&](int q, int st, bf16x8* B) {
+#pragma unroll
+          for (int t = 0; t < SPL; ++t)
+            B[t] = cat8(*reinterpret_cast<const bf16x4*>(&hb[buf][2 * q][st][128 * t + lane * 2]),
+                        *reinterpret_cast<const bf16x4*>(&hb[buf][2 * q + 1][st][128 * t + lane * 2]));
+        };
+        constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+        bf16x8 Bc[SPL], Bn[SPL];
+        ldB(0, 0, Bc);
+#pragma unroll
+        for (int q = 0; q < GK / 2; ++q) {
+          const int kp = GK / 2 * gi + q;
+          bf16x8 w8[MCg][SPL];
+#pragma unroll
+          for (int mi = 0; mi < MCg; ++mi)
+#pragma unroll
+            for (int t = 0; t < SPL; ++t)
+              w8[mi][t] = wp16[(((size_t)t * (KT / 2) + (STPDE_ABLATE == 3 ? q : kp)) * MT + mi) * 64];
+#pragma unroll
+          for (int st = 0; st < S; ++st) {
+            if (st + 1 < S) ldB(q, st + 1, Bn);
+            else if (q + 1 < GK / 2) ldB(q + 1, 0, Bn);
+            __builtin_amdgcn_sched_barrier(PIN);
+#pragma unroll
+            for (int c = 0; c < (STPDE_ABLATE == 6 ? 1 : 6); ++c)
+#pragma unroll
+              for (int mi = 0; mi < MCg; ++mi) acc[mi][st] = mfma_bf(w8[mi][TW[c]], Bc[TB[c]], acc[mi][st]);
+            __builtin_amdgcn_sched_barrier(PIN);
+#pragma unroll
+            for (int t = 0; t < SPL; ++t) Bc[t] = Bn[t];
+          }
+        }
+      } else if constexpr (BF) {
         const bf16x8* wp16 = reinterpret_cast<const bf16x8*>(a.Wp16) + (size_t)mt0 * 64 + lane;
 #pragma unroll
         for (int q = 0; q < GK / 2; ++q) {
