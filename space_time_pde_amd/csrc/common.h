@@ -513,25 +513,32 @@ __device__ __forceinline__ float swish_beta_adj(const stpde_jet_cfg& cfg, const 
 }
 
 // Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15 = the 16 rows of a fragment block for one feature group):
-// four v_add_f32 with row_shr DPP modifiers; lane 16g+15 ends up with the full sum.
-// one v_add_f32 with a DPP row-shift on its first operand (lanes shifted in from outside the 16-lane row read 0); written
-// as inline assembly because the compiler otherwise emits v_mov_b32_dpp + v_add_f32 (two VALU issues, and on gfx950 VALU
-// issue cycles are MFMA cycles)
-#define STPDE_DPP_ADD(v, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v))
+// four v_add_f32 with row_shr DPP modifiers on the first operand (lanes shifted in from outside the 16-lane row read 0);
+// lane 16g+15 ends up with the full sum.  Written as inline assembly because the compiler otherwise emits v_mov_b32_dpp +
+// v_add_f32 (two VALU issues, and on gfx950 VALU issue cycles are MFMA cycles).
+// HAZARD: a DPP instruction must not read a VGPR that a VALU instruction wrote less than two wait states earlier, and the
+// compiler's hazard recognizer does not look inside an asm statement.  Every DPP add of this file therefore sits in ONE
+// asm volatile block that (a) opens with `s_nop 1` (covers whatever VALU wrote the operand in front of the block) and
+// (b) keeps two wait states between consecutive shifts of the same register (s_nop 1 here; three other DPP adds in
+// row_sum16x4).  tools/check_dpp_hazard.py scans the disassembly of the built library for violations (run by build()).
 __device__ __forceinline__ float row_sum16(float v) {
-  STPDE_DPP_ADD(v, "row_shr:1");
-  STPDE_DPP_ADD(v, "row_shr:2");
-  STPDE_DPP_ADD(v, "row_shr:4");
-  STPDE_DPP_ADD(v, "row_shr:8");
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(v));
   return v;
 }
 
-// The same sum for the four registers of a fragment block in ONE asm statement, hazard-safe for a wave that has its SIMD to
-// itself: a DPP instruction must not read a VGPR a VALU instruction wrote less than two wait states earlier, and the compiler
-// sees neither the DPP modifiers inside an asm statement nor, therefore, that hazard.  With two waves per SIMD the other
-// wave's instructions happened to sit in between; the one-wave-per-SIMD kernel of round 5 (jet_fc1_bwd.hip) produced wrong
-// row sums with four back-to-back row_sum16 calls.  Here every register's consecutive shifts are three instructions apart and
-// the statement opens with the wait states for whatever wrote v in front of it.
+// The same sum for the four registers of a fragment block in ONE asm statement: every register's consecutive shifts are three
+// instructions apart and the statement opens with the wait states for whatever wrote v in front of it.  (History: with two
+// waves per SIMD the other wave's instructions happened to sit between back-to-back DPP adds; the one-wave-per-SIMD kernel of
+// round 5, jet_fc1_bwd.hip, produced wrong row sums with four scalar row sums in a row.  Round 6: no unprotected form is left.)
 __device__ __forceinline__ f32x4 row_sum16x4(f32x4 v) {
   float a = v[0], b = v[1], c = v[2], d = v[3];
   asm volatile(

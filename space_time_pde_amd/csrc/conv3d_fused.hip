@@ -205,11 +205,8 @@ __global__ __launch_bounds__(256) void k_conv_fused(FusedArgs a) {
         st4(yp, o);
       }
       if (EPI) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s1[r] = row_sum16(s1[r]);
-          s2[r] = row_sum16(s2[r]);
-        }
+        s1 = row_sum16x4(s1);
+        s2 = row_sum16x4(s2);
         if (j == 15) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -303,17 +300,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
     mscale = a.f.m_gamma ? mrstd * ld4(a.f.m_gamma + ch) : mrstd;
     mbeta = a.f.m_beta ? ld4(a.f.m_beta + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // lanes j == 15: this wave's channel sums over its blocks (statistics: fp64; mask sums: fp32 like the atomics they end in)
-  using SumT = typename std::conditional<EPI == 2, float, double>::type;
+  // lanes j == 15: this wave's channel sums over its blocks, in fp64 for both epilogues (per-flush partial sums of at most
+  // FLUSH blocks are fp32 row sums, everything above them is fp64 until the final atomic; ADVICE r5: the fp32 running sum of
+  // the mask epilogue made the BatchNorm-backward sums depend on how many blocks a persistent workgroup processed)
+  using SumT = double;
   SumT sd1[4] = {0, 0, 0, 0}, sd2[4] = {0, 0, 0, 0};
   constexpr int FLUSH = 16;
   f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1, sh = s1;
   int nacc = 0;
   bool have_sh = false;
   auto flush = [&]() {
+    const f32x4 r1 = row_sum16x4(s1), r2 = row_sum16x4(s2);      // (hazard-safe DPP row sums, common.h)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      SumT t1 = row_sum16(s1[rr]), t2 = row_sum16(s2[rr]);
+      SumT t1 = r1[rr], t2 = r2[rr];
       if constexpr (EPI == 1) {                          // sums around the wave's shift -> plain sums, in fp64
         const double s = sh[rr], n = 64. * nacc;
         t2 = t2 + 2. * s * t1 + n * s * s;

@@ -181,9 +181,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
         st_blk(a.Out, (PKM & 2) ? 2 : 0, tile, 1, MT, 0, mt, lane, ab[0]);      // (bf16 mode: the layer-0 adjoint as bf16 blocks)
         f32x4 ts[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ts[d][r] = row_sum16(ab[1 + d][r]);
+        for (int d = 0; d < 3; ++d) ts[d] = row_sum16x4(ab[1 + d]);
         if ((lane & 15) == 15) {
           float* tp = a.Tan0 + ((size_t)tile * MT + mt) * 48 + 4 * (lane >> 4);
 #pragma unroll

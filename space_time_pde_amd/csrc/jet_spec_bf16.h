@@ -487,9 +487,7 @@ __global__ __launch_bounds__(512, 2) void k_fc1_dgrad_spec(LayerArgs a) {
         if (S1 == 3) {
           f32x4 ts[3];
 #pragma unroll
-          for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ts[d][r] = STPDE_DSPEC_ABL == 6 ? ab[1 + d][r] : row_sum16(ab[1 + d][r]);
+          for (int d = 0; d < 3; ++d) ts[d] = STPDE_DSPEC_ABL == 6 ? ab[1 + d] : row_sum16x4(ab[1 + d]);
           if ((lane & 15) == 15 && (STPDE_DSPEC_ABL != 4 || ts[0][0] == 12345.678f)) {
             float* tp = a.Tan0 + ((size_t)tile * MT + mt) * 48 + 4 * (lane >> 4);
 #pragma unroll

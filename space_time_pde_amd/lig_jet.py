@@ -768,6 +768,12 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
 # ``loss.backward()`` sees gradients delivered that way (not ``torch.autograd.grad``): opt-in, set by sharded_step.
 sync_hooks = None
 
+# True while train_step.sharded_step runs the FORWARD of a step whose backward will install ``sync_hooks`` (the hooks themselves
+# are set only around loss.backward(), i.e. after LigJetFunction.forward has made its memory plan): the plan then budgets the
+# dgrad-first scratch of the last chunk (with the test on ``sync_hooks`` alone the term was never counted and a
+# step near the limit failed with an out-of-memory error in the backward instead of shrinking its chunks).
+expect_two_phase = False
+
 # Points of the LAST launch chunk of a differentiable call (0 = no separate tail).  With "defer_wgrad" the weight gradients
 # of that chunk are what the U-Net backward runs beside: 2^17 points = ~18 ms of weight-gradient kernels in exact fp32
 # against ~6 ms of U-Net backward, for +7 GB of dgrad-first adjoint buffers (a whole 2^20-point chunk would take +58 GB).
@@ -849,15 +855,16 @@ def _avail_bytes(meta, device):
 def _stash_bytes(meta, P):
     fwd, bwd = _per_point_bytes(meta)
     last = _chunk_ranges(meta, P)[-1][1]
-    # (the dgrad-first scratch of the last chunk only when the point-sharded step's hooks are installed: ADVICE r4)
-    two = _two_phase_bytes(meta) if sync_hooks else 0
+    # (the dgrad-first scratch of the last chunk only when the point-sharded step's hooks are / will be installed: ADVICE r4, r5)
+    two = _two_phase_bytes(meta) if (sync_hooks or expect_two_phase) else 0
     return P * fwd + min(P, meta.chunk) * bwd + last * two
 
 
 def _recompute_chunk(meta, device):
     """Largest power-of-two chunk whose stash + backward scratch takes at most half of the available memory."""
     fwd, bwd = _per_point_bytes(meta)
-    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd + (_two_phase_bytes(meta) if sync_hooks else 0))))
+    two = _two_phase_bytes(meta) if (sync_hooks or expect_two_phase) else 0
+    n = max(1, int(0.5 * _avail_bytes(meta, device) / (fwd + bwd + two)))
     c = 1 << (n.bit_length() - 1)
     mult = 8 if meta.S == 1 else 2
     return max(mult, min(c, DEFAULT_CHUNK))

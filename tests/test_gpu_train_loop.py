@@ -270,6 +270,120 @@ def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_pat
             assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-10
 
 
+def _config2_rank_worker(rank, port, out):
+    """One rank of BASELINE configs[2] (2^22 points over 8 GPUs -> 2^19 points per rank on the configs[1] grid) behind a
+    world-size-1 "nccl" (RCCL) process group: sharded_step(distributed=True) with n_points_global = 2^22."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import bench
+    from space_time_pde_amd import implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, train_step, unet3d
+    torch.manual_seed(1)
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32,
+                             activation=nonlinearities.NONLINEARITIES["softplus"]).to(dev)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(32, 128, 128), nf=16, mf=256).to(dev).train()
+    n_global, world, shard = 1 << 22, 8, 3                      # this process plays rank 3 of 8
+    n_local = n_global // world
+    g = torch.Generator().manual_seed(7)
+    crop = torch.randn(1, 4, 32, 128, 128, generator=g).to(dev)
+    # the shard's points / targets as bench.py cuts them: a contiguous slice of ONE global draw
+    pts = torch.rand(1, n_global, 3, generator=g)[:, shard * n_local:(shard + 1) * n_local].contiguous().to(dev)
+    tgt = torch.randn(1, n_global, 4, generator=g)[:, shard * n_local:(shard + 1) * n_local].contiguous().to(dev)
+    inner = physics.get_rb2_pde_layer(**bench.RB2)
+    seen = {}
+
+    class _Spy:                      # sharded_step's view of the PDE layer, keeping what the step computed per point
+        def update_forward_method(self, f):
+            inner.update_forward_method(f)
+
+        def __call__(self, q, return_residue=True):
+            pred, res = inner(q, return_residue=return_residue)
+            seen["pred"], seen["res"] = pred.detach(), {k: v.detach() for k, v in res.items()}
+            return pred, res
+
+    unet.register_forward_hook(lambda m, i, o: seen.__setitem__("latent", o.detach().permute(0, 2, 3, 4, 1).contiguous().clone()))
+    res = {}
+    n0 = lig.stats["hip_jet_calls"]
+    for name, flag in (("dist", True), ("local", False)):
+        for p in list(unet.parameters()) + list(net.parameters()):
+            p.grad = None
+        loss, reg, pde = train_step.sharded_step(unet, net, _Spy(), crop, pts, tgt, n_global, bench.ALPHA_REG, bench.ALPHA_PDE,
+                                                 "l1", distributed=flag)
+        torch.cuda.synchronize()
+        res[name] = dict(loss=loss.cpu(), reg=reg.cpu(), pde=pde.cpu(), g_im=[p.grad.cpu().clone() for p in net.parameters()],
+                         collectives=list(train_step.last_collectives))
+    assert lig.stats["hip_jet_calls"] == n0 + 2
+    sel = torch.randperm(n_local, generator=g)[:1024]
+    res.update(latent=seen["latent"].cpu(), pts_sel=pts[:, sel].cpu(), tgt_sel=tgt[:, sel].cpu(), pred_sel=seen["pred"][:, sel].cpu(),
+               res_sel={k: v[:, sel].cpu() for k, v in seen["res"].items()},
+               reg_from_pred=float((seen["pred"] - tgt).abs().sum() / (n_global * 4)),
+               pde_from_res=float(sum(v.abs().sum() for v in seen["res"].values()) / (len(seen["res"]) * n_global)),
+               params=[(net.fc[k].weight.detach().cpu(), net.fc[k].bias.detach().cpu()) for k in range(6)],
+               backend=dist.get_backend(), peak_gb=torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+               recompute=lig_jet.stats["recompute_steps"])
+    torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config2_per_rank_shard_behind_a_world1_nccl_group_vs_oracle_subset(hiplib, tmp_path):
+    """VERDICT r5 next #8 / weak #1 -- BASELINE configs[2]'s PER-RANK workload on hardware: 2^19 points (rank 3's slice of a
+    2^22-point draw) on the [1,32,128,128,32] grid of the training-mode U-Net, through ``sharded_step(distributed=True)`` with
+    n_points_global = 2^22 behind a world-size-1 RCCL ("nccl") process group (train_ddp.py:361-368, 401-406; the box has one
+    device, so the sums over ranks are identities, but every collective of the step is issued on RCCL with its real size).
+    (a) predictions and all four residuals of a random 1024-point subset equal the CPU oracle run on that subset over the
+        latent grid the step's own U-Net produced;
+    (b) the step's losses are the GLOBAL means: local sums / (2^22 points), as train.py:70-75 would give on the full batch;
+    (c) exactly three collectives with configs[2]'s sizes: d latent 64 MiB, the flat IM-NET gradient (>= 0.84 MB), 12 bytes
+        of loss statistics (SURVEY 8e);
+    (d) losses and IM-NET gradients equal the collective-free step on the same shard (fp32 atomic summation order)."""
+    import socket
+    import torch.multiprocessing as mp
+    import bench
+    from oracle import cpu_ref
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "c2_rank.pt")
+    mp.spawn(_config2_rank_worker, args=(port, out), nprocs=1, join=True)
+    r = torch.load(out)
+    assert r["backend"] == "nccl" and r["recompute"] == 0
+    # (a)
+    ref = cpu_ref.lig_pde_step(r["params"], "softplus", r["latent"], r["pts_sel"], r["tgt_sel"], cpu_ref.rb2_oracle(**bench.RB2),
+                               backward=False)
+    assert (r["pred_sel"] - ref["pred"]).abs().max().item() < 2e-5 * ref["pred"].abs().max().item()
+    for k, v in ref["residues"].items():
+        err = (r["res_sel"][k] - v).abs() / v.abs().max()
+        assert err.median().item() < 1e-5 and err.max().item() < 1e-3, (k, err.max().item())
+    # (b)
+    d = r["dist"]
+    assert abs(float(d["reg"]) - r["reg_from_pred"]) < 2e-6 * r["reg_from_pred"]
+    assert abs(float(d["pde"]) - r["pde_from_res"]) < 2e-6 * r["pde_from_res"]
+    assert abs(float(d["loss"]) - (bench.ALPHA_REG * float(d["reg"]) + bench.ALPHA_PDE * float(d["pde"]))) < 1e-6 * abs(float(d["loss"]))
+    # (c)
+    sizes = [b for _, b in d["collectives"]]
+    assert len(sizes) == 3 and sizes[0] == 32 * 128 * 128 * 32 * 4 and sizes[1] >= 209924 * 4 and sizes[2] == 12, d["collectives"]
+    assert r["local"]["collectives"] == []
+    # (d)
+    loc = r["local"]
+    # (two runs of the training-mode U-Net: its statistics are accumulated with atomics, and the 7-level encoder amplifies
+    # rounding differences of its input statistics, DESIGN 2a -- so "equal" is to 1e-4 on the losses and 1e-2 in the Frobenius
+    # norm on the gradients here; the bit-for-bit version of this statement is the fixed-latent case of
+    # test_world_size_1_nccl_group_runs_the_overlapped_collectives)
+    for k in ("loss", "reg", "pde"):
+        assert abs(float(d[k]) - float(loc[k])) <= 1e-4 * abs(float(loc[k])), k
+    for a, b in zip(d["g_im"], loc["g_im"]):
+        assert (a - b).norm().item() <= 1e-2 * b.norm().item() + 1e-12
+    print("configs[2] per-rank shard: peak %.1f GB" % r["peak_gb"])
+
+
 @pytest.mark.gpu
 def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
     """BASELINE configs[3] as ONE composite (VERDICT r4 #3b; reference experiments/rb2d/train.py:58-77 at C4 size): the
