@@ -266,17 +266,10 @@ def small_workload(args):
     for _ in range(max(args.warmup, 3)):
         eager_step()                                                       # (the first optimizer step moves the parameters into
     n0 = lig.stats["hip_jet_calls"]                                        #  the flat buffers: before any capture)
-    import gc
-    gc.collect()
-    gc.disable()
-    ms_eager, loss_e = timed(eager_step, args.steps)
-    ms_eager_async, _ = timed(eager_step, args.steps, item=False)
-    gc.enable()
-    assert lig.stats["hip_jet_calls"] == n0 + 2 * args.steps, "HIP jet path was not taken"
-    # dispatches and device time of ONE eager step (outside the timed regions)
-    disp = ksum = None
-    prof_err = None
-    try:
+    if args.profile_only:
+        # child run of this workload: kernel dispatches and device time of ONE eager step through torch.profiler (roctracer).
+        # In a process of its own: a HIP-graph capture after roctracer has been active in the same process crashed the
+        # interpreter on the test box, and a profiler that is unavailable must not cost the parent its line.
         from torch.profiler import ProfilerActivity, profile
         nprof = 3
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
@@ -285,17 +278,17 @@ def small_workload(args):
             torch.cuda.synchronize()
         kev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "memcpy" not in e.name.lower()
                and "memset" not in e.name.lower()]
-        if kev:
-            disp = len(kev) / float(nprof)
-            ksum = sum((getattr(e, "device_time", None) or getattr(e, "cuda_time", 0.0)) for e in kev) / 1e3 / nprof
-    except Exception as e:  # noqa: BLE001 -- a profiler that is unavailable must not cost the line
-        prof_err = "%s: %s" % (type(e).__name__, e)
-    if disp is None:
-        # fall-back: the library's own dispatch trace (its kernels only; torch's elementwise / cat / copy launches are not seen)
-        from space_time_pde_amd import _lib
-        with _lib.dispatch_trace() as tr:
-            eager_step()
-        disp = float(len(tr.kernels))
+        ksum = sum((getattr(e, "device_time", None) or getattr(e, "cuda_time", 0.0)) for e in kev) / 1e3 / nprof
+        rec = dict(dispatches_per_step=len(kev) / float(nprof), kernel_ms_per_step=ksum)
+        print(json.dumps(rec))
+        return rec
+    import gc
+    gc.collect()
+    gc.disable()
+    ms_eager, loss_e = timed(eager_step, args.steps)
+    ms_eager_async, _ = timed(eager_step, args.steps, item=False)
+    gc.enable()
+    assert lig.stats["hip_jet_calls"] == n0 + 2 * args.steps, "HIP jet path was not taken"
     # the same iteration with forward + backward replayed from a HIP graph
     ms_graph = ms_graph_async = loss_g = None
     graph_err = None
@@ -320,6 +313,26 @@ def small_workload(args):
     except Exception as e:  # noqa: BLE001
         gc.enable()
         graph_err = "%s: %s" % (type(e).__name__, str(e)[:400])
+    # dispatches and device time of ONE eager step: a child run of this script (see --profile-only above); the library's own
+    # dispatch trace (its kernels only, torch's elementwise / cat / copy launches not seen) if that fails
+    disp = ksum = prof_err = None
+    try:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--act", args.act, "--profile-only"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            j = json.loads(line[-1])
+            disp, ksum = j["dispatches_per_step"], j["kernel_ms_per_step"]
+        else:
+            prof_err = "child rc %d: %s" % (r.returncode, r.stderr[-300:])
+    except Exception as e:  # noqa: BLE001
+        prof_err = "%s: %s" % (type(e).__name__, e)
+    if disp is None:
+        from space_time_pde_amd import _lib
+        with _lib.dispatch_trace() as tr:
+            eager_step()
+        disp = float(len(tr.kernels))
     ms = ms_graph if ms_graph is not None else ms_eager
     pts_step = B * N
     out = {
@@ -391,6 +404,7 @@ def main(argv=None):
                     help="skip the `other_configs` block (BASELINE configs[3] and configs[4], each timed by a child run of this "
                          "script after the headline's timed region) and the second headline-grade line `value_fp32x3`")
     ap.add_argument("--sub", action="store_true", help=argparse.SUPPRESS)   # child run of `other_configs`: no side figures
+    ap.add_argument("--profile-only", action="store_true", help=argparse.SUPPRESS)   # child run of a launch-bound workload
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes of each kernel from the committed rocprofv3 --pmc runs")
     args = ap.parse_args(argv)
@@ -422,8 +436,7 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    force_dist = os.environ.get("STPDE_BENCH_FORCE_DIST") == "1"   # exercise the RCCL code path with a single rank
-    if world > 1 or (force_dist and "RANK" in os.environ):
+    if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -470,8 +483,7 @@ def main(argv=None):
     def step():
         for p in params + uparams:
             p.grad = None
-        loss, _, _ = sharded_step(unet, net, layer, crop, pts, tgt, args.points, ALPHA_REG, ALPHA_PDE, "l1",
-                                  distributed=True if (force_dist and dist.is_initialized()) else None)
+        loss, _, _ = sharded_step(unet, net, layer, crop, pts, tgt, args.points, ALPHA_REG, ALPHA_PDE, "l1")
         return loss
 
     def sync():
@@ -505,7 +517,7 @@ def main(argv=None):
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30      # warm-up + timed steps (allocated, not reserved)
     recompute_steps = lig_jet.stats["recompute_steps"]
     # Per-rank diagnosis of a multi-GPU line (outside the timed region, VERDICT r3 #3c): what THIS rank's step costs with no
-    # collective in it (same shard, same kernels, same STPDE_OVERLAP_UNET_BWD setting -- off by default) and what
+    # collective in it (same shard, same kernels) and what
     # its replicated U-Net costs alone; rank 0 prints the per-rank lists and ms_per_step - max(compute_ms) as the exposed
     # communication (+ load imbalance) of the timed steps.
     def local_step():
@@ -666,8 +678,7 @@ def main(argv=None):
         # dominant kernel = largest (median launch time x launches): what a rocprofv3 --stats summary of this command puts in
         # its top row, robust against a single slow launch (>= 8 samples per kernel)
         dom = max(kern, key=lambda k: kern[k]["median_ms"] * kern[k]["launches"])
-        # A kernel may take several launches per step (launch chunks; with the U-Net backward overlapped, a separate last
-        # chunk of lig_jet.tail_chunk points): achieved = its algorithmic FLOPs per STEP / its time per step, which is also
+        # A kernel may take several launches per step (launch chunks): achieved = its FLOPs per STEP / its time per step, which is also
         # FLOPs per launch / average launch duration with both averaged over the same launches -- the figure a rocprofv3
         # --stats summary of this command gives
         lps = kern[dom]["launches"] / float(nprof)
@@ -799,13 +810,8 @@ def main(argv=None):
                          "exposed_comm_ms": round(1e3 * dt / args.steps - max(r[0] for r in per_rank), 2),
                          "note": "compute_ms = this rank's step on its shard with no collective in it (2 steps after the timed "
                                  "region); unet_*_ms = its replicated U-Net alone, eager launches with their gaps (inside the "
-                                 "step the backward runs %s); exposed_comm_ms = ms_per_step - "
-                                 "max(compute_ms): exchange + load imbalance not hidden behind compute"
-                                 % ("beside the IM-NET weight gradients of the last launch chunk (STPDE_OVERLAP_UNET_BWD=1)"
-                                    if os.environ.get("STPDE_OVERLAP_UNET_BWD", "0") == "1" else
-                                    "after the IM-NET backward on the same stream: STPDE_OVERLAP_UNET_BWD=0, the default -- "
-                                    "the side-stream overlap was measured slower, profiles/r4_overlap_timeline.txt"),
-                         "overlap_unet_bwd": os.environ.get("STPDE_OVERLAP_UNET_BWD", "0") == "1"},
+                                 "step the backward runs after the IM-NET backward on the same stream); exposed_comm_ms = "
+                                 "ms_per_step - max(compute_ms): exchange + load imbalance not hidden behind compute"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -65,6 +65,19 @@ typedef struct {
 
 int stpde_version(void);
 int stpde_last_error(char* buf, unsigned long n);
+/* Launch-geometry overrides for TESTS (round 6; nothing in the reference corresponds to it, and the library reads no
+ * environment variable): the persistent-grid convolution kernels pick their grid and their minimum volume themselves; a
+ * test forces other values to reach their multi-block and ragged-tail paths on volumes it can afford.  value 0 = the library's
+ * own choice (the default of every key).  Keys: "conv3_lds_off" (1: the 3x3x3 LDS-tile kernel is not used),
+ * "conv3_lds_minblk" (minimum number of blocks for it), "conv3_lds_gx", "conv_wgrad_lds_gx", "conv1_wgrad_lds_gx" (grid sizes).
+ * Returns the previous value, -1 for an unknown key.  Process-wide, thread-safe. */
+#define STPDE_TUNE_CONV3_LDS_OFF 0
+#define STPDE_TUNE_CONV3_LDS_MINBLK 1
+#define STPDE_TUNE_CONV3_LDS_GX 2
+#define STPDE_TUNE_CONV_WGRAD_LDS_GX 3
+#define STPDE_TUNE_CONV1_WGRAD_LDS_GX 4
+#define STPDE_TUNE_COUNT 5
+int stpde_tune(const char* name, int value);
 /* Dispatch trace (test / debugging facility; nothing in the reference corresponds to it): while enabled, every kernel
  * launch records which template instantiation it dispatched ("<kernel expression> @ <launcher with template
  * arguments>", unique entries).  stpde_trace_enable clears the set; stpde_trace_read copies the newline-separated
@@ -124,12 +137,6 @@ typedef struct {
    * of stpde_jet_layer_bwd / _bwd_to, including the layer-0 adjoint of a first-hidden-layer call: adjoint format),
    * 4 = abar_out (input of the backward / weight-gradient kernels) is a packed adjoint buffer. */
   int packed;
-  /* bf16 mode (round 4): the ACTIVATED input of this layer as the bf16 MFMA operand blocks its forward pass produces anyway
-   * (activation jet of in_pre -- of the layer-0 pre-activations for the first hidden layer -- rounded to bf16), kept as
-   * [tile][KT][S][16 rows][16 features] bf16 (KT * S * 512 bytes per row tile).  stpde_jet_layer_fwd WRITES it when non-NULL;
-   * stpde_jet_wgrad then READS it as its second operand instead of loading in_pre and evaluating the activation jets a
-   * second time (those jets were 2/3 of the first-hidden-layer weight gradient's instructions).  NULL: not kept. */
-  void* act16;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
  * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16.
@@ -227,7 +234,7 @@ int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* abar_out, co
  * of fc1's rows; WhT_pack_bf16: bf16 pack of W1h^T; z0 / tanc0 / cw / X as for the two calls it replaces; abar0 (packed
  * ADJOINT blocks of the value stream, must not alias z0), abar0_tan ([tile][32][3][16] row sums) as stpde_jet_layer_bwd writes
  * them; dW_aug: fc1's block of the flat gradient buffer (accumulated with fp32 atomics).
- * stpde_jet_fc1_bwd_supported(d) != 0 iff this call serves d (STPDE_FC1_FUSED=0 switches it off for A/B timing). */
+ * stpde_jet_fc1_bwd_supported(d) != 0 iff this call serves d (a pure function of d). */
 int stpde_jet_fc1_bwd_supported(const stpde_layer_desc* d);
 int stpde_jet_fc1_bwd(const stpde_layer_desc* d, const float* abar1, const void* WhT_pack_bf16, const float* z0,
                       const float* tanc0, const float* cw, const float* X, float* abar0, float* abar0_tan, float* dW_aug,
@@ -322,7 +329,6 @@ typedef struct {
   unsigned long sort_tmp_bytes;
   float* abar4x;   /* packed buffers: adjoint buffer of fc4's output rows (abar2x / abar3x / abar4x / abar1x then hold packed
                       ADJOINT buffers: nt * S * MT_l * 512 bytes) */
-  void* act16[2];  /* bf16 mode, nullable: stpde_layer_desc.act16 of fc1 and fc2 (nt * KT_l * S * 512 bytes each) */
 } stpde_lig_workspace;
 #define STPDE_F_STASH 1          /* forward: keep what the backward needs (z0) */
 #define STPDE_F_VALUE_TILES 2    /* forward-only value queries: four row tiles per pass over the weights */
@@ -336,6 +342,11 @@ typedef struct {
  * PHASE_B = the remaining weight gradients (fc4 .. fc0).  Between the two the caller may start the all-reduce of d latent. */
 #define STPDE_F_PHASE_A 128
 #define STPDE_F_PHASE_B 256
+/* bf16 mode: do NOT use the fused backward of the first hidden layer (stpde_jet_fc1_bwd); the input gradient and the weight
+ * gradient of that layer then run as two kernels.  A/B switch of the tests.  Both phases of a dgrad-first backward must carry
+ * the same value of this bit and of STPDE_F_WGRAD: phase B skips fc1's weight gradient exactly when phase A's fused kernel
+ * produced it. */
+#define STPDE_F_NO_FC1_FUSED 512
 /* cfg_mlp = streams the layer kernels carry, cfg_out = streams of `jets` (they differ for piecewise-linear activations,
  * see stpde_lig_reduce_fwd); jets points at the first point of the chunk inside [S_out][n_out][ldp]. */
 int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* plan, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,

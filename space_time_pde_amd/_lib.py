@@ -14,9 +14,12 @@ _CSRC = os.path.join(_HERE, "csrc")
 # STPDE_LIB: load another build of the library (A/B timing of kernel variants on one box; never set by tests or the driver)
 LIB_PATH = os.environ.get("STPDE_LIB") or os.path.join(_HERE, "libstpde_hip.so")
 _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_layer_s30.hip", "jet_layer_s31.hip", "jet_layer_s32.hip", "jet_layer_s34.hip", "jet_layer_s36.hip", "jet_tail.hip", "jet_wgrad.hip", "jet_wgrad_s00.hip", "jet_wgrad_s30.hip", "jet_wgrad_s31.hip", "jet_wgrad_s32.hip", "jet_wgrad_s34.hip", "jet_wgrad_s36.hip", "jet_fc1_bwd.hip", "lig_gather_reduce.hip", "lig_pipeline.hip", "interp_nd.hip", "conv3d.hip", "conv3d_fused.hip", "optim.hip", "residual.hip", "bn.hip", "resample.hip", "api.cpp"]
-_HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
+# --offload-compress: the gfx950 code objects are stored zstd-compressed in the fat binary (the HIP runtime inflates them at
+# module load): libstpde_hip.so 68 MB -> ~1/4; the instruction bytes are the same (tools/check_dpp_hazard.py scans them)
+_HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+             "--offload-compress"]
 
-ABI_VERSION = 311   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 312   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
@@ -36,7 +39,7 @@ class GatherDesc(C.Structure):
 
 class LayerDesc(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg),
-                ("mfma_bf16", C.c_int), ("packed", C.c_int), ("act16", C.c_void_p)]
+                ("mfma_bf16", C.c_int), ("packed", C.c_int)]
 
 
 class XbarDesc(C.Structure):
@@ -55,12 +58,11 @@ class LigWorkspace(C.Structure):        # stpde_lig_workspace
     _fields_ = [("X", C.c_void_p), ("XR", C.c_void_p), ("coef", C.c_void_p), ("cw", C.c_void_p), ("cell", C.c_void_p),
                 ("pre", C.c_void_p * 8), ("abar2x", C.c_void_p), ("abar3x", C.c_void_p), ("tan0", C.c_void_p),
                 ("abar0", C.c_void_p), ("abar1x", C.c_void_p), ("abar0x", C.c_void_p), ("xrows", C.c_void_p), ("perm", C.c_void_p), ("start", C.c_void_p),
-                ("sort_tmp", C.c_void_p), ("sort_tmp_bytes", C.c_ulong), ("abar4x", C.c_void_p),
-                ("act16", C.c_void_p * 2)]
+                ("sort_tmp", C.c_void_p), ("sort_tmp_bytes", C.c_ulong), ("abar4x", C.c_void_p)]
 
 
 F_STASH, F_VALUE_TILES, F_FUSED_TAIL, F_TAN0_ROWSUM, F_DETERMINISTIC, F_WGRAD, F_WGRAD_FP32 = 1, 2, 4, 8, 16, 32, 64
-F_PHASE_A, F_PHASE_B = 128, 256
+F_PHASE_A, F_PHASE_B, F_NO_FC1_FUSED = 128, 256, 512
 
 
 class Conv3dDesc(C.Structure):
@@ -168,7 +170,7 @@ def build_library(force=False, verbose=False):
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
         with open(ostamp, "w") as f:
             f.write(owant)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = ["hipcc", "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
@@ -184,6 +186,7 @@ _VP = C.c_void_p
 _SIGNATURES = {
     "stpde_version": ([], C.c_int),
     "stpde_last_error": ([C.c_char_p, C.c_ulong], C.c_int),
+    "stpde_tune": ([C.c_char_p, C.c_int], C.c_int),
     "stpde_trace_enable": ([C.c_int], C.c_int),
     "stpde_trace_read": ([C.c_char_p, C.c_ulong], C.c_long),
     "stpde_lig_gather": ([C.POINTER(GatherDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
@@ -277,6 +280,31 @@ def check(rc):
         buf = C.create_string_buffer(512)
         lib().stpde_last_error(buf, 512)
         raise _EXC.get(rc, RuntimeError)("libstpde_hip: " + buf.value.decode())
+
+
+def tune(name, value):
+    """stpde_tune: launch-geometry override for tests (0 = the library's own choice); returns the previous value."""
+    prev = lib().stpde_tune(name.encode(), int(value))
+    if prev < 0:
+        raise KeyError(name)
+    return prev
+
+
+class tuned:
+    """``with tuned(conv3_lds_gx=24, conv3_lds_minblk=1): ...`` -- overrides restored on exit."""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = tune(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            tune(k, v)
+        return False
 
 
 class dispatch_trace:

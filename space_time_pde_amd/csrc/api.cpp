@@ -29,7 +29,23 @@ int stpde_check_launch(const char* what) {
 }
 
 // ABI version: bumped whenever a descriptor or a signature of include/stpde_hip.h changes (_lib.ABI_VERSION must match)
-extern "C" int stpde_version(void) { return 311; }
+extern "C" int stpde_version(void) { return 312; }
+
+// ---- launch-geometry overrides for tests (stpde_tune, include/stpde_hip.h) ---------------------------------------
+// Not performance switches: the persistent-grid kernels of the U-Net pick their own grid and their own minimum volume; tests
+// force other values to reach the multi-block-per-workgroup and ragged-tail paths on volumes a test can afford.
+#include <atomic>
+static const char* const g_tune_names[STPDE_TUNE_COUNT] = {"conv3_lds_off", "conv3_lds_minblk", "conv3_lds_gx", "conv_wgrad_lds_gx",
+                                                           "conv1_wgrad_lds_gx"};
+static std::atomic<int> g_tune[STPDE_TUNE_COUNT];
+int stpde_tune_get(int key) { return (key >= 0 && key < STPDE_TUNE_COUNT) ? g_tune[key].load(std::memory_order_relaxed) : 0; }
+extern "C" int stpde_tune(const char* name, int value) {
+  if (!name) return -1;
+  for (int k = 0; k < STPDE_TUNE_COUNT; ++k)
+    if (!strcmp(name, g_tune_names[k])) return g_tune[k].exchange(value);
+  stpde_set_error("stpde_tune: unknown key '%s'", name);
+  return -1;
+}
 
 extern "C" int stpde_last_error(char* buf, unsigned long n) {
   if (!buf || n == 0) return STPDE_E_BADARG;

@@ -378,9 +378,8 @@ extern "C" int stpde_bn_bwd(const stpde_bn_desc* d, const float* x, const float*
   a.dr = dresidual;
   a.dgamma = dgamma;
   a.dbeta = dbeta;
-  static const int il_env = getenv("STPDE_BN_IL") ? atoi(getenv("STPDE_BN_IL")) : 1;      // (-5 ... -8 % on the 4.2 M-voxel levels)
-  static const int rg_env = getenv("STPDE_BN_RGRID") ? atoi(getenv("STPDE_BN_RGRID")) : 1024;
-  a.il = il_env;
+  const int rg_env = 1024;      // grid of the reduction pass
+  a.il = 1;                     // interleaved apply pass (-5 ... -8 % on the 4.2 M-voxel levels)
   const unsigned grid = bn_grid(d);
   if (!d->reduce_done) {
     if (!d->scratch_zeroed) (void)hipMemsetAsync(bsum, 0, (size_t)STPDE_BN_REP * 2 * d->C * sizeof(float), (hipStream_t)stream);

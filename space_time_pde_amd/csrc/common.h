@@ -620,3 +620,4 @@ __device__ __forceinline__ void bn_stat_f64(const double* sums, int C, int c, lo
 int stpde_bn_stats_f64(const float* x, long N, int C, double* sums, hipStream_t stream);
 void stpde_set_error(const char* fmt, ...);
 int stpde_check_launch(const char* what);
+int stpde_tune_get(int key);      // test overrides of launch geometry (api.cpp: stpde_tune; 0 = the library's own choice)

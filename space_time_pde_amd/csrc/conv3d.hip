@@ -568,14 +568,13 @@ __global__ __launch_bounds__(512) void k_conv1_wgrad_lds(ConvArgs a) {
 template <bool ONLOAD>
 static bool launch_conv1_wgrad_lds(const ConvArgs& a, hipStream_t st) {
   const int Ci = a.d.Ci, Co = a.d.Co;
-  static const int env = getenv("STPDE_CONV1_WGRAD_LDS") ? atoi(getenv("STPDE_CONV1_WGRAD_LDS")) : 1;
-  if (!env || a.d.ksize != 1 || (Ci != 16 && Ci != 32 && Ci != 64) || (Co != 16 && Co != 32 && Co != 64) || a.nvox < 65536)
+  if (a.d.ksize != 1 || (Ci != 16 && Ci != 32 && Ci != 64) || (Co != 16 && Co != 32 && Co != 64) || a.nvox < 65536)
     return false;
   const int nblk = (a.nvox + 255) / 256;
   // persistent workgroups: as many per CU as their LDS tiles (1 KB per channel of x and ybar) and 32 wave slots allow
   int per_cu = 160 / (Ci + Co + 1);
   if (per_cu > 4) per_cu = 4;
-  static const int gx_env = getenv("STPDE_CONV1_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV1_WGRAD_LDS_GX")) : 0;
+  const int gx_env = stpde_tune_get(STPDE_TUNE_CONV1_WGRAD_LDS_GX);      // (test override, 0 = own choice)
   int gx = gx_env > 0 ? gx_env : 256 * per_cu;
   if (gx > nblk) gx = nblk;
 #define STPDE_C1W(CIT, COT)                                                                              \
@@ -723,20 +722,19 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
     return gx < 1 ? 1 : gx;
   };
   // full-resolution levels (16 / 32 channels, volume made of whole 2 x 4 x 32 blocks, enough of them): the LDS-tile kernel
-  static const int lds_env = getenv("STPDE_CONV_WGRAD_LDS") ? atoi(getenv("STPDE_CONV_WGRAD_LDS")) : 1;
   const int nblk = d->B * (d->T / 2) * (d->Z / 4) * (d->X / 32);
   // (the LDS kernels address x / ybar with 32-bit byte offsets)
   const bool off32 = (size_t)a.nvox * (d->Ci > d->Co ? d->Ci : d->Co) * 4 < (1u << 31);
-  if (lds_env && off32 && d->ksize == 3 && KT <= 2 && MT <= 2 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 32 == 0 && nblk >= 256) {
+  if (off32 && d->ksize == 3 && KT <= 2 && MT <= 2 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 32 == 0 && nblk >= 256) {
     const int wide = (KT == 2 || MT == 2);
     int gx = wide ? 256 : 512;               // persistent workgroups: one (137 KB of LDS) or two (68 KB) per CU
     // Volumes below ~2 M voxels: the training step runs this kernel on a side stream next to the input-gradient chain
     // (unet3d._DeferredGrads), which at that size is a chain of short launches -- a grid that fills every CU with persistent
     // MFMA-bound workgroups stretches that chain by more than the weight gradients shrink (2^17-point step 63.2 -> 64.6 ms);
-    // on half of the CUs it is neutral there and still 2x the per-wave kernel when it runs alone.  STPDE_CONV_WGRAD_LDS_GX
-    // overrides.
-    static const int gx_env = getenv("STPDE_CONV_WGRAD_LDS_GX") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_GX")) : 0;
-    static const int half_below = getenv("STPDE_CONV_WGRAD_LDS_HALF_BELOW") ? atoi(getenv("STPDE_CONV_WGRAD_LDS_HALF_BELOW")) : 8192;
+    // on half of the CUs it is neutral there and still 2x the per-wave kernel when it runs alone.  (stpde_tune
+    // "conv_wgrad_lds_gx": test override of the grid.)
+    const int gx_env = stpde_tune_get(STPDE_TUNE_CONV_WGRAD_LDS_GX);
+    const int half_below = 8192;
     if (gx_env > 0)
       gx = gx_env;
     else if (nblk < half_below)
@@ -755,8 +753,7 @@ static int conv3d_wgrad(const stpde_conv3d_desc* d, const float* x, const float*
   // 64 -> 64 channels (third level): 2 x 4 x 16 blocks, one 16-channel output tile per workgroup on blockIdx.y (round 5; two
   // tiles per workgroup spill: 4 taps x 2 x 4 accumulator tiles + the staging registers)
   const int nblk16 = d->B * (d->T / 2) * (d->Z / 4) * (d->X / 16);
-  static const int lds64_env = getenv("STPDE_CONV_WGRAD_LDS64") ? atoi(getenv("STPDE_CONV_WGRAD_LDS64")) : 1;
-  if (lds_env && lds64_env && off32 && d->ksize == 3 && KT == 4 && MT == 4 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 16 == 0 &&
+  if (off32 && d->ksize == 3 && KT == 4 && MT == 4 && d->T % 2 == 0 && d->Z % 4 == 0 && d->X % 16 == 0 &&
       nblk16 >= 256) {
     int gx = 64;                             // x 4 output tiles: one workgroup (116 KB of LDS) per CU
     if (gx > nblk16) gx = nblk16;

@@ -23,7 +23,6 @@
 struct FusedArgs {
   stpde_conv3d_fused_args f;
   int nvox;
-  int phase;       // k_conv3_lds: start delay of the second half of the grid, in units of s_sleep 127 (~8k cycles)
 };
 
 // MC output tiles per pass, VT voxel tiles per wave, K3: 3x3x3 (else 1x1x1)
@@ -382,13 +381,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
         if (!((f_none >> k) & 1u)) st4(const_cast<float*>(lds_k[k]) + i * HX * SV, px[i][k]);
   };
   if ((int)blockIdx.x < nblk) fetch(blockIdx.x);
-  // Experiment switch (STPDE_CONV3_LDS_PHASE, default 0): the second half of the grid (the second workgroup of every CU)
-  // starts phase x 8k cycles late, so that the staging / epilogue phases of the two workgroups of a CU cannot coincide.
-  // Measured on the configs[3] volume: no difference (32 -> 32 channels 1935 / 1926 / 1948 us for 0 / 2 / 8) -- the two
-  // workgroups do not run in lockstep.
-  if (a.phase > 0 && blockIdx.x >= gridDim.x / 2) {
-    for (int i = 0; i < a.phase; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 #pragma unroll 1
   for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
     __syncthreads();                                     // the readers of the previous block are done
@@ -535,26 +527,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
 // the LDS-tile kernel serves square 16 / 32 / 64-channel 3x3x3 convolutions on volumes made of whole blocks, enough of them
 template <int EPI>
 static bool launch_conv3_lds(const FusedArgs& a0, hipStream_t st) {
-  // (the switches are read per call, not once per process: tests/test_gpu_conv_fused.py compares the two kernels in one run)
-  const char* e = getenv("STPDE_CONV3_LDS");
-  const int env = e ? atoi(e) : 1;
+  // (test overrides through stpde_tune, read per call: tests/test_gpu_conv_fused.py compares the two kernels in one run)
   const stpde_conv3d_desc& d = a0.f.d;
-  if (!env || d.ksize != 3 || d.Ci != d.Co || (d.Ci != 16 && d.Ci != 32 && d.Ci != 64)) return false;
+  if (stpde_tune_get(STPDE_TUNE_CONV3_LDS_OFF) || d.ksize != 3 || d.Ci != d.Co || (d.Ci != 16 && d.Ci != 32 && d.Ci != 64)) return false;
   const int KT = d.Ci / 16;
   const int TZ = KT == 1 ? 4 : 2, TX = KT == 4 ? 16 : 32;
   if (d.T % 2 || d.Z % TZ || d.X % TX) return false;
   if ((size_t)d.B * d.T * d.Z * d.X * d.Ci * 4 >= (1u << 31)) return false;      // 32-bit byte offsets into x / y / m
   const int nblk = d.B * (d.T / 2) * (d.Z / TZ) * (d.X / TX);
-  e = getenv("STPDE_CONV3_LDS_MINBLK");
-  const int minblk = e ? atoi(e) : 1024;
-  if (nblk < minblk) return false;
-  e = getenv("STPDE_CONV3_LDS_GX");
-  const int gx_env = e ? atoi(e) : 0;
+  const int minblk_t = stpde_tune_get(STPDE_TUNE_CONV3_LDS_MINBLK);
+  if (nblk < (minblk_t > 0 ? minblk_t : 1024)) return false;
+  const int gx_env = stpde_tune_get(STPDE_TUNE_CONV3_LDS_GX);
   int gx = gx_env > 0 ? gx_env : 512;                    // two persistent workgroups (64 - 77 KB of LDS) per CU
   if (gx > nblk) gx = nblk;
-  e = getenv("STPDE_CONV3_LDS_PHASE");
-  FusedArgs a = a0;
-  a.phase = e ? atoi(e) : 0;
+  const FusedArgs& a = a0;
 #define STPDE_C3L(K)                                                                  \
   if (KT == K) {                                                                     \
     if constexpr (EPI == 0) STPDE_LAUNCH((k_conv3_lds<K, 0>), dim3(gx), dim3(256), 0, st, a); \

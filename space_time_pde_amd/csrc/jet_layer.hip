@@ -54,7 +54,6 @@ extern "C" int stpde_jet_layer_fwd(const stpde_layer_desc* d, const float* in_pr
   a.ntiles = d->ntiles;
   a.cfg = d->cfg;
   a.pk = d->packed & 3;      // 1: in_pre packed, 2: out_pre packed
-  a.H16 = d->mfma_bf16 == 1 ? d->act16 : nullptr;
   if (!X || !Ws_pack || !out_pre || (d->cfg.S1 && !tanc)) {
     stpde_set_error("jet_layer_fwd: null pointer");
     return STPDE_E_BADARG;

@@ -101,8 +101,6 @@ struct LayerArgs {
   float* Z0;           // [tile][KT or MT][256] value stream of the layer-0 pre-activations: written by the PRO_L0 forward
                        // (nullable there: the stores are dropped), read by EPI_ADJ_L0 instead of regenerating it from X
                        // (may alias Out when Out holds the value stream only: each lane reads its element before it writes it)
-  void* H16;           // forward, bf16 mode, nullable: [tile][KT][S][16][16] bf16 = the activated B-operand blocks of this
-                       // layer as the produce stage rounds them (stpde_layer_desc.act16), kept for the weight gradient
   int KT, MT, ntiles;
   int split;           // cooperative kernel: > 0 = number of output passes, each run by its own workgroup
   int pk;              // packed-buffer flags (common.h: ld_blk / st_blk): 1 = Bin, 2 = Out, 4 = Pre -- a forward kernel reads /
@@ -746,30 +744,17 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
 template <int S1, int S2, int MCg, int PRO, int EPI, int ACT, int NW>
 static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   LayerArgs a = a0;
-  // bf16 operands, first hidden layer of the reference width: the wave-specialised persistent kernel (jet_spec_bf16.h);
-  // STPDE_BF_SPEC=0 keeps the cooperative kernel
+  // bf16 operands, first hidden layer of the reference width: the wave-specialised persistent kernel (jet_spec_bf16.h)
   if constexpr (PRO == PRO_L0 && EPI == EPI_FWD && NW == 4 && MCg == 4 && S1 == 3 && S2 <= 2) {
-    static const int spec_env = getenv("STPDE_BF_SPEC") ? atoi(getenv("STPDE_BF_SPEC")) : 1;
-    if (a.Wp16 && a.nsplit == 1 && spec_env && a.MT == 16 && (a.KT == 32 || a.KT == 16))
+    if (a.Wp16 && a.nsplit == 1 && a.MT == 16 && (a.KT == 32 || a.KT == 16))
       return launch_fc1_fwd_spec<S1, S2, ACT>(a, stream);
   }
-  // ... and its input gradient with packed buffers and the tangent row sums (round 4): k_fc1_dgrad_spec; STPDE_BF_SPEC_DGRAD=0
-  // keeps the cooperative kernel
-  if constexpr (PRO == PRO_NONE && EPI == EPI_ADJ_L0 && NW == 4 && MCg == 4 && S1 == 3 && S2 <= 1) {
-    static const int dspec_env = getenv("STPDE_BF_SPEC_DGRAD") ? atoi(getenv("STPDE_BF_SPEC_DGRAD")) : 1;
-    if (a.Wp16 && a.nsplit == 1 && dspec_env && a.pk == 3 && a.MT == 32 && a.KT == 16 && a.Tan0 && a.Z0)
-      return launch_fc1_dgrad_spec<S1, S2, ACT>(a, stream);
-  }
-  // ... and the forward of the second hidden layer (round 5): k_fc2_fwd_bf; STPDE_FC2_FWD_SPEC=0 keeps the cooperative kernel
+  // ... and the forward of the second hidden layer (round 5): k_fc2_fwd_bf.  (The input gradient of the first hidden layer
+  // in that mode is the fused kernel of jet_fc1_bwd.hip, sequenced by lig_pipeline.hip; this cooperative kernel serves a
+  // backward without weight gradients and the stream sets the fused kernel is not compiled for.)
   if constexpr (PRO == PRO_ACT && EPI == EPI_FWD && NW == 4 && MCg == 2 && S1 == 3 && S2 <= 1) {
-    static const int f2_env = getenv("STPDE_FC2_FWD_SPEC") ? atoi(getenv("STPDE_FC2_FWD_SPEC")) : 1;
-    if (a.Wp16 && a.nsplit == 1 && f2_env && a.pk == 3 && a.KT == 16 && a.MT == 8 && !a.H16)
+    if (a.Wp16 && a.nsplit == 1 && a.pk == 3 && a.KT == 16 && a.MT == 8)
       return launch_fc2_fwd_bf<S1, S2, ACT>(a, stream);
-  }
-  if (EPI == EPI_FWD && a.H16) {
-    stpde_set_error("jet_layer_fwd: act16 is written by the wave-specialised bf16 forward of the first hidden layer only "
-                    "(S1 = 3, S2 <= 2, 16 output tiles, 16 / 32 input tiles, STPDE_BF_SPEC != 0)");
-    return STPDE_E_UNSUPPORTED;
   }
   const int npass = a.MT / (NW * MCg);
   // kernels that stream their B operand from the stash and need several output passes: one workgroup per pass
@@ -807,15 +792,12 @@ static int launch_layer_coop(const LayerArgs& a0, hipStream_t stream) {
   }
   else {
     // 4 output tiles per wave: weight fragments through the 3-deep register ring (-2.5 % on the forward of the widest
-    // layer; no gain for the 2-tile-per-wave shapes).  STPDE_WRING=0 switches it off.
-    static const int wring_env = getenv("STPDE_WRING") ? atoi(getenv("STPDE_WRING")) : 1;
+    // layer; no gain for the 2-tile-per-wave shapes).  (The cooperative kernels are launched with KT >= 8 only.)
     if constexpr (NW == 4 && MCg == 4 && S1 + S2 <= 5) {      // (S = 8: the ring's 48 fragment registers spill)
-      if (wring_env && a.KT >= 8) {
-        STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false, 1, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
-        return stpde_check_launch("k_layer_coop");
-      }
+      STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false, 1, true>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
+    } else {
+      STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
     }
-    STPDE_LAUNCH((k_layer_coop<S1, S2, MCg, PRO, EPI, ACT, NW, false>), dim3(nblocks), dim3(64 * NW), 0, stream, a);
   }
   return stpde_check_launch("k_layer_coop");
 }
@@ -877,16 +859,14 @@ static int launch_fwd_act(const LayerArgs& a, hipStream_t stream) {
     }
   }
   // many-stream sets (S = 10, configs[4]): the cooperative kernel with two output tiles per wave, one workgroup per CU (its
-  // ring takes 80 KB) instead of the per-wave kernel below (round 4: configs[4] step 994 -> 892 ms, first-layer forward 251 -> 183 ms; STPDE_COOP_S10=0: per-wave kernels)
+  // ring takes 80 KB) instead of the per-wave kernel below (round 4: configs[4] step 994 -> 892 ms, first-layer forward 251 -> 183 ms)
   if constexpr (S1 + S2 > 5) {
-    static const int coop10 = getenv("STPDE_COOP_S10") ? atoi(getenv("STPDE_COOP_S10")) : 1;
     // S = 8 (round 5, the (3,4) set of configs[4]): its forward kernels also fit four output tiles per wave without scratch
-    // (250 registers, 64 KB ring: two workgroups per CU) -- half the ring reads per MFMA; STPDE_COOP_S8_MC4=0: two tiles
+    // (250 registers, 64 KB ring: two workgroups per CU) -- half the ring reads per MFMA (configs[4] 690.0 -> 682.4 ms)
     if constexpr (S1 + S2 == 7 && EPI == EPI_FWD) {
-      static const int mc4 = getenv("STPDE_COOP_S8_MC4") ? atoi(getenv("STPDE_COOP_S8_MC4")) : 1;   // (measured: configs[4] 690.0 -> 682.4 ms)
-      if (mc4 && coop10 && a.KT % 4 == 0 && a.KT >= 8 && a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4, 4>(a, stream);
+      if (a.KT % 4 == 0 && a.KT >= 8 && a.MT % 16 == 0) return launch_coop_act<S1, S2, PRO, EPI, 4, 4>(a, stream);
     }
-    if (coop10 && a.KT % 4 == 0 && a.KT >= 8 && a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
+    if (a.KT % 4 == 0 && a.KT >= 8 && a.MT % 8 == 0) return launch_coop_act<S1, S2, PRO, EPI, 2, 4>(a, stream);
   }
   // kernels that stream their B operand from memory (everything except the layer-0-on-the-fly forward) halve that
   // traffic with 8 output tiles per pass; S=10 would not fit the register file

@@ -83,11 +83,6 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
     auto produce = [&](auto gc, int tile) {
       constexpr int g = decltype(gc)::value;
       const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
-      // the operand blocks of this tile for the weight gradient (stpde_layer_desc.act16): [kt][st][row][feature] bf16, this
-      // lane's four features of its row as one 8-byte store (empty descriptor when not kept: the stores are dropped)
-      const auto h16r = opt_store_rsrc(a.H16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.H16) + (size_t)tile * KT * S * 512) : nullptr,
-                                       (unsigned)(KT * S) * 512u);
-      const int h16lane = ((lane & 15) * 16 + 4 * (lane >> 4)) * 2;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int slot = 4 * k + w, kt = GK * g + slot;
@@ -112,8 +107,6 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
         for (int st = 0; st < S; ++st) {
           const bf16x4 b4 = to_bf4(B[st]);
           *reinterpret_cast<bf16x4*>(&hb[g & 1][slot >> 1][st][slot & 1][lane * 2]) = b4;
-          // (the k-tile index depends on the wave index: through readfirstlane, or every store sits in a waterfall loop)
-          buf_st8(h16r, h16lane, (__builtin_amdgcn_readfirstlane(kt) * S + st) * 512, b4);
         }
       }
     };
@@ -287,279 +280,24 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
   static_assert(NST <= 4 && NST >= 2 && NST % 2 == 0, "ring parity needs an even number of steps per tile");
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Input gradient of the first hidden layer, bf16 operands, packed buffers (round 4): the same idea the other way round.
-// In k_layer_coop<..., EPI_ADJ_L0, BF> every wave alternates between the bf16 MFMAs of its output tiles and their epilogue --
-// the activation-jet adjoint against the z0 stash, the VALU-heavy half of the kernel -- and the two never overlap inside a
-// wave: SQ counters of round 3 (profiles/r3_bf16_pmc_sq_counters.txt) 11.1 ms of VALU issue + 5.2 ms of MFMA for a 22.3 ms kernel.
-// Here the 8 waves of a persistent workgroup (one per CU) have fixed roles, one of each on every SIMD:
-//   waves 0-3 ("M")  the bf16 MFMAs.  The B operand of a row tile -- its S x 16 adjoint blocks, 40 KB at S = 5 -- is read from
-//                    an LDS copy into REGISTERS once per row tile (S x 8 bf16x8 fragments) and reused for the wave's 8 output
-//                    tiles; the weight fragments stream from L2 through a register ring one step (8 k-tile pairs) deep that
-//                    runs across steps and row tiles.  One output tile (S accumulator blocks) per step goes to an LDS
-//                    hand-off slot.  (Wave 0 also carries the next row tile's combination weights cw into LDS.)
-//   waves 4-7 ("E")  the epilogue of the tile their partner M-wave finished in the PREVIOUS step: activation-jet adjoint
-//                    against the z0 block and the tangent constants W0[:, d] (this wave's 8 tiles: registers, loaded once),
-//                    layer-0 adjoint value stream as bf16 blocks, tangent streams as DPP row sums.  They also bring the NEXT
-//                    row tile into LDS -- its adjoint blocks (staging buffer of the M-waves) and its z0 blocks (each into the
-//                    slot whose block has just been consumed) -- with global_load_lds: no registers, no wait at a use.  An
-//                    E-wave has NO ordinary global load in its loop (the first version waited an HBM round trip per step at
-//                    the use of a load issued in the same step: 22.8 ms, no faster than the cooperative kernel); the only
-//                    vector-memory wait is one counted s_waitcnt per row tile in front of the barrier that hands the staged
-//                    tile to the M-waves.
-// One barrier per step (8 per row tile).  LDS: 40 KB staging + 4 x 2 x S KB hand-off + 32 KB of z0.  Arithmetic: operand
-// rounding, the accumulation order over the k-tile pairs and the epilogue are those of k_layer_coop<..., BF = true, PKM = 3>.
-// ------------------------------------------------------------------------------------------------------------
+// (Round 4's wave-specialised input gradient of this layer, k_fc1_dgrad_spec, was superseded in round 5 by the fused backward
+// k_fc1_bwd_fused, csrc/jet_fc1_bwd.hip, and deleted in round 6; a backward that wants no weight gradients, or a stream set
+// the fused kernel is not compiled for, takes k_layer_coop<..., EPI_ADJ_L0, BF>.)
+
 // Workgroup barrier WITHOUT the vector-memory drain: __syncthreads() of a wave that has a global_load_lds in flight is
 // compiled to `s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier`, i.e. every step would wait for the HBM round trip of the piece it
-// has just requested (measured: 3.3 k cycles per step, the whole gain of the role split).  LDS writes of this wave are
-// complete at lgkmcnt(0); pieces in flight are waited for explicitly where their data is needed.
+// has just requested.  LDS writes of this wave are complete at lgkmcnt(0); pieces in flight are waited for explicitly where
+// their data is needed.
 #define SPEC_BARRIER()                                     \
   do {                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
     __builtin_amdgcn_s_barrier();                          \
     asm volatile("" ::: "memory");                         \
   } while (0)
-// Timing-only ablations of k_fc1_dgrad_spec (tools/micro/ablate_dgrad_spec.py, private builds; results are WRONG):
-// 1 = weight fragments not re-fetched, 2 = no activation-jet adjoint, 3 = no LDS-DMA pieces, 4 = no global stores,
-// 5 = no MFMAs, 6 = no DPP row sums
-#ifndef STPDE_DSPEC_ABL
-#define STPDE_DSPEC_ABL 0
-#endif
+// 16 bytes per lane from global memory straight into LDS (no registers, no wait at a use)
 #define STPDE_GLDS16(gptr, lptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-// TPS = output tiles per wave and step (1 or 2).  With one tile per step an E-wave issues ~280 instructions per step at
-// ~6 cycles each -- a single dependent chain per wave (LDS read -> transcendentals -> DPP row sums), 1750 cycles per step with
-// the MFMAs removed (tools/micro/ablate_dgrad_spec.py, profiles/r4_ablate_dgrad_spec.txt) -- so TPS = 2 gives it two
-// independent tiles per step to interleave, and halves the barriers.
-template <int S1, int S2, int ACT, int TPS>
-__global__ __launch_bounds__(512, 2) void k_fc1_dgrad_spec(LayerArgs a) {
-  constexpr int S = 1 + S1 + S2, MT = 32, KT = 16, KP = KT / 2, NSTEP = MT / (4 * TPS);
-  constexpr int NCHUNK = S * KT / 2;                                       // 1 KiB chunks of a packed ADJOINT tile (40 at S = 5)
-  constexpr int WRING = TPS == 1 ? KP : KP / 2;                            // weight ring: k-tile pairs ahead
-  __shared__ __attribute__((aligned(16))) float bst[NCHUNK * 256];         // the tile as it lies in HBM: [st][kt][lane][4 bf16]
-  __shared__ __attribute__((aligned(16))) float ho[4][2][TPS][S][256];     // hand-off: accumulator blocks (fp32)
-  __shared__ __attribute__((aligned(16))) float z0s[MT][256];              // z0 blocks of the row tile in flight
-  __shared__ float cqs[2][16];                                             // combination weights of the two points of a row tile
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const bool ewave = wv >= 4;
-  const int w = __builtin_amdgcn_readfirstlane(wv & 3);
-  const int lo = lane * 4;
-  const int G = gridDim.x;
-  const int ntl = a.ntiles > (int)blockIdx.x ? (a.ntiles - (int)blockIdx.x + G - 1) / G : 0;   // row tiles of this workgroup
-  constexpr size_t TILE_IN = (size_t)NCHUNK * 1024;
-  // output tile e of this wave in step s
-  auto mt_of = [&](int s, int e) { return 4 * (TPS * s + e) + w; };
-
-  if (!ewave) {
-    // =========================================== M-waves ===========================================
-    bf16x8 B8[KP][S];
-    f32x4 acc[TPS][S];
-    bf16x8 wr[TPS][WRING];
-    const auto wrs = load_rsrc(a.Wp16, (unsigned)KP * MT * 1024u);
-    const int wlane = lane * 16 + w * 1024;
-    // weight fragment (n, e) of this wave's stream: step n / KP, k-tile pair n % KP, output tile 4 (TPS step + e) + w
-    auto wload = [&](int n, int e) -> bf16x8 {
-      const int step = (n / KP) % NSTEP, kp = n % KP;
-      return __builtin_bit_cast(bf16x8, buf_ld16(wrs, wlane, ((kp * MT + 4 * (TPS * step + e)) * 64) * 16));
-    };
-#pragma unroll
-    for (int e = 0; e < TPS; ++e)
-#pragma unroll
-      for (int q = 0; q < WRING; ++q) wr[e][q] = wload(q, e);
-    float cwn = 0.f;
-    if (S2 == 1 && w == 0 && lane < 16 && ntl > 0) cqs[0][lane] = a.cw[(size_t)blockIdx.x * 16 + lane];
-    SPEC_BARRIER();                      // the E-waves have staged the first row tile
-    for (int it = 0; it <= ntl; ++it) {
-      const int tile = (int)blockIdx.x + it * G;
-      auto step = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-#pragma unroll
-        for (int e = 0; e < TPS; ++e)
-#pragma unroll
-          for (int st = 0; st < S; ++st) acc[e][st] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp) {
-          const int n = s * KP + kp;               // compile-time after unrolling
-#pragma unroll
-          for (int e = 0; e < TPS; ++e) {
-#pragma unroll
-            for (int st = 0; st < S; ++st)
-              if (STPDE_DSPEC_ABL != 5) acc[e][st] = mfma_bf(wr[e][kp % WRING], B8[kp][st], acc[e][st]);
-            // ring: WRING pairs ahead (wraps into the next step / row tile: the weights do not depend on the row tile)
-            if (STPDE_DSPEC_ABL != 1) wr[e][kp % WRING] = wload(n + WRING, e);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < TPS; ++e)
-#pragma unroll
-          for (int st = 0; st < S; ++st) st4(&ho[w][s & 1][e][st][lo], acc[e][st]);
-        // combination weights of the next row tile: requested in step 0, into LDS in step 2 (wave 0, 16 lanes)
-        if (S2 == 1 && s == 0 && w == 0 && lane < 16 && it + 1 < ntl) cwn = a.cw[(size_t)(tile + G) * 16 + lane];
-        if (S2 == 1 && s == 2 && w == 0 && lane < 16 && it + 1 < ntl) cqs[(it + 1) & 1][lane] = cwn;
-      };
-      if (it < ntl) {
-        const bf16x4* bs = reinterpret_cast<const bf16x4*>(bst) + lane;
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp)
-#pragma unroll
-          for (int st = 0; st < S; ++st) B8[kp][st] = cat8(bs[(st * KT + 2 * kp) * 64], bs[(st * KT + 2 * kp + 1) * 64]);
-        step(std::integral_constant<int, 0>{});
-      }
-      SPEC_BARRIER();
-      if (it == ntl) break;
-      step(std::integral_constant<int, 1>{});
-      SPEC_BARRIER();
-      step(std::integral_constant<int, 2>{});
-      SPEC_BARRIER();
-      step(std::integral_constant<int, 3>{});
-      SPEC_BARRIER();
-      if constexpr (NSTEP == 8) {
-        step(std::integral_constant<int, 4>{});
-        SPEC_BARRIER();
-        step(std::integral_constant<int, 5>{});
-        SPEC_BARRIER();
-        step(std::integral_constant<int, 6>{});
-        SPEC_BARRIER();
-        step(std::integral_constant<int, 7>{});
-        SPEC_BARRIER();
-      }
-    }
-  } else {
-    // =========================================== E-waves ===========================================
-    f32x4 tc[S1 == 3 ? NSTEP * TPS : 1][3];
-    if (S1 == 3) {
-#pragma unroll
-      for (int q = 0; q < NSTEP * TPS; ++q)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) tc[q][d] = ld4(a.tanc0 + ((size_t)d * MT + 4 * q + w) * 256 + lo);
-    }
-    float cq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float pacc = 0.f;
-    // chunks q0 .. q1 of this wave's share (chunk w + 4 q) of row tile `tile` into the staging buffer
-    auto stage = [&](int tile, int q0, int q1) {
-      const char* src = reinterpret_cast<const char*>(a.Bin) + (size_t)tile * TILE_IN + lane * 16;
-#pragma unroll
-      for (int q = q0; q < q1; ++q) {
-        const int c = __builtin_amdgcn_readfirstlane(w + 4 * q);
-        if (STPDE_DSPEC_ABL != 3) STPDE_GLDS16(src + (size_t)c * 1024, reinterpret_cast<char*>(bst) + c * 1024);
-      }
-    };
-    auto z0dma = [&](int tile, int blk) {          // z0 block `blk` (wave-uniform) of row tile `tile` into its LDS slot
-      if (STPDE_DSPEC_ABL != 3) STPDE_GLDS16(a.Z0 + ((size_t)tile * MT + blk) * 256 + lo, &z0s[blk][0]);
-    };
-    constexpr int NQ = NCHUNK / 4;                 // chunks per E-wave and row tile (10 at S = 5)
-    if (ntl > 0) {
-      stage(blockIdx.x, 0, NQ);
-#pragma unroll
-      for (int q = 0; q < NSTEP * TPS; ++q) z0dma(blockIdx.x, 4 * q + w);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    SPEC_BARRIER();                      // (matches the M-waves' barrier in front of their loop)
-    // epilogue of the output tiles of step s of row tile `tile` out of hand-off slot (s & 1)
-    auto epi = [&](int tile, auto sc) {
-      constexpr int s = decltype(sc)::value;
-#pragma unroll
-      for (int e = 0; e < TPS; ++e) {
-        const int mt = mt_of(s, e);
-        f32x4 hbar[S], pre[S], ab[S];
-#pragma unroll
-        for (int st = 0; st < S; ++st) hbar[st] = ld4(&ho[w][s & 1][e][st][lo]);
-        pre[0] = ld4(&z0s[mt][lo]);
-        if (S1 == 3) {
-#pragma unroll
-          for (int d = 0; d < 3; ++d) pre[1 + d] = tc[S1 == 3 ? TPS * s + e : 0][d];
-#pragma unroll
-          for (int p = 0; p < S2; ++p) pre[4 + p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (STPDE_DSPEC_ABL == 2) {
-#pragma unroll
-          for (int st = 0; st < S; ++st) ab[st] = hbar[st] + pre[st];
-        } else {
-          act_jet_adj<S1, S2, ACT>(a.cfg, pre, hbar, ab, cq);
-        }
-        if (ACT == STPDE_ACT_SWISH && a.pbar) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, hbar, cq);
-        // layer-0 adjoint: value stream as a bf16 block (packed ADJOINT buffer with one stream), tangent streams as row sums
-        if (STPDE_DSPEC_ABL != 4 || ab[0][0] == 12345.678f)
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.Out) + ((size_t)tile * MT + mt) * 512 + lane * 8) = to_bf4(ab[0]);
-        if (S1 == 3) {
-          f32x4 ts[3];
-#pragma unroll
-          for (int d = 0; d < 3; ++d) ts[d] = STPDE_DSPEC_ABL == 6 ? ab[1 + d] : row_sum16x4(ab[1 + d]);
-          if ((lane & 15) == 15 && (STPDE_DSPEC_ABL != 4 || ts[0][0] == 12345.678f)) {
-            float* tp = a.Tan0 + ((size_t)tile * MT + mt) * 48 + 4 * (lane >> 4);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) st4(tp + 16 * d, ts[d]);
-          }
-        }
-      }
-    };
-    // the z0 slots of step s take the blocks of row tile `tile` (after their old blocks have been read)
-    auto z0next = [&](int tile, int s) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < TPS; ++e) z0dma(tile, mt_of(s, e));
-    };
-    for (int it = 0; it <= ntl; ++it) {
-      const int tile = (int)blockIdx.x + it * G;           // the M-waves' tile; step 0 here finishes tile - G
-      // step 0: last step of the previous row tile (cq still belongs to it), then its z0 slots take this tile's blocks
-      if (it >= 1) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        epi(tile - G, std::integral_constant<int, NSTEP - 1>{});
-        if (it < ntl) z0next(tile, NSTEP - 1);
-      }
-      if (S2 == 1 && it < ntl) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cq[i] = cqs[it & 1][8 * ((lane & 15) >> 3) + i];
-      }
-      SPEC_BARRIER();
-      if (it == ntl) break;
-      const bool more = it + 1 < ntl;
-      // steps 1 .. NSTEP-1: epilogue of (tile, s - 1), then the next row tile's z0 blocks into the slots just consumed; steps 1
-      // and 2 also bring the next row tile's adjoint blocks into the staging buffer (the M-waves read it in step 0 only)
-      auto step = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        // the only vector-memory wait of a step: everything but the 8 newest operations has landed (a step issues >= 5 TPS of
-        // them: TPS z0 blocks requested, 4 TPS stores) -- the z0 blocks requested two steps ago or earlier (they are read
-        // NSTEP steps after their request), and in front of step 3 the staged row tile (requested in steps 1 and 2)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        if (s <= 2 && more) stage(tile + G, (s - 1) * (NQ / 2), s == 2 ? NQ : NQ / 2);
-        epi(tile, std::integral_constant<int, s - 1>{});
-        if (more) z0next(tile + G, s - 1);
-        SPEC_BARRIER();
-      };
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
-      if constexpr (NSTEP == 8) {
-        step(std::integral_constant<int, 4>{});
-        step(std::integral_constant<int, 5>{});
-        step(std::integral_constant<int, 6>{});
-        step(std::integral_constant<int, 7>{});
-      }
-    }
-    if (ACT == STPDE_ACT_SWISH && a.pbar) {
-      const float v = wave_sum(pacc);
-      if (lane == 0) atomicAdd(a.pbar + (blockIdx.x % STPDE_PBAR_SLOTS), v);
-    }
-  }
-}
-
-template <int S1, int S2, int ACT>
-static int launch_fc1_dgrad_spec(const LayerArgs& a, hipStream_t stream) {
-  int dev = 0, ncu = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const int grid = ncu < a.ntiles ? ncu : a.ntiles;
-  static const int tps_env = getenv("STPDE_DSPEC_TPS") ? atoi(getenv("STPDE_DSPEC_TPS")) : 2;
-  if (tps_env == 2)
-    STPDE_LAUNCH((k_fc1_dgrad_spec<S1, S2, ACT, 2>), dim3(grid), dim3(512), 0, stream, a);
-  else
-    STPDE_LAUNCH((k_fc1_dgrad_spec<S1, S2, ACT, 1>), dim3(grid), dim3(512), 0, stream, a);
-  return stpde_check_launch("k_fc1_dgrad_spec");
-}
 
 template <int S1, int S2, int ACT>
 static int launch_fc1_fwd_spec(const LayerArgs& a, hipStream_t stream) {

@@ -346,16 +346,10 @@ static int launch_tail_nft(const TailArgs& a, int nft, hipStream_t stream) {
   if (a.packed || a.Wh16[0]) {
     if constexpr (S1 == 3) {       // bf16 mode: the training stream sets, reference width, every layer buffer packed
       if (nft == 2 && a.packed == 3 && a.Wh16[0] && a.Wh16[1] && a.Wh16[2]) {
-        // persistent, tile-independent operands in LDS (STPDE_TAIL_FWD_LDS=0: one wave per tile, operands from L2)
-        static const int ldsw = getenv("STPDE_TAIL_FWD_LDS") ? atoi(getenv("STPDE_TAIL_FWD_LDS")) : 1;
-        if (ldsw && a.cfg.S1 == 3) {
-          static const int gx_env = getenv("STPDE_TAIL_FWD_LDS_GX") ? atoi(getenv("STPDE_TAIL_FWD_LDS_GX")) : 0;
-          int gx = gx_env > 0 ? gx_env : 256;
-          if (gx > (a.ntiles + 7) / 8) gx = (a.ntiles + 7) / 8;
-          STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT, true>), dim3(gx), dim3(512), 0, stream, a);
-        } else {
-          STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT, false>), grid, dim3(256), 0, stream, a);
-        }
+        // persistent, tile-independent operands in LDS
+        int gx = 256;
+        if (gx > (a.ntiles + 7) / 8) gx = (a.ntiles + 7) / 8;
+        STPDE_LAUNCH((k_tail_fwd_bf<S1, S2, ACT, true>), dim3(gx), dim3(512), 0, stream, a);
         return stpde_check_launch("k_tail_fwd_bf");
       }
     }

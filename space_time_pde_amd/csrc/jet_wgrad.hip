@@ -34,7 +34,6 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   a.cfg = d->cfg;
   a.bf16 = d->mfma_bf16;
   a.pk = d->packed & 5;      // 1: in_pre (Q) packed, 4: abar_out (P) packed
-  a.H16 = d->mfma_bf16 == 1 ? d->act16 : nullptr;
   if (d->KT > 0 && !in_pre) {
     stpde_set_error("jet_wgrad: null in_pre");
     return STPDE_E_BADARG;

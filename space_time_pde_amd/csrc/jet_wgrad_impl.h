@@ -31,16 +31,11 @@ struct WgradArgs {
   const float* tanc0;  // [3][KT][256] layer-0 tangent constants W0[:, d], column-major image (MODE 1)
   float* dW;           // [16*MT][16*(KT+XT)]
   const float* cw;     // [P][8] weights of the combined second-order stream (S2 == 1)
-  const void* H16;     // bf16 mode, nullable: the activated input as the forward's bf16 operand blocks [tile][KT][S][16][16]
-                       // (stpde_layer_desc.act16); the kernels compiled for it (PKM bit 8) copy these blocks into the ring
-                       // instead of loading Q and evaluating the activation jets
   int SP, KT, MT, ntiles;
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
   int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
   int pk;              // packed-buffer flags (common.h: ld_blk): 1 = Q (the layer input's pre-activations), 4 = P (abar_out)
-  int xonly;           // launch the raw-input k-group only (the hidden k-tiles were done by k_fc1_bwd_fused, jet_fc1_bwd.hip)
-  int swap;            // plain bf16 mode: the second wave of every SIMD runs the two phases of an iteration in the other order
   int xfold;           // fp32 hidden-group launches: the (k-group, k-slot) pairs 0 .. XT-1 also contract their abar blocks with
                        // raw-input tile 0 .. XT-1 (one extra 16x16 tile per wave, the XR fragment straight from memory), and all
                        // of them keep the row sums of the tangent-stream adjoints (the tangent "input" of a skip connection is the
@@ -108,11 +103,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // with one ds_read_b64 -- the same layout serves the column-major producers (transposing ds_write_b16) and the
   // row-major ones (ds_write_b64).
   constexpr bool SPLP = BF && SPL == 3;
-  // HQ (PKM bit 8, plain bf16 mode): the hidden k-tiles' operand blocks come ready-made from the forward pass (a.H16, the
-  // very bytes put() would write: [row][feature] bf16) -- load_q fetches 8 bytes per lane and stream, finish_q copies them
-  // into the ring slot.  No stash load, no activation jet, no rounding: bit-identical blocks for 2/3 fewer instructions.
-  constexpr bool HQ = (PKM & 8) != 0;
-  static_assert(!HQ || (BF && SPL == 1), "ready-made operand blocks are a plain-bf16-mode feature");
   // bf16-pipe modes: every LDS block (ring slots and the private abar patches) holds the SPL bf16 terms of a fragment as
   // [term][16][16] bf16 (512 B per term), written with ONE ds_write_b64 per lane and term at (lane & 15) * 16 + 4 * (lane >> 4)
   // -- which is [row][feature] for a column-major source and [feature][row] for a row-major one -- and read back as the
@@ -197,17 +187,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // so the loads' latency hides behind the MFMAs instead of sitting in front of the barrier
   auto load_q = [&](int tile, f32x4* pre, float* cq) {
     const int kq = kq0 + wv;
-    if constexpr (HQ) {
-      if (!HASX || kq < KT) {
-        const char* hb8 = reinterpret_cast<const char*>(a.H16) + ((size_t)tile * KT + kq) * S * 512 + lane * 8;
-#pragma unroll
-        for (int st = 0; st < S; ++st) {
-          const float2 v = *reinterpret_cast<const float2*>(hb8 + st * 512);
-          pre[st] = f32x4{v.x, v.y, 0.f, 0.f};
-        }
-        return;
-      }
-    }
     if (!HASX || kq < KT) {
       // rows of this lane (column-major image): row = lane & 15
       load_cq<S2>(a.cw, tile * 2 + (c >> 3), cq);
@@ -231,14 +210,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   };
   auto finish_q = [&](const f32x4* pre, const float* cq, int buf) {
     const int kq = kq0 + wv;
-    if constexpr (HQ) {
-      if (!HASX || kq < KT) {
-#pragma unroll
-        for (int st = 0; st < S; ++st)
-          *reinterpret_cast<float2*>(&hl[buf][wv][st][lane * 2]) = float2{pre[st][0], pre[st][1]};
-        return;
-      }
-    }
     if (!HASX || kq < KT) {
       f32x4 H[S];
       act_jet_fwd<S1, S2, ACT>(a.cfg, pre, H, cq);
@@ -462,11 +433,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
   // adjoint operand goes to a staging set), so waves 4 .. 7 -- the second wave of every SIMD -- run them the other way
   // round: while one wave of a SIMD issues MFMAs the other one is in its VALU / LDS phase.  Their operand loads are
   // requested one iteration ahead (behind the preparation, in flight during the MFMAs and across the barrier).
-  // STPDE_WGRAD_SWAP=0: every wave in the same order.
   // (compiled for the packed-buffer variants: with fp32 blocks on both sides the second loop body spills)
   constexpr bool SWAPOK = BF && SPL == 1 && NBUF == 2 && !HASX && PKM != 0 && MODE == 1;
   if constexpr (SWAPOK) {
-    if (a.swap && wv >= NW / 2) {
+    if (wv >= NW / 2) {
       auto pack_to = [&](f32x4 (*raw_)[MCW], bf16x8 (*dst)[MCW]) {
         if constexpr (NPP > 2) {
 #pragma unroll
@@ -1272,28 +1242,20 @@ static int try_wgrad_wave(const WgradArgs& a, hipStream_t stream) {
       if (a.KT == 2) return launch_wgrad_wave<S1, S2, ACT, 2, 2>(a, stream);
       if (a.KT == 4) return launch_wgrad_wave<S1, S2, ACT, 2, 4>(a, stream);
       // fc3 of the reference net (4 output tiles, 8 hidden k-tiles): all four output tiles in ONE pass halves the stash reads
-      // of this HBM-bound kernel (the two-pass grid reads abar3 / pre2 twice: 11.4 -> 9.6 ms per step, 368 registers = one wave
-      // per SIMD); STPDE_WGRAD_MCW4=0: two passes
-      static const int quad = getenv("STPDE_WGRAD_QUAD") ? atoi(getenv("STPDE_WGRAD_QUAD")) : 1;
+      // of this HBM-bound kernel (the two-pass grid reads abar3 / pre2 twice: 11.4 -> 9.6 ms per step)
       if constexpr (S1 == 3) {
-        if (a.KT == 8 && a.MT == 4 && quad && XT == 3 && (a.pk == 0 || a.pk == 5)) {
+        if (a.KT == 8 && a.MT == 4 && XT == 3 && (a.pk == 0 || a.pk == 5)) {
           int gx = 768;                        // three workgroups per CU, persistent
           if (gx > a.ntiles) gx = a.ntiles;
-          static const int octbf4 = getenv("STPDE_WGRAD_OCT_BF") ? atoi(getenv("STPDE_WGRAD_OCT_BF")) : 1;
-          if (a.pk && octbf4) {
+          if (a.pk) {                          // bf16 mode, packed buffers: bf16 operand blocks in LDS
             STPDE_LAUNCH((k_wgrad_oct_bf<S1, S2, ACT, 4>), dim3(gx), dim3(256), 0, stream, a);
             return stpde_check_launch("k_wgrad_oct_bf");
           }
-          if (a.pk)
-            STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 3, true>), dim3(gx), dim3(256), 0, stream, a);
-          else
-            STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 0, false>), dim3(gx), dim3(256), 0, stream, a);
+          STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 0, false>), dim3(gx), dim3(256), 0, stream, a);
           return stpde_check_launch("k_wgrad_quad");
         }
       }
-      static const int mcw4 = getenv("STPDE_WGRAD_MCW4") ? atoi(getenv("STPDE_WGRAD_MCW4")) : 1;
-      static const int mcw4_bf = getenv("STPDE_WGRAD_MCW4_BF") ? atoi(getenv("STPDE_WGRAD_MCW4_BF")) : 1;
-      if (a.KT == 8 && a.MT == 4 && (a.pk ? mcw4_bf : mcw4)) return launch_wgrad_wave<S1, S2, ACT, 4, 8>(a, stream);
+      if (a.KT == 8 && a.MT == 4) return launch_wgrad_wave<S1, S2, ACT, 4, 8>(a, stream);
       if (a.KT == 8) return launch_wgrad_wave<S1, S2, ACT, 2, 8>(a, stream);
     }
     return -1;
@@ -1308,22 +1270,18 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
   const int ngr = (a.KT + XT + 7) / 8;      // k-groups (ring = 8 k-tiles)
   const int nhid = a.KT / 8;                // groups made of hidden tiles only
   // fp32, every hidden k-tile in a full group and enough (k-group, k-slot) pairs for the XT raw-input tiles: those are folded
-  // into the hidden-group launch and the second launch is dropped (STPDE_WGRAD_XFOLD=0: two launches)
-  static const int xfold_env = getenv("STPDE_WGRAD_XFOLD") ? atoi(getenv("STPDE_WGRAD_XFOLD")) : 1;
+  // into the hidden-group launch and the second launch is dropped
   const int kslots = 8 / KC;                 // k-slots per workgroup (NW / NM)
   // "fp32x3" (a.bf16 == 3) is a contract on ACCURACY (fp32), not on the pipe: stream sets / widths its split kernels are not
   // compiled for take the exact-fp32 kernels (round 4; they used to be refused)
   constexpr bool SPLIT_OK = KC >= 4 && S1 + S2 <= 4;
   const int bfm = (a.bf16 == 3 && !SPLIT_OK) ? 0 : a.bf16;
-  static const int x3fold_env = getenv("STPDE_X3_XFOLD") ? atoi(getenv("STPDE_X3_XFOLD")) : 1;
-  const bool xfold = xfold_env && !a.xonly && (!bfm || (bfm == 1 && KC >= 4) || (bfm == 3 && KC >= 4 && STPDE_X3_XFOLD && x3fold_env)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.X;
-  static const int swap_env = getenv("STPDE_WGRAD_SWAP") ? atoi(getenv("STPDE_WGRAD_SWAP")) : 1;
-  a.swap = swap_env;
+  const bool xfold = (!bfm || (bfm == 1 && KC >= 4) || (bfm == 3 && KC >= 4 && STPDE_X3_XFOLD)) && a.KT > 0 && a.KT % 8 == 0 && nhid * kslots >= XT && a.X;
   for (int part = 0; part < 2; ++part) {
     a.kz0 = part == 0 ? 0 : nhid;
     a.gz = part == 0 ? nhid : ngr - nhid;
     a.xfold = (xfold && part == 0) ? 1 : 0;
-    if (a.gz <= 0 || (xfold && part == 1) || (a.xonly && part == 0)) continue;
+    if (a.gz <= 0 || (xfold && part == 1)) continue;
     int gx = 512 / (a.gy * a.gz);           // ~2 rounds of one 8-wave workgroup per CU
     if (gx > a.ntiles) gx = a.ntiles;
     gx = (gx + 7) / 8 * 8;
@@ -1345,11 +1303,7 @@ static int launch_wgrad_kc(const WgradArgs& a0, hipStream_t stream) {
           stpde_set_error("packed layer buffers: combination %d not compiled for this weight-gradient kind", a.pk);
           return STPDE_E_UNSUPPORTED;
         }
-        static const int hq_env = getenv("STPDE_WGRAD_H16") ? atoi(getenv("STPDE_WGRAD_H16")) : 1;
-        if (part == 0 && a.pk && a.H16 && hq_env && MODE == 1 && KC == 8)
-          STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 1, (MODE == 1 && KC == 8) ? (PKA | 8) : PKA>), grid,
-                       dim3(512), 0, stream, a);
-        else if (part == 0 && a.pk)
+        if (part == 0 && a.pk)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true, 1, PKA>), grid, dim3(512), 0, stream, a);
         else if (part == 0)
           STPDE_LAUNCH((k_wgrad_coop<S1, S2, MODE, ACT, KC, false, true>), grid, dim3(512), 0, stream, a);
@@ -1388,25 +1342,18 @@ static int launch_wgrad_act(const WgradArgs& a, hipStream_t stream) {
     if (rc >= 0) return rc;
     // second hidden layer of the reference width: eight waves on one row tile (k_wgrad_quad<..., 8>); exact-fp32 operands, or
     // bf16 operands with packed buffers (the three-term split mode keeps the ring kernel)
-    static const int oct = getenv("STPDE_WGRAD_OCT") ? atoi(getenv("STPDE_WGRAD_OCT")) : 1;
     if constexpr (S1 == 3 && S1 + S2 <= 5) {
       // "fp32x3" (a.bf16 == 3, round 5): the exact-fp32 eight-wave kernel as well -- 25.7 ms per 2^20 points against 26.0 + 8.0
       // for the split ring kernel and its separate raw-input launch; the mode is a contract on accuracy, not on the pipe
-      // (STPDE_X3_FC2_QUAD=0: the split kernels)
-      static const int x3quad = getenv("STPDE_X3_FC2_QUAD") ? atoi(getenv("STPDE_X3_FC2_QUAD")) : 1;
-      if (oct && a.KT == 16 && a.MT == 8 && XT == 3 && a.SP == 1 + S1 + S2 && a.X &&
-          ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5) || (a.bf16 == 3 && a.pk == 0 && x3quad))) {
+      if (a.KT == 16 && a.MT == 8 && XT == 3 && a.SP == 1 + S1 + S2 && a.X &&
+          ((a.bf16 == 0 && a.pk == 0) || (a.bf16 == 1 && a.pk == 5) || (a.bf16 == 3 && a.pk == 0))) {
         int gx = 256;                          // one workgroup per CU, persistent
         if (gx > a.ntiles) gx = a.ntiles;
-        static const int octbf = getenv("STPDE_WGRAD_OCT_BF") ? atoi(getenv("STPDE_WGRAD_OCT_BF")) : 1;
-        if (a.pk && octbf) {
+        if (a.pk) {                            // bf16 mode, packed buffers: bf16 operand blocks in LDS
           STPDE_LAUNCH((k_wgrad_oct_bf<S1, S2, ACT>), dim3(gx), dim3(512), 0, stream, a);
           return stpde_check_launch("k_wgrad_oct_bf");
         }
-        if (a.pk)
-          STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 3, true, 8>), dim3(gx), dim3(512), 0, stream, a);
-        else
-          STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 0, false, 8>), dim3(gx), dim3(512), 0, stream, a);
+        STPDE_LAUNCH((k_wgrad_quad<S1, S2, ACT, 0, false, 8>), dim3(gx), dim3(512), 0, stream, a);
         return stpde_check_launch("k_wgrad_quad");
       }
     }

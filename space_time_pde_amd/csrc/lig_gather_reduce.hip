@@ -252,8 +252,7 @@ extern "C" int stpde_lig_gather(const stpde_gather_desc* d, const float* pts, co
     return STPDE_E_BADARG;
   }
   GatherArgs a{*d, pts, latent, X, XR, coef, cell, cw};
-  static const int tile_env = getenv("STPDE_GATHER_TILE") ? atoi(getenv("STPDE_GATHER_TILE")) : 1;
-  if (d->C == 32 && tile_env) {       // the reference's latent width: one wave per row tile, 16-byte loads and stores
+  if (d->C == 32) {       // the reference's latent width: one wave per row tile, 16-byte loads and stores
     STPDE_LAUNCH(k_gather_tile, dim3((unsigned)((d->P / 2 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return stpde_check_launch("k_gather_tile");
   }

@@ -147,7 +147,6 @@ extern "C" int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* p, const stpde_je
     const void* w16 = p->mfma_bf16 ? p->Wh16[l] : nullptr;
     stpde_layer_desc d = layer_desc(lnt, p, l, lcfg, w16 ? p->mfma_bf16 : 0);
     d.packed = packed_flags(p, l, l) & 3;
-    d.act16 = (p->mfma_bf16 == 1 && l <= 2 && (flags & STPDE_F_STASH)) ? ws->act16[l - 1] : nullptr;
     seq([&] {
       return stpde_jet_layer_fwd(&d, prev, ws->X, p->Wh[l], p->Ws[l], p->tanc[l], p->Ws[0], p->tanc[0], ws->pre[l], ws->cw, w16,
                                  (l == 1 && stash) ? ws->pre[0] : nullptr, stream);
@@ -209,7 +208,6 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     // same operand mode as the layer kernels; only the wide layers (MT >= 8) have bf16-pipe weight-gradient kernels
     stpde_layer_desc dwg = layer_desc(nt, p, l, cfg, (w16 && p->MT[l] >= 8 && (p->mfma_bf16 == 1 || !(flags & STPDE_F_WGRAD_FP32))) ? p->mfma_bf16 : 0);
     dwg.packed = packed_flags(p, l, -1) & 5;
-    dwg.act16 = (p->mfma_bf16 == 1 && l <= 2) ? ws->act16[l - 1] : nullptr;
     seq([&] {
       return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->X, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
                              stream);
@@ -256,12 +254,16 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     });
   };
   // bf16 mode, reference width: weight gradient + input gradient of the first hidden layer in one kernel (jet_fc1_bwd.hip)
-  auto fc1_fused_ok = [&]() -> bool {
-    if (!wgrad || !split0) return false;
+  // Decided ONCE per call, from the plan and the flags only (it used to be re-evaluated, with a getenv, at every use;
+  // phase B skips fc1's weight gradient exactly when phase A's fused kernel produced it, so both phases of a dgrad-first
+  // backward MUST be called with the same flags apart from the phase bits -- STPDE_F_WGRAD and STPDE_F_NO_FC1_FUSED included)
+  const bool fc1_fused_on = [&]() -> bool {
+    if (!wgrad || !split0 || (flags & STPDE_F_NO_FC1_FUSED)) return false;
     stpde_layer_desc d = layer_desc(nt, p, 1, cfg, p->mfma_bf16 ? p->mfma_bf16 : 0);
     d.packed = packed_flags(p, 1, 0);
     return p->WhT16[1] && stpde_jet_fc1_bwd_supported(&d) != 0 && abar0 != z0;
-  };
+  }();
+  auto fc1_fused_ok = [&]() -> bool { return fc1_fused_on; };
   auto fc1_fused = [&] {
     stpde_layer_desc d = layer_desc(nt, p, 1, cfg, p->mfma_bf16);
     d.packed = packed_flags(p, 1, 0);

@@ -351,31 +351,6 @@ def _buf_floats(meta, l, nt):
     return nt * meta.S * mt * _FRAG
 
 
-# bf16 mode: layers whose forward keeps its activated input as bf16 operand blocks for the weight gradient (act16 of
-# include/stpde_hip.h).
-# Measured (round 4, profiles/r4_act16_swap_ab.txt): the weight gradient of the first hidden layer gains 3 ms (26.2 -> 23.3 per
-# step), the forward that writes the blocks loses 4 (21.9 -> 25.9: 80 KB more stores per row tile), 40 GB more stash -- the
-# kernel is bound by its dependent chains, not by the jets' instruction count.  Kept as an opt-in (STPDE_ACT16=1), off by default.
-_act16_env = os.environ.get("STPDE_ACT16", "0") == "1"
-
-
-def _act16_layers(meta, l):
-    """True when layer l's forward keeps its operand blocks: the kernels that write them (csrc/jet_spec_bf16.h: the
-    wave-specialised forward of the first hidden layer) and read them (k_wgrad_coop with PKM bit 8) exist for the plain
-    bf16 mode with packed buffers, S1 = 3, S2 <= 2 and the reference width only."""
-    lay = meta.plan.layers[l]
-    return bool(_act16_env and l in ACT16_LAYERS and meta.packed_mask == 31 and meta.packs16 is not None and meta.nsplit == 1
-                and meta.cfg.S1 == 3 and meta.cfg.S2 <= 2 and lay["MT"] == 16 and lay["KT"] in (16, 32)
-                and os.environ.get("STPDE_BF_SPEC", "1") != "0")
-
-
-ACT16_LAYERS = (1,)
-
-
-def _act16_bytes(meta, l, nt):
-    return nt * meta.plan.layers[l]["KT"] * meta.S * 512
-
-
 def _adj_floats(meta, l, nt):
     """floats of the adjoint buffer of layer l's output rows: the size of the layer buffer, or -- packed mode -- a packed
     ADJOINT buffer, every stream bf16 (layer 0: its value stream only)."""
@@ -394,9 +369,9 @@ def _pk(meta, l, writes):
 
 # ------------------------------------------------------------------------------------------------------------
 # one C call per direction (include/stpde_hip.h: stpde_lig_imnet_jet_fwd / _bwd); the per-kernel functions below stay as
-# the profiling path (bench.py's per-kernel event timings) and are what ``STPDE_PIPELINE=0`` selects
+# the profiling path (bench.py's per-kernel event timings) and are what ``use_pipeline = False`` selects (tests)
 # ------------------------------------------------------------------------------------------------------------
-use_pipeline = os.environ.get("STPDE_PIPELINE", "1") != "0"
+use_pipeline = True
 
 
 def _dp(t):
@@ -449,6 +424,8 @@ def _flags(meta, need_grad):
         f |= _lib.F_WGRAD
     if not wgrad_split:
         f |= _lib.F_WGRAD_FP32
+    if not fc1_fused_enabled():
+        f |= _lib.F_NO_FC1_FUSED
     return f
 
 
@@ -467,11 +444,6 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     s["cell"] = torch.empty(Pc, device=dev, dtype=torch.int32)
     s["bufs"] = [None] + [torch.empty(_buf_floats(meta, l, nt), device=dev) for l in range(1, 6)]
     s["z0"] = torch.empty(nt * plan.layers[0]["MT"] * _FRAG, device=dev) if need_grad else None
-    # bf16 mode: the activated inputs of fc1 / fc2 as the bf16 operand blocks their forward passes produce anyway
-    # (stpde_layer_desc.act16) -- the weight gradients read these instead of evaluating the activation jets again
-    s["act16"] = [torch.empty(_act16_bytes(meta, l, nt), device=dev, dtype=torch.uint8) if (need_grad and _act16_layers(meta, l))
-                  else None for l in (1, 2)]
-    ws.act16[0], ws.act16[1] = _dp(s["act16"][0]), _dp(s["act16"][1])
     ws.X, ws.XR, ws.coef, ws.cw, ws.cell = (_dp(s[k]) for k in ("X", "XR", "coef", "cw", "cell"))
     ws.pre[0] = _dp(s["z0"])
     for l in range(1, 6):
@@ -485,16 +457,14 @@ def _forward_chunk_c(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return s
 
 
-def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None, side_stream=None):
+def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None):
     """_backward_chunk through ONE library call (+ allocation of its scratch).
 
     after_dlatent (callable or None): "dgrad-first" order in TWO calls -- phase A runs the whole input-gradient chain into
     fresh adjoint buffers and finishes d latent, after_dlatent() is called (the point-sharded step starts the all-reduce of
-    d latent there), phase B computes the remaining weight gradients while that all-reduce is in flight.
-    side_stream: phase B is launched on THAT stream (after an event behind phase A) instead of the current one, so that
-    whatever the caller queues on the current stream next -- the U-Net backward -- runs beside the weight gradients.  Returns
-    the scratch tensors phase B works on (the caller keeps them alive until it has joined the streams), or None when phase B
-    ran on the current stream."""
+    d latent there), phase B computes the remaining weight gradients while that all-reduce is in flight.  (Both phases on the
+    current stream.  Round 4's variant with phase B on a side stream, so that the U-Net backward ran beside it, measured slower
+    -- profiles/r4_overlap_timeline.txt -- and was deleted in round 6.)"""
     plan, S = meta.plan, meta.S
     Pc, ws, gd = saved["Pc"], saved["ws"], saved["gd"]
     nt = Pc // 2
@@ -539,11 +509,6 @@ def _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None,
             ws.abar0x = buf(nt * MT0 * _FRAG)
         call(flags | _lib.F_PHASE_A)
         after_dlatent()
-        if side_stream is not None and meta.need_wgrad:
-            side_stream.wait_event(torch.cuda.current_stream().record_event())
-            with torch.cuda.stream(side_stream):
-                call(flags | _lib.F_PHASE_B)
-            return keep
         call(flags | _lib.F_PHASE_B)
     else:
         call(flags)
@@ -628,11 +593,11 @@ def _forward_chunk(meta, packs, latent, pts_c, jets, p0, need_grad=True):
     return dict(X=X, XR=X, coef=coef, cell=cell, bufs=bufs, p0=p0, Pc=Pc, cw=cw, z0=z0)
 
 
-def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None, side_stream=None):
+def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, after_dlatent=None):
     """reduce_bwd -> for l = 5..1: wgrad_l (reads abar_l and the still intact pre-activations of layer l-1), then
     dgrad_l (overwrites them with abar_{l-1}) -> wgrad_0 -> xbar/scatter."""
     if "ws" in saved:
-        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar, after_dlatent, side_stream)
+        return _backward_chunk_c(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar, after_dlatent)
     plan, cfg, S = meta.plan, meta.cfg, meta.S
     L = _lib.lib()
     st = stream_ptr()
@@ -669,14 +634,14 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
         lay = plan.layers[l]
         w16 = meta.packs16.get((l, "WhT")) if meta.packs16 else None
         d = _layer_desc(nt, lay, cfg, l == 1, meta.nsplit if w16 is not None else 0, _pk(meta, l, l - 1))
-        # weight gradient: same operand mode as the layer kernels (STPDE_WGRAD_SPLIT=0 keeps it on exact-fp32 MFMA in
+        # weight gradient: same operand mode as the layer kernels (``wgrad_split = False`` keeps it on exact-fp32 MFMA in
         # "fp32x3" mode, for A/B timing); only the wide layers, MT >= 8, have bf16-pipe weight-gradient kernels --
         # flagging a narrow layer would take it off its per-wave kernel
         dwg = _layer_desc(nt, lay, cfg, l == 1, (meta.nsplit if wgrad_split or meta.nsplit == 1 else 0)
                           if (w16 is not None and lay["MT"] >= 8) else 0, _pk(meta, l, -1) & 5)
         off, mp, ka = plan.dw_off[l]
         if (l == 1 and meta.need_wgrad and split0 and w16 is not None and abar0 is not z0
-                and L.stpde_jet_fc1_bwd_supported(C.byref(d))):
+                and fc1_fused_enabled() and L.stpde_jet_fc1_bwd_supported(C.byref(d))):
             # bf16 mode, reference width (round 5): weight gradient + input gradient of the first hidden layer in ONE kernel
             # (csrc/jet_fc1_bwd.hip: one read of the adjoint tile, one activation-jet evaluation per z0 element)
             with _timed("layer1_bwd"):
@@ -760,12 +725,8 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
     return None
 
 
-# {"dlatent": f(tensor) -> work | None, "dw": f(tensor) -> work | None, "defer_wgrad": bool}: collectives of the point-sharded
-# step, started from inside the backward (set / cleared by train_step.sharded_step; the first LigJetFunction.backward of the
-# step consumes them).  "defer_wgrad": the weight gradients of the LAST chunk (phase B of the dgrad-first order) run on a side
-# stream and the IM-NET ``.grad`` are assigned by a callback when the whole backward pass is over, so that the U-Net backward
-# -- a chain of short launches that leaves most of the chip idle -- runs BESIDE them instead of after them.  Only
-# ``loss.backward()`` sees gradients delivered that way (not ``torch.autograd.grad``): opt-in, set by sharded_step.
+# {"dlatent": f(tensor) -> work | None, "dw": f(tensor) -> work | None}: collectives of the point-sharded step, started from
+# inside the backward (set / cleared by train_step.sharded_step; the first LigJetFunction.backward of the step consumes them).
 sync_hooks = None
 
 # True while train_step.sharded_step runs the FORWARD of a step whose backward will install ``sync_hooks`` (the hooks themselves
@@ -774,30 +735,9 @@ sync_hooks = None
 # step near the limit failed with an out-of-memory error in the backward instead of shrinking its chunks).
 expect_two_phase = False
 
-# Points of the LAST launch chunk of a differentiable call (0 = no separate tail).  With "defer_wgrad" the weight gradients
-# of that chunk are what the U-Net backward runs beside: 2^17 points = ~18 ms of weight-gradient kernels in exact fp32
-# against ~6 ms of U-Net backward, for +7 GB of dgrad-first adjoint buffers (a whole 2^20-point chunk would take +58 GB).
-tail_chunk = 0
-
-_wgrad_streams = {}
-
-
-def _wgrad_stream(device):
-    key = (device.type, device.index)
-    if key not in _wgrad_streams:
-        _wgrad_streams[key] = torch.cuda.Stream(device=device)
-    return _wgrad_streams[key]
-
-
 def _chunk_ranges(meta, P):
-    """[(first point, points)] of the launch chunks: ``meta.chunk`` points each, plus -- for a call with ``meta.tail`` -- a
-    separate last chunk of that many points."""
-    tail = meta.tail if (meta.tail and P >= 2 * meta.tail and meta.tail < meta.chunk) else 0
-    body = P - tail
-    out = [(p0, min(meta.chunk, body - p0)) for p0 in range(0, body, meta.chunk)]
-    if tail:
-        out.append((body, tail))
-    return out
+    """[(first point, points)] of the launch chunks: ``meta.chunk`` points each."""
+    return [(p0, min(meta.chunk, P - p0)) for p0 in range(0, P, meta.chunk)]
 
 stats = {"recompute_steps": 0}     # calls whose backward rebuilt the stash chunk by chunk (memory plan below)
 
@@ -817,7 +757,6 @@ def _per_point_bytes(meta):
     mt0 = plan.layers[0]["MT"]
     cp = (plan.cin + 3) // 4 * 4
     fwd_tile = 4 * (sum(_buf_floats(meta, l, 1) for l in range(1, 6)) + mt0 * _FRAG + XT * _FRAG)
-    fwd_tile += sum(_act16_bytes(meta, l, 1) for l in (1, 2) if _act16_layers(meta, l))
     fwd = fwd_tile // 2 + 4 * 16 + (4 * 8 if meta.cfg_out.combo else 0) + 4
     bwd_tile = 4 * (_adj_floats(meta, 2, 1) + _adj_floats(meta, 3, 1) + mt0 * 48)
     if meta.packed_mask:
@@ -914,8 +853,6 @@ class LigJetFunction(torch.autograd.Function):
             chunk = meta.chunk = min(chunk, _recompute_chunk(meta, pts.device))
         saved = []
         oom = False
-        if not need_grad:
-            meta.tail = 0
         try:
             for p0, n in _chunk_ranges(meta, P):
                 s = _forward_chunk(meta, packs, latent, pts[p0:p0 + n], jets, p0, need_grad and not recompute)
@@ -971,14 +908,12 @@ class LigJetFunction(torch.autograd.Function):
         # the IM-NET gradients are all-reduced in place in their flat buffer before they are unpacked.
         hooks = sync_hooks if (sync_hooks and not sync_hooks.get("used")) else None
         works = []
-        side = _wgrad_stream(dev) if (hooks and hooks.get("defer_wgrad") and meta.need_wgrad) else None
 
         def start_dlatent_sync():
             if hooks and need_lat and hooks.get("dlatent"):
                 works.append(hooks["dlatent"](dlatent))
                 hooks["dlatent_done"] = dlatent      # WHICH tensor is summed over ranks (train_step._SumGradAcrossRanks)
 
-        held = None        # scratch of a phase B that runs on the side stream
         if rebuild:
             latent, pts = ctx.inputs
             scratch = torch.empty(meta.S_out, meta.plan.cout, pts.shape[0], device=pts.device)
@@ -986,50 +921,18 @@ class LigJetFunction(torch.autograd.Function):
             for p0, n in ranges:
                 last = hooks and p0 == ranges[-1][0]
                 s = _forward_chunk(meta, ctx.packs, latent, pts[p0:p0 + n], scratch, p0, True)
-                held = _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
-                                       start_dlatent_sync if last else None, side if last else None)
-                if held is not None:
-                    held.append(s)
+                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar, start_dlatent_sync if last else None)
                 s = None
         else:
             for k, s in enumerate(ctx.saved):
                 last = hooks and k == len(ctx.saved) - 1
-                held = _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar,
-                                       start_dlatent_sync if last else None, side if last else None)
-                if held is not None:
-                    held.append(dict(s))             # the stash phase B still reads
+                _backward_chunk(meta, ctx.packs, s, jets_bar, dw_flat, dlatent, pbar, start_dlatent_sync if last else None)
                 s["bufs"] = s["z0"] = None  # release the stash chunk by chunk
         ctx.saved = []
         grads = [None] * ctx.n_params
-        deferred = held is not None
         if hooks:
             hooks["used"] = True
-        if deferred:
-            # the weight gradients of the last chunk are still running on the side stream: the collective on the flat IM-NET
-            # gradient and its unpacking follow them THERE; ``.grad`` is assigned when the whole backward pass is over
-            with torch.cuda.stream(side):
-                if hooks.get("dw"):
-                    wk = hooks["dw"](dw_flat)
-                    if wk is not None:
-                        wk.wait()                    # (a stream-level wait: the side stream waits for the collective)
-                    hooks["dw_done"] = True
-                g = meta.plan.unpack_grads(dw_flat, ctx.params)
-            done = side.record_event()
-            held += [dw_flat, ctx.packs]
-            params, needs = ctx.params, ctx.needs_input_grad[4:]
-
-            def assign_grads():
-                with torch.cuda.device(dev):
-                    torch.cuda.current_stream().wait_event(done)
-                for p, gi, need in zip(params, g, needs):
-                    if need:
-                        p.grad = gi if p.grad is None else p.grad + gi
-                held.clear()     # operands of the side-stream kernels: free for reuse on the main stream from here on
-
-            torch.autograd.Variable._execution_engine.queue_callback(assign_grads)
-            if pbar is not None and hooks.get("dw"):
-                works.append(hooks["dw"](pbar))
-        elif hooks and meta.need_wgrad and hooks.get("dw"):
+        if hooks and meta.need_wgrad and hooks.get("dw"):
             works.append(hooks["dw"](dw_flat))
             if pbar is not None:                      # adjoint of the learnable swish beta: same treatment
                 works.append(hooks["dw"](pbar))
@@ -1037,7 +940,7 @@ class LigJetFunction(torch.autograd.Function):
         for wk in works:
             if wk is not None:
                 wk.wait()
-        if meta.need_wgrad and not deferred:
+        if meta.need_wgrad:
             g = meta.plan.unpack_grads(dw_flat, ctx.params)
             grads = [gi if need else None for gi, need in zip(g, ctx.needs_input_grad[4:])]
         dprm = pbar.sum().reshape(ctx.prm_shape) if pbar is not None else None
@@ -1064,21 +967,30 @@ def activation_name(module):
     return None
 
 
-# d latent: per-node gather in a fixed order (bit-reproducible, like the reference's CPU index_put_ accumulate) instead of
-# fp32 atomics.  STPDE_DLATENT_ATOMIC=1 selects the atomic scatter (kept for A/B timing).
-deterministic_dlatent = os.environ.get("STPDE_DLATENT_ATOMIC", "0") != "1"
-# forward-only value queries use the value-tile kernels (4 row tiles per weight pass); STPDE_VALUE_TILES=0 = one tile
-value_tiles = os.environ.get("STPDE_VALUE_TILES", "1") != "0"
-# layer-0 tangent-stream adjoints as per-tile row sums (STPDE_TAN0_ROWSUM=0: full fragment blocks, for A/B timing)
-tan0_rowsum = os.environ.get("STPDE_TAN0_ROWSUM", "1") != "0"
-wgrad_split = os.environ.get("STPDE_WGRAD_SPLIT", "1") != "0"
-packed_stash = os.environ.get("STPDE_PACKED_STASH", "1") != "0"
-# forward of fc3 -> fc4 -> fc5 in one kernel (STPDE_FUSED_TAIL=0: three per-layer kernels)
-fused_tail = os.environ.get("STPDE_FUSED_TAIL", "1") != "0"
+# Module-level settings (plain attributes: tests set them with monkeypatch; none of them is read from the environment since
+# round 6 -- the environment selects only the operand mode, the memory budget and the A/B switch of the fused fc1 backward).
+# d latent: per-node gather in a fixed order (bit-reproducible, like the reference's CPU index_put_ accumulate); False = the
+# fp32-atomic scatter.
+deterministic_dlatent = True
+# forward-only value queries use the value-tile kernels (4 row tiles per weight pass); False = one tile per pass
+value_tiles = True
+# layer-0 tangent-stream adjoints as per-tile row sums (False: full fragment blocks)
+tan0_rowsum = True
+wgrad_split = True
+packed_stash = True
+# forward of fc3 -> fc4 -> fc5 in one kernel (False: three per-layer kernels)
+fused_tail = True
 
-# STPDE_RECOMPUTE=1 (or ``force_recompute = True``): never keep the stash, always rebuild it in the backward (tests; also
-# what the memory plan of LigJetFunction.forward switches to on its own when the stash does not fit)
-force_recompute = os.environ.get("STPDE_RECOMPUTE", "0") == "1"
+# ``force_recompute = True``: never keep the stash, always rebuild it in the backward (tests; also what the memory plan of
+# LigJetFunction.forward switches to on its own when the stash does not fit)
+force_recompute = False
+
+
+def fc1_fused_enabled():
+    """bf16 mode: the fused backward of the first hidden layer (csrc/jet_fc1_bwd.hip) is used where the library serves it.
+    STPDE_FC1_FUSED=0 (read per call: tests switch it inside one process) runs the input gradient and the weight gradient of
+    that layer as two kernels -- the A/B reference of tests/test_gpu_bf16_kernel_variants.py."""
+    return os.environ.get("STPDE_FC1_FUSED", "1") != "0"
 
 DEFAULT_CHUNK = 1 << 20   # query points per launch chunk (per-chunk backward scratch: ~50 GB at 2^20; measured on
                           # MI355X: 2^17 / 2^18 / 2^19 / 2^20 points per chunk -> 459.8 / 458.7 / 455.5 / 454.3 ms per step)
@@ -1163,7 +1075,6 @@ def lig_jets(imnet, latent_grid, query_pts, xmin, xmax, first=True, pairs=(), ch
     meta.need_wgrad = True
     meta.recompute = force_recompute
     meta.budget = memory_budget if memory_budget is not None else globals()["memory_budget"]
-    meta.tail = int(tail_chunk) // 2 * 2
     meta.cfg_val = make_cfg(act, prm, False, [])[0]
     P = B * N
     if P == 0:   # empty query set: nothing to launch (the reference returns an empty [b, 0, o] tensor as well)

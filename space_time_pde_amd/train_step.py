@@ -130,27 +130,14 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
     if distributed:
         latent_grid = _SumGradAcrossRanks.apply(latent_grid)
     pde_layer.update_forward_method(lambda pts: query_local_implicit_grid(imnet, latent_grid, pts, xmin, xmax))
-    # U-Net backward BESIDE the IM-NET weight gradients (lig_jet.sync_hooks["defer_wgrad"]): the last launch chunk of the
-    # query -- ``tail_chunk`` points -- runs its input-gradient chain first and its weight gradients on a side stream.
-    # OFF by default (STPDE_OVERLAP_UNET_BWD=1 turns it on): measured on MI355X (round 4, profiles/r4_overlap_timeline.txt) the
-    # two streams do run side by side, but the first / second hidden layer's weight-gradient kernels hold every VGPR of every
-    # CU (254 registers x 8 waves, 147 KB of LDS), so a U-Net kernel dispatched beside them waits for a whole workgroup to
-    # retire (a 15 us convolution took 6.1 ms) and the chain of ~350 short launches advances by three kernels per heavy
-    # kernel: 63.1 -> 63.7 ms per step at 2^17 points, 422.2 -> 424.7 ms at 2^20 (the dgrad-first order and the extra
-    # launch chunk cost more than the overlap of the light kernels gains).
-    overlap_unet = latent_grid.is_cuda and os.environ.get("STPDE_OVERLAP_UNET_BWD", "0") == "1"
-    prev_tail = lig_jet.tail_chunk
-    if overlap_unet:
-        lig_jet.tail_chunk = int(os.environ.get("STPDE_TAIL_CHUNK", 1 << 17))
     # collectives issued from inside the HIP backward: d latent asynchronously behind the IM-NET weight gradients, the
     # IM-NET gradients in place in their flat buffer (no cat / copy-back); both are waited for before backward returns
     overlap_sync = distributed and os.environ.get("STPDE_OVERLAP_SYNC", "1") != "0"
     # (the forward's memory plan must know NOW that the backward will take the dgrad-first two-phase order)
-    lig_jet.expect_two_phase = bool(overlap_sync or overlap_unet)
+    lig_jet.expect_two_phase = bool(overlap_sync)
     try:
         pred, residues = pde_layer(point_coord, return_residue=True)    # train.py:66-67
     finally:
-        lig_jet.tail_chunk = prev_tail
         lig_jet.expect_two_phase = False
     b = point_coord.shape[0]
     reg = loss_sum(pred, point_value, loss_type) / (b * n_points_global * pred.shape[-1])
@@ -172,8 +159,6 @@ def _sharded_step(unet, imnet, pde_layer, input_grid, point_coord, point_value, 
     if overlap_sync:
         hooks.update(dlatent=_all_reduce_async("d(loss)/d(latent grid), from inside the HIP backward"),
                      dw=_all_reduce_async("IM-NET gradients (flat dW buffer, in place)"))
-    if overlap_unet:
-        hooks["defer_wgrad"] = True
     hooks = hooks or None
     lig_jet.sync_hooks = hooks
     try:
@@ -268,6 +253,10 @@ class GraphedStep:
 
         # lazy initialisation (kernel modules, function attributes, cached index tables, sympy lambdas) must not happen inside
         # the capture: a few eager steps on a side stream first (torch's recipe for whole-network capture)
+        # (the AccumulateGrad nodes of the parameters were created on whatever stream ran their first eager step; the warm-up /
+        # capture streams differ from it by design -- torch's warning about that is not an error here)
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=input_grid.device)
         side.wait_stream(cur)

@@ -222,8 +222,8 @@ def test_mask_and_batchnorm_backward_sums_epilogue(hiplib, shape, k, c):
 def test_conv3_from_lds_halo_tiles_equals_the_per_wave_kernel(hiplib, monkeypatch, c, epi):
     """k_conv3_lds (csrc/conv3d_fused.hip, round 5): the square 3x3x3 convolutions of the wide levels from LDS halo tiles,
     on a batch of TWO samples (a block's halo must stop at the sample boundary and at every face of the volume) with more
-    blocks than workgroups (2 x 8 x 32 x 64 voxels = 128 .. 512 blocks on STPDE_CONV3_LDS_GX = 24 persistent workgroups: 5 - 22
-    blocks each through the register-pipelined staging; MINBLK = 1 puts the kernel on this small volume).  Same MFMA order per output element as k_conv_fused: the outputs must be bit-identical;
+    blocks than workgroups (2 x 8 x 32 x 64 voxels = 128 .. 512 blocks on 24 persistent workgroups -- stpde_tune "conv3_lds_gx" --
+    5 - 22 blocks each through the register-pipelined staging; "conv3_lds_minblk" = 1 puts the kernel on this small volume).  Same MFMA order per output element as k_conv_fused: the outputs must be bit-identical;
     the epilogue sums (fp64 per wave over its blocks, one set of atomics per workgroup) against torch fp64."""
     dev = torch.device("cuda:0")
     torch.manual_seed(40 + c)
@@ -238,9 +238,8 @@ def test_conv3_from_lds_halo_tiles_equals_the_per_wave_kernel(hiplib, monkeypatc
     fp = _packs(w, dev)[0]
     out = {}
     for lds in ("1", "0"):
-        monkeypatch.setenv("STPDE_CONV3_LDS", lds)
-        monkeypatch.setenv("STPDE_CONV3_LDS_MINBLK", "1")
-        monkeypatch.setenv("STPDE_CONV3_LDS_GX", "24")
+        tuned = _lib.tuned(conv3_lds_off=int(lds == "0"), conv3_lds_minblk=1, conv3_lds_gx=24)
+        tuned.__enter__()
         y = torch.full((*shape, c), float("nan"), device=dev)
         sums = torch.zeros(R * 2 * c, device=dev, dtype=torch.float64)
         bsum = torch.zeros(R * 2 * c, device=dev)
@@ -256,6 +255,7 @@ def test_conv3_from_lds_halo_tiles_equals_the_per_wave_kernel(hiplib, monkeypatc
         with _lib.dispatch_trace() as tr:
             _lib.check(hiplib.stpde_conv3d_fused(C.byref(a), C.byref(done), _lib.stream_ptr()))
             torch.cuda.synchronize()
+        tuned.__exit__(None, None, None)
         assert done.value == 1
         assert tr.has("k_conv3_lds<%d, %d>" % (c // 16, ("plain", "stats", "mask").index(epi))) == (lds == "1"), "\n".join(tr.kernels)
         assert tr.has("k_conv_fused<") == (lds == "0"), "\n".join(tr.kernels)

@@ -124,18 +124,18 @@ def _assert_mode_kernels(tr, prec):
 def _assert_bf16_kernels(tr, cfg, dump):
     # first hidden layer forward: the wave-specialised persistent kernel (csrc/jet_spec_bf16.h)
     assert tr.has("k_fc1_fwd_spec", cfg), dump
-    # second hidden layer: forward on the persistent LDS-DMA kernel (round 5; STPDE_FC2_FWD_SPEC=0: the cooperative kernel),
-    # input gradient on the cooperative kernel
+    # second hidden layer: forward on the persistent LDS-DMA kernel (round 5; the cooperative kernel for the stream sets it is not
+    # compiled for), input gradient on the cooperative kernel
     assert tr.has("k_fc2_fwd_bf", cfg) or tr.has("k_layer_coop", "true", cfg, "PRO = 1", "EPI = 0"), dump
     assert tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 1"), dump
     if tr.has("k_fc1_bwd_fused"):
         # round 5 (default): input gradient + weight gradient of the first hidden layer in ONE kernel (csrc/jet_fc1_bwd.hip);
         # neither of the two kernels it replaces is launched
-        assert not tr.has("k_fc1_dgrad_spec") and not tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1"), dump
+        assert not tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1"), dump
     else:
-        # STPDE_FC1_FUSED=0: k_fc1_dgrad_spec (round 4; the cooperative kernel with STPDE_BF_SPEC_DGRAD=0) + the ring kernel
-        # with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
-        assert tr.has("k_fc1_dgrad_spec", cfg) or tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 2"), dump
+        # STPDE_FC1_FUSED=0 (or a stream set the fused kernel does not serve): the cooperative input-gradient kernel + the ring
+        # kernel with the raw-input k-tiles folded into the hidden-group launch (no HASX = true launch)
+        assert tr.has("k_layer_coop", "true", cfg, "PRO = 0", "EPI = 2"), dump
         assert tr.has("k_wgrad_coop", "KC, false, true", cfg, "MODE = 1", "KC = 8"), dump
         assert not tr.has("k_wgrad_coop", "KC, true, true", cfg), dump
     assert tr.has("k_wgrad_oct_bf", "ACT>)", cfg), dump       # layer 2: eight waves on one row tile, bf16 blocks in LDS (round 4)

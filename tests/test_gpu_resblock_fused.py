@@ -169,11 +169,12 @@ def test_unet_with_fused_blocks_equals_layerwise_unet(hiplib):
 
 
 def test_lds_weight_gradient_grid_override(hiplib):
-    """STPDE_CONV_WGRAD_LDS_GX (read once per process) only changes how the persistent workgroups share the voxel blocks:
-    same weight gradient as the default grid and as torch."""
+    """stpde_tune "conv_wgrad_lds_gx" only changes how the persistent workgroups share the voxel blocks: same weight gradient
+    as the default grid and as torch."""
     code = r'''
 import ctypes as C, sys, torch
 from space_time_pde_amd import _lib, unet3d
+_lib.tune("conv_wgrad_lds_gx", int(sys.argv[1]))
 torch.manual_seed(3)
 dev = torch.device("cuda:0")
 x = torch.randn(1, 16, 64, 64, 32, device=dev)
@@ -191,8 +192,8 @@ assert err < 2e-5
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for gx in ("7", "256", "1000"):
-        env = dict(os.environ, STPDE_CONV_WGRAD_LDS_GX=gx, PYTHONPATH=root)
-        out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        env = dict(os.environ, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", code, gx], env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout + out.stderr
 
 

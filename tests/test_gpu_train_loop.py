@@ -270,6 +270,61 @@ def test_world_size_1_nccl_group_runs_the_overlapped_collectives(hiplib, tmp_pat
             assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-10
 
 
+@pytest.mark.gpu
+def test_graphed_step_replays_the_eager_step(hiplib):
+    """train_step.GraphedStep (round 6): forward + backward of the reference's own training regime
+    (experiments/rb2d/run_experiment.sh:16 -- 10 crops x 512 points, latent (4,16,16), train.py:58-77) captured in a HIP graph.
+    A replay must give what the eager step gives on the same inputs: on the captured inputs, and on NEW inputs copied into the
+    static buffers (the graph holds addresses, not values); the deferred U-Net weight gradients (side stream) are part of the
+    capture.  Losses to 1e-5, IM-NET gradients to fp32 atomic summation order, U-Net gradients in the Frobenius norm (training-
+    mode BatchNorm over 8 voxels at the deepest level amplifies rounding)."""
+    from space_time_pde_amd import implicit_net, local_implicit_grid as lig, physics, unet3d
+    from space_time_pde_amd.train_step import GraphedStep, sharded_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(4, 16, 16), nf=16, mf=256).to(dev).train()
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32, activation=torch.nn.Softplus).to(dev)
+    layer = physics.get_rb2_pde_layer(mean=(0.01, 0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                      x_crop=1., use_continuity=True)
+    g = torch.Generator().manual_seed(12)
+    B, N = 10, 512
+
+    def draw():
+        return (torch.randn(B, 4, 4, 16, 16, generator=g).to(dev), (0.02 + 0.96 * torch.rand(B, N, 3, generator=g)).to(dev),
+                torch.randn(B, N, 4, generator=g).to(dev))
+
+    params = list(unet.parameters()) + list(net.parameters())
+
+    def eager(crop, pts, tgt):
+        for p in params:
+            p.grad = None
+        loss, reg, pde = sharded_step(unet, net, layer, crop, pts, tgt, N, 1.0, 0.0125, "l1", distributed=False)
+        torch.cuda.synchronize()
+        return [float(loss), float(reg), float(pde)], [p.grad.clone() for p in params]
+
+    a = draw()
+    n0 = lig.stats["hip_jet_calls"]
+    gstep = GraphedStep(unet, net, layer, *a, N, 1.0, 0.0125, "l1")
+    assert lig.stats["hip_jet_calls"] > n0                       # the HIP jet path is what was captured
+    grads = [p.grad for p in params]                              # static tensors of the graph's pool
+    assert all(gr is not None for gr in grads)
+    nu = len(list(unet.parameters()))
+    for inputs in (a, draw(), draw()):
+        out = gstep(*inputs)
+        torch.cuda.synchronize()
+        got = [float(v) for v in out]
+        ggrads = [gr.clone() for gr in grads]
+        want, wgrads = eager(*inputs)
+        for x, y in zip(got, want):
+            assert abs(x - y) <= 1e-5 * abs(y), (got, want)
+        for k, (x, y) in enumerate(zip(ggrads, wgrads)):
+            if k < nu:
+                assert (x - y).norm().item() <= 2e-2 * y.norm().item() + 1e-7, k
+            else:
+                assert (x - y).abs().max().item() <= 2e-4 * y.abs().max().item() + 1e-10, k
+    assert gstep.replays == 3
+
+
 def _config2_rank_worker(rank, port, out):
     """One rank of BASELINE configs[2] (2^22 points over 8 GPUs -> 2^19 points per rank on the configs[1] grid) behind a
     world-size-1 "nccl" (RCCL) process group: sharded_step(distributed=True) with n_points_global = 2^22."""
@@ -444,7 +499,7 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
     kernels = a[5]
     for needle in ("k_fc1_fwd_spec", "k_wgrad_oct_bf", "k_tail_fwd_bf", "k_tail_bwd_bf", "k_conv_fused"):
         assert any(needle in k for k in kernels), (needle, kernels)
-    assert any(("k_fc1_bwd_fused" in k) or ("k_fc1_dgrad_spec" in k) for k in kernels), kernels
+    assert any("k_fc1_bwd_fused" in k for k in kernels), kernels
     assert lig_jet.stats["recompute_steps"] == rc0 or torch.cuda.get_device_properties(0).total_memory < 200e9   # stash kept
     a2 = run(True)
     b = run(False)

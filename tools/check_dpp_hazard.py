@@ -8,7 +8,7 @@ row_sum16x4) need their own wait states.  ADVICE round 5 found 4 + sites where a
 instruction earlier; this scan is the build check that keeps them from coming back (run by __graft_entry__.build() and by
 tests/test_host_logic.py).
 
-Method: every object file under csrc/build is un-bundled with `llvm-objdump --offloading` in a scratch directory, its gfx950
+Method: the fat binary of every object file under csrc/build is un-bundled (and inflated) in a scratch directory, its gfx950
 code object disassembled, and every `*_dpp` instruction checked against the straight-line instructions in front of it: each
 instruction between the writer and the DPP reader counts one wait state, `s_nop N` counts N + 1.  Labels (branch targets) end the
 backward scan -- a hazard across a taken branch is not seen (none of the hand-written DPP code sits at a block entry: each
@@ -103,20 +103,25 @@ def scan_disassembly(text, need=2):
 
 
 def disassemble(obj, scratch):
-    """gfx950 disassembly text of one host object with an embedded offload bundle ('' if it has none)."""
-    local = os.path.join(scratch, os.path.basename(obj))
-    shutil.copy(obj, local)
-    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], stdout=subprocess.DEVNULL,
-                   stderr=subprocess.DEVNULL, check=False)
-    cos = glob.glob(local + ".*gfx950*")
-    out = []
-    for co in cos:
-        r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], stdout=subprocess.PIPE,
+    """gfx950 disassembly text of one host object with an embedded offload bundle ('' if it has none).  The fat binary section
+    is dumped with llvm-objcopy and un-bundled with clang-offload-bundler, which also inflates the compressed bundles of
+    --offload-compress builds (llvm-objdump --offloading hands those out still compressed)."""
+    base = os.path.join(scratch, os.path.basename(obj))
+    fat, co = base + ".fat", base + ".co"
+    r = subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, base + ".tmp"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    text = ""
+    if r.returncode == 0 and os.path.exists(fat):
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--input=" + fat, "--unbundle",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, check=False)
-        out.append(r.stdout.decode(errors="replace"))
-    for f in glob.glob(local + "*"):
+        if r.returncode == 0 and os.path.exists(co):
+            r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, check=False)
+            text = r.stdout.decode(errors="replace")
+    for f in glob.glob(base + "*"):
         os.remove(f)
-    return "\n".join(out)
+    return text
 
 
 def scan_build(build_dir=BUILD, verbose=False):

@@ -11,7 +11,6 @@ orderings that could make a correct kernel read or write the wrong bytes:
              kept alive by references, not by record_stream) is queued -- not synchronised -- right before each iteration, so
              the pool's buffers are carved out of blocks the previous step just released while the side stream may still run
   churn      the caching allocator is emptied / refilled with different block sizes between iterations
-  jetside    the LIG backward with its weight gradients on the second side stream (lig_jet._wgrad_stream) in flight
 
 Every iteration compares hip vs torch on the device bit for bit (forward and both backward results, both pooling shapes, the
 up-sampling); on a mismatch it recomputes torch's result on the host to say which side is off and whether the inputs survived.
@@ -78,7 +77,7 @@ def make_unet_step(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=250)
-    ap.add_argument("--modes", default="alone,h2d,side,churn,jetside")
+    ap.add_argument("--modes", default="alone,h2d,side,churn")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -89,7 +88,7 @@ def main():
     for mode in args.modes.split(","):
         report, bad, t0 = [], 0, time.time()
         n = args.iters if mode != "h2d" else max(10, args.iters // 5)
-        if mode in ("side", "jetside") and step is None:
+        if mode == "side" and step is None:
             step = make_unet_step(dev)
         junk = []
         for it in range(n):
@@ -102,10 +101,6 @@ def main():
             if mode == "side":
                 os.environ["STPDE_UNET_DEFERRED"] = "1"
                 step()                                   # queued, NOT synchronised: its side stream is still busy
-            elif mode == "jetside":
-                os.environ["STPDE_OVERLAP_UNET_BWD"] = "1"
-                step()
-                os.environ.pop("STPDE_OVERLAP_UNET_BWD")
             elif mode == "churn":
                 junk = [torch.empty((1 + (it * 7919) % 97) << 20, device=dev) for _ in range(3)]
                 del junk
