@@ -244,7 +244,18 @@ def small_workload(args):
     pts = torch.rand(B, N, 3, generator=g).to(dev)
     tgt = torch.randn(B, N, 4, generator=g).to(dev)
     params = list(unet.parameters()) + list(net.parameters())
-    opt = optim.FusedClipAdam(params, lr=1e-2, clip_grad=1.0)            # train.py:205, :79-83, :330-333
+    # the forward + backward of the step captured in a HIP graph FIRST (before any optimizer step and any profiler activity in
+    # this process): the graph holds the parameters' addresses, so the optimizer below runs with flat=False (pointer-table
+    # kernel, storages untouched -- optim.FusedClipAdam's flat mode would re-point every p.data into its own buffer)
+    gstep = graph_err = None
+    if not args.profile_only:
+        try:
+            gstep = GraphedStep(unet, net, layer, crop, pts, tgt, N, ALPHA_REG, ALPHA_PDE, "l1")
+            ggrads = [p.grad for p in params]
+        except Exception as e:  # noqa: BLE001
+            graph_err = "%s: %s" % (type(e).__name__, str(e)[:400])
+            gstep = None
+    opt = optim.FusedClipAdam(params, lr=1e-2, clip_grad=1.0, flat=False)    # train.py:205, :79-83, :330-333
 
     def eager_step():
         for p in params:
@@ -264,12 +275,11 @@ def small_workload(args):
         return 1e3 * (time.perf_counter() - t0) / steps, float(loss)
 
     for _ in range(max(args.warmup, 3)):
-        eager_step()                                                       # (the first optimizer step moves the parameters into
-    n0 = lig.stats["hip_jet_calls"]                                        #  the flat buffers: before any capture)
+        eager_step()
+    n0 = lig.stats["hip_jet_calls"]
     if args.profile_only:
         # child run of this workload: kernel dispatches and device time of ONE eager step through torch.profiler (roctracer).
-        # In a process of its own: a HIP-graph capture after roctracer has been active in the same process crashed the
-        # interpreter on the test box, and a profiler that is unavailable must not cost the parent its line.
+        # In a process of its own: a profiler that is unavailable or crashes must not cost the parent its line.
         from torch.profiler import ProfilerActivity, profile
         nprof = 3
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
@@ -289,16 +299,12 @@ def small_workload(args):
     ms_eager_async, _ = timed(eager_step, args.steps, item=False)
     gc.enable()
     assert lig.stats["hip_jet_calls"] == n0 + 2 * args.steps, "HIP jet path was not taken"
-    # the same iteration with forward + backward replayed from a HIP graph
+    # the same iteration with forward + backward replayed from the HIP graph
     ms_graph = ms_graph_async = loss_g = None
-    graph_err = None
-    try:
-        gstep = GraphedStep(unet, net, layer, crop, pts, tgt, N, ALPHA_REG, ALPHA_PDE, "l1")
-        grads = [p.grad for p in params]
-
+    if gstep is not None:
         def graph_step():
             loss, _, _ = gstep()
-            for p, gr in zip(params, grads):                               # (the optimizer re-points .grad into its flat buffer)
+            for p, gr in zip(params, ggrads):                              # (the graph's static gradient tensors)
                 p.grad = gr
             opt.step()
             return loss
@@ -310,9 +316,6 @@ def small_workload(args):
         ms_graph, loss_g = timed(graph_step, args.steps)
         ms_graph_async, _ = timed(graph_step, args.steps, item=False)
         gc.enable()
-    except Exception as e:  # noqa: BLE001
-        gc.enable()
-        graph_err = "%s: %s" % (type(e).__name__, str(e)[:400])
     # dispatches and device time of ONE eager step: a child run of this script (see --profile-only above); the library's own
     # dispatch trace (its kernels only, torch's elementwise / cat / copy launches not seen) if that fails
     disp = ksum = prof_err = None
@@ -354,8 +357,9 @@ def small_workload(args):
                    "loss": loss_g if loss_g is not None else loss_e},
         "roofline": {"bound": "launch latency", "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None,
                      "traffic": None,
-                     "note": "5,120-point steps are ~%d dispatches of microseconds each: no kernel of this workload is near a "
-                             "hardware roof; the figure of merit is step time over the sum of kernel time" % int(disp)},
+                     "note": "a %d-point step is ~%d dispatches of microseconds each: no kernel of this workload is near a "
+                             "hardware roof; the figure of merit is step time over the sum of kernel time (below 1 when the "
+                             "graph's side-stream branches overlap)" % (pts_step, int(disp))},
     }
     print(json.dumps(out))
     return out

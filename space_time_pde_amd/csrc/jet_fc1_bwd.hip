@@ -13,21 +13,14 @@
 // act_eval ONCE, feeding the layer-0 adjoint and the bf16 operand blocks h0 of the weight gradient (which never leave the
 // wave: a private LDS patch turns them into the row-major image).
 //
-// Work split (round 6): the 512 x 256 block of dW1h cannot stay resident in one workgroup's registers, so FOUR workgroups share a
-// row tile: each owns 8 of the 32 feature tiles of layer 0 -- input gradient of those 8 tiles (contraction over all of abar1),
-// weight gradient dW1h[:, its 8 tiles].  A workgroup = 4 waves; wave w owns 2 feature tiles and keeps dW1h[16 output
-// tiles][its 2 tiles] = 32 accumulator blocks (128 registers) for the whole launch (persistent, grid stride over row tiles,
-// atomics at the end), streams W1h^T from L2 through a register ring and the adjoint tile from LDS.  With 128 accumulator
-// registers a wave fits 256 registers, so TWO workgroups are resident per CU = two waves per SIMD that belong to different
-// workgroups and share no barrier: while one of them evaluates activation jets (vector ALU) the other one's MFMAs run, and
-// while one waits for its next adjoint tile the other one computes.  (Round 5 had two workgroups per row tile, four feature
-// tiles = 256 accumulator registers per wave, ONE wave per SIMD: its matrix and vector phases ran back to back -- 18.7k
-// cycles per row tile against ~7k of either pipe's time -- and every attempt to interleave them inside the one instruction
-// stream ended in spills.)  The LDS tile is single-buffered (40 KB + 20 KB of h0 patches per workgroup; two buffers would not
-// let two workgroups share a CU): the next tile is requested when every wave has finished reading the current one.
-// The four quarters of a row tile sit on the same XCD (blocks b, b + 8, b + 16, b + 24), so HBM delivers the adjoint tile once.
+// Work split: the 512 x 256 block of dW1h cannot stay resident in one workgroup's registers, so TWO workgroups share a row
+// tile: each owns 16 of the 32 feature tiles of layer 0 -- input gradient of those 16 tiles (contraction over all of abar1),
+// weight gradient dW1h[:, its 16 tiles].  A workgroup = 4 waves, ONE per SIMD, 512 registers each: wave w owns 4 feature
+// tiles, keeps dW1h[16 output tiles][its 4 tiles] = 64 accumulator blocks (256 AGPRs) for the whole launch (persistent, grid
+// stride over row tiles, atomics at the end), streams W1h^T from L2 through a register ring and the adjoint tile from LDS.
+// The two halves of a row tile sit on the same XCD (blocks b and b + 8), so HBM delivers the adjoint tile once.
 // The raw-input columns of dW1 (skip connection / bias: 3 k-tiles, value stream + tangent column sums) are dealt over the
-// sixteen waves of a row tile's four workgroups (one output tile each).
+// eight waves of a row tile's two workgroups (two output tiles each).
 // Arithmetic: operand rounding and the accumulation order of the input gradient are those of k_fc1_dgrad_spec (bit-identical
 // abar0 / tangent row sums); the weight gradient sums the same bf16 products in another order (fp32 summation rounding).
 #include "jet_wgrad_impl.h"
@@ -88,27 +81,25 @@ struct Fc1BwdArgs {
   } while (0)
 
 template <int S2, int ACT>
-__global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
-  constexpr int S1 = 3, S = 1 + S1 + S2, MT = 32, KT = 16, KP = KT / 2, NQ = 2;
+__global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
+  constexpr int S1 = 3, S = 1 + S1 + S2, MT = 32, KT = 16, KP = KT / 2, NQ = 4;
   constexpr int NCH = S * KT / 2;          // 1 KiB chunks of a packed adjoint tile (40 at S = 5)
   constexpr int NP = (S + 1) / 2;          // stream pairs of the weight-gradient MFMAs (K = 32 = 2 streams x 16 rows)
   static_assert(NCH % 4 == 0, "chunks are dealt to four waves");
-  __shared__ __attribute__((aligned(16))) float bst[NCH * 256];        // one row tile as it lies in HBM
-  // h0 operand blocks of each wave's own feature tiles (bf16); slots [1] and [2] first park the input-gradient accumulators of
-  // the wave's second tile (fp32: two 512-byte slots per stream) while the first tile goes through its jets
-  __shared__ __attribute__((aligned(16))) float hp[4][NQ + 1][S][128];
+  __shared__ __attribute__((aligned(16))) float bst[2][NCH * 256];     // two row tiles as they lie in HBM
+  __shared__ __attribute__((aligned(16))) float hp[4][NQ][S][128];     // h0 operand blocks of each wave's own feature tiles (bf16)
   __shared__ __attribute__((aligned(16))) float tcl[4][NQ][3][16];     // tangent constants: features 4g .. 4g+3 at [4 g + r]
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lo = lane * 4;
   const int b = blockIdx.x, G = gridDim.x;
-  // the four quarters of a row tile on one XCD (block -> XCD is b % 8) when the grid allows it
-  const bool xa = (G % 32) == 0;
-  const int half = xa ? ((b >> 3) & 3) : (b & 3);                // (which quarter of the feature tiles)
-  const int pair = xa ? ((b & 7) + 8 * (b >> 5)) : (b >> 2);     // (which group of four workgroups)
-  const int npairs = G / 4;
+  // the two halves of a row tile on one XCD (block -> XCD is b % 8) when the grid allows it
+  const bool xa = (G % 16) == 0;
+  const int half = xa ? ((b >> 3) & 1) : (b & 1);
+  const int pair = xa ? ((b & 7) + 8 * (b >> 4)) : (b >> 1);
+  const int npairs = G / 2;
   const int ntl = a.ntiles > pair ? (a.ntiles - pair + npairs - 1) / npairs : 0;
-  const int kt0 = 8 * half + w;            // feature tile of local index q: kt0 + 4 q
+  const int kt0 = 16 * half + w;           // feature tile of local index q: kt0 + 4 q
   // transpose-read offset (bytes) inside a 512-byte bf16 block stored lane by lane ([g][row][4 features]): lane i of group g'
   // passes the 8 bytes of lane (i % 4, 4 g' + i / 4) and receives rows 4g' .. 4g'+3 of feature i (common.h: lds_read_tr16)
   const int trofs = (16 * (lane & 3) + 4 * (lane >> 4) + ((lane & 15) >> 2)) * 8;
@@ -122,15 +113,17 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
 
   // Raw-input columns of dW1 (skip connection / bias: XT k-tiles; value stream x raw input, tangent columns = row sums of the
   // tangent-stream adjoints through the pattern operand [feature == d], as k_wgrad_coop's XB path): the 16 output tiles are
-  // dealt one to each of the sixteen waves of a row tile's four workgroups -- 3 accumulator blocks per wave, 4 MFMAs per row tile
+  // dealt two to each of the eight waves of a row tile's two workgroups -- 6 accumulator blocks per wave, 8 MFMAs per row tile
   // (the first version kept a separate launch of the ring kernel for them: 5.5 ms per 2^20 points to re-read every adjoint)
-  constexpr int NMX = 1;
-  const int mx = 4 * half + w;
-  f32x4 dwx[NMX][XT];
+  const int mx = 2 * (4 * half + w);
+  f32x4 dwx[2][XT];
 #pragma unroll
-  for (int mi = 0; mi < NMX; ++mi)
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) dwx[mi][xt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x4 one4 = to_bf4(f32x4{1.f, 1.f, 1.f, 1.f});
+  const bf16x4 pat0 = (lane & 15) == 0 ? one4 : zero4;
+  const bf16x8 pat12 = cat8((lane & 15) == 1 ? one4 : zero4, (lane & 15) == 2 ? one4 : zero4);
 
   // tangent constants W0[:, d] of this wave's feature tiles: in the column-major image a block holds the same four values in
   // every row, so 16 floats per (tile, d) in LDS and one broadcast ds_read_b128 per use (48 registers otherwise: the 256
@@ -153,10 +146,14 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
   // gradient ran at 2.5x its MFMA time)
   constexpr int RD = STPDE_FC1F_RING;
   bf16x8 wr[RD][2];
+#pragma unroll
+  for (int s = 0; s < RD; ++s)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wr[s][q] = wload(s, q);
 
-  auto stage = [&](int tile) {              // this wave's chunks (w + 4 c) of row tile `tile` into the LDS tile
+  auto stage = [&](int tile, int bb) {      // this wave's chunks (w + 4 c) of row tile `tile` into buffer bb
     const char* src = reinterpret_cast<const char*>(a.abar1) + (size_t)tile * (NCH * 1024) + lane * 16;
-    char* dst = reinterpret_cast<char*>(&bst[0]);
+    char* dst = reinterpret_cast<char*>(&bst[bb][0]);
 #pragma unroll
     for (int c = 0; c < NCH / 4; ++c) {
       const int ch = __builtin_amdgcn_readfirstlane(w + 4 * c);
@@ -171,22 +168,20 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cqn);
   };
   if (ntl > 0) {
-    stage(pair);
+    stage(pair, 0);
     fetch(pair);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FC1F_BARRIER();
   float pacc = 0.f;
 
   for (int it = 0; it < ntl; ++it) {
     const int tile = pair + it * npairs;
+    const int buf = it & 1;
     const bool more = it + 1 < ntl;
     const int tnext = more ? tile + npairs : tile;
-    // this row tile has landed (every wave waits for its own chunks, the barrier makes them visible to all): the only
-    // vector-memory wait of an iteration -- the other workgroup of the CU computes meanwhile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FSTAMP(6);
-    FC1F_BARRIER();
-    FSTAMP(7);
-    float* const cq = cqn;      // (used by the jets only; fetch() overwrites it with the next tile's after them)
+    if (more && STPDE_FC1F_ABL != 6) stage(tnext, buf ^ 1);
+    float* const cq = cqn;
 
     // Schedule of a row tile.  One wave per SIMD: nothing but this wave's own instruction stream hides a latency, so the matrix
     // phases request every LDS operand one step ahead of its MFMAs and a step carries enough MFMAs (20 / 12 x 17 cycles) to
@@ -196,20 +191,26 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     //   2  the same for feature tiles 2, 3
     //   3  weight gradient of the four tiles (192 MFMAs, adjoint fragments of output tile m + 1 in flight)
     f32x4 acc[2][S];          // the input gradient runs two feature tiles at a time: 40 accumulator registers instead of 80
-    const bf16x4* bs = reinterpret_cast<const bf16x4*>(&bst[0]) + lane;
+    const bf16x4* bs = reinterpret_cast<const bf16x4*>(&bst[buf][0]) + lane;
     // hbar0 of feature tiles q0, q0 + 1 = W1h^T abar1; wr[.][0..1] hold the first two k-tile pairs of their weights on entry
     auto dgrad2 = [&](int q0) {
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
         for (int st = 0; st < S; ++st) acc[qq][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 Bn[S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) Bn[st] = cat8(bs[(st * KT) * 64], bs[(st * KT + 1) * 64]);
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
-        // (no one-ahead copy of the B fragments any more: two waves share the SIMD, the other one's instructions cover this
-        // LDS round trip, and the 20 registers are what the 128 accumulator registers leave no room for)
         bf16x8 B8[S];
 #pragma unroll
-        for (int st = 0; st < S; ++st) B8[st] = cat8(bs[(st * KT + 2 * kp) * 64], bs[(st * KT + 2 * kp + 1) * 64]);
+        for (int st = 0; st < S; ++st) B8[st] = Bn[st];
+        if (kp + 1 < KP && STPDE_FC1F_ABL != 5) {
+#pragma unroll
+          for (int st = 0; st < S; ++st) Bn[st] = cat8(bs[(st * KT + 2 * kp + 2) * 64], bs[(st * KT + 2 * kp + 3) * 64]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
@@ -248,52 +249,50 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
         }
       } else {
         act_jet_adj<S1, S2, ACT>(a.cfg, pre, acc[q & 1], ab, cq);
+        act_jet_fwd<S1, S2, ACT>(a.cfg, pre, h, cq);
       }
       if (ACT == STPDE_ACT_SWISH && a.pbar) pacc += swish_beta_adj<S1, S2>(a.cfg, pre, acc[q & 1], cq);
       *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.abar0) + ((size_t)tile * MT + kt) * 512 + lane * 8) = to_bf4(ab[0]);
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        const f32x4 ts = row_sum16x4(ab[1 + d]);      // (hazard-safe form, common.h)
+        const f32x4 ts = row_sum16x4(ab[1 + d]);      // (hazard-safe form: this wave has its SIMD to itself, common.h)
         buf_st16(tanr, tanlane, (__builtin_amdgcn_readfirstlane(kt) * 48 + 16 * d) * 4, ts);
+        // (round 6: wait states between the 16-byte store and the next write of its data registers.  The compiler re-uses them
+        // for the next row sum's inputs, its hazard model exempts buffer stores with a scalar offset, and a two-waves-per-SIMD
+        // variant of this kernel -- four workgroups per row tile, measured slower and not kept, DESIGN 8 -- stored the NEW value
+        // of the first data dword now and then when the overwrite was the very next instruction; tools/check_dpp_hazard.py rule 2)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 2");
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // (the adjoint is stored before the operand blocks are evaluated: with 128 accumulator registers and two waves per SIMD
-      // the two jets' temporaries together do not fit)
-      __builtin_amdgcn_sched_barrier(0);
-      if (STPDE_FC1F_ABL != 1) act_jet_fwd<S1, S2, ACT>(a.cfg, pre, h, cq);
 #pragma unroll
       for (int st = 0; st < S; ++st) *reinterpret_cast<bf16x4*>(&hp[w][q][st][lane * 2]) = to_bf4(h[st]);
     };
     // (one tile at a time: interleaving the evaluations multiplies their temporaries past the 256 registers the accumulators of
     // dW1h leave, and every spilled register is a scratch access inside the loop)
     FSTAMP(0);
-    wring(0);            // (the same weights for every row tile; requested here, not a phase earlier: registers)
     dgrad2(0);
     __builtin_amdgcn_sched_barrier(0);
     FSTAMP(1);
-    // (the second tile's accumulators wait in LDS: 20 registers the jets of the first tile need)
-#pragma unroll
-    for (int st = 0; st < S; ++st) {
-      *reinterpret_cast<float2*>(&hp[w][1][st][lane * 2]) = float2{acc[1][st][0], acc[1][st][1]};
-      *reinterpret_cast<float2*>(&hp[w][2][st][lane * 2]) = float2{acc[1][st][2], acc[1][st][3]};
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    wring(2);
     epi(0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int st = 0; st < S; ++st) {
-      const float2 lo2 = *reinterpret_cast<const float2*>(&hp[w][1][st][lane * 2]);
-      const float2 hi2 = *reinterpret_cast<const float2*>(&hp[w][2][st][lane * 2]);
-      acc[1][st] = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);
     epi(1);
+    __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(2);
+    dgrad2(2);
+    __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(3);
+    epi(2);
+    __builtin_amdgcn_sched_barrier(0);
+    epi(3);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);
     FSTAMP(4);
     // next row tile's z0 blocks / combination weights and the first stages of its weight ring (the same weights for every row
     // tile): they land while the weight-gradient MFMAs run
     fetch(tnext);
+    wring(0);
     // ---------------- weight gradient: dW1h[:, this wave's tiles] += abar1^T h0
     {
       bf16x8 H8[NQ][NP];
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
           H8[q][p] = cat8(lds_read_tr16(reinterpret_cast<const __bf16*>(h0)),
                           2 * p + 1 < S ? lds_read_tr16(reinterpret_cast<const __bf16*>(h1)) : zero4);
         }
-      const char* ab = reinterpret_cast<const char*>(&bst[0]) + trofs;
+      const char* ab = reinterpret_cast<const char*>(&bst[buf][0]) + trofs;
       auto rdA = [&](int m, bf16x8* A8) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -316,21 +315,27 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
           A8[p] = cat8(a0, a1);
         }
       };
+      // raw-input columns: this wave's two output tiles against the row tile's XT raw-input fragments (requested here, used
+      // after the hidden k-tiles' MFMAs)
+      f32x4 xr[XT];
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) xr[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+      bf16x8 An[NP];
+      rdA(0, An);
 #pragma unroll
       for (int m = 0; m < KT; ++m) {
         bf16x8 A8[NP];
-        rdA(m, A8);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) A8[p] = An[p];
+        if (m + 1 < KT) rdA(m + 1, An);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
             if (STPDE_FC1F_ABL != 2) dw[m][q] = mfma_bf(A8[p], H8[q][p], dw[m][q]);
       }
-      // raw-input columns: this wave's output tile against the row tile's XT raw-input fragments, as row-major bf16 operands
-      // through this wave's h0 patch (its blocks are in registers by now)
-      f32x4 xr[XT];
-#pragma unroll
-      for (int xt = 0; xt < XT; ++xt) xr[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+      // the raw-input fragments as row-major bf16 operands: through this wave's h0 patch (its blocks are in registers by now)
       bf16x4 xb4[XT];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -340,12 +345,8 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
       for (int xt = 0; xt < XT; ++xt)
         xb4[xt] = lds_read_tr16(reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(&hp[w][0][xt][0]) + trofs));
       __builtin_amdgcn_wave_barrier();
-      // (pattern operands [feature == d] rebuilt per row tile: a dozen registers the accumulators leave no room to keep)
-      const bf16x4 one4 = to_bf4(f32x4{1.f, 1.f, 1.f, 1.f});
-      const bf16x4 pat0 = (lane & 15) == 0 ? one4 : zero4;
-      const bf16x8 pat12 = cat8((lane & 15) == 1 ? one4 : zero4, (lane & 15) == 2 ? one4 : zero4);
 #pragma unroll
-      for (int mi = 0; mi < NMX; ++mi) {
+      for (int mi = 0; mi < 2; ++mi) {
         const char* am = ab + (size_t)(mx + mi) * 512;
         const bf16x8 A01 = cat8(lds_read_tr16(reinterpret_cast<const __bf16*>(am)),
                                 lds_read_tr16(reinterpret_cast<const __bf16*>(am + KT * 512)));
@@ -359,9 +360,11 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     FSTAMP(5);
-    // every wave is done reading the LDS tile: request the next one into it
+    // the staged row tile has landed (the only vector-memory wait of an iteration), every wave is done with this buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FSTAMP(6);
     FC1F_BARRIER();
-    if (more && STPDE_FC1F_ABL != 6) stage(tnext);
+    FSTAMP(7);
   }
 
   const int g = lane >> 4, c = lane & 15;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void k_fc1_bwd_fused(Fc1BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * m + 4 * g + r) * ldw + 16 * (kt0 + 4 * q) + c, dw[m][q][r]);
 #pragma unroll
-  for (int mi = 0; mi < NMX; ++mi)
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
@@ -389,10 +392,10 @@ static int launch_fused(const Fc1BwdArgs& a, hipStream_t stream) {
   int dev = 0, ncu = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  int groups = 2 * ncu / 4;                 // two workgroups per CU, four workgroups per row tile
-  if (groups > a.ntiles) groups = a.ntiles;
-  if (groups < 1) groups = 1;
-  STPDE_LAUNCH((k_fc1_bwd_fused<S2, ACT>), dim3(4 * groups), dim3(256), 0, stream, a);
+  int pairs = ncu / 2;
+  if (pairs > a.ntiles) pairs = a.ntiles;
+  if (pairs < 1) pairs = 1;
+  STPDE_LAUNCH((k_fc1_bwd_fused<S2, ACT>), dim3(2 * pairs), dim3(256), 0, stream, a);
   return stpde_check_launch("k_fc1_bwd_fused");
 }
 

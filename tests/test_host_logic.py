@@ -325,3 +325,17 @@ def test_no_unprotected_dpp_sequences_in_the_built_library():
     bad, ndpp, nobj = check_dpp_hazard.scan_build()
     assert nobj >= 20 and ndpp > 1000
     assert not bad, bad[:5]
+
+
+def test_hazard_scanner_flags_a_store_whose_data_is_overwritten_at_once():
+    """Round 6, found on hardware: buffer_store_dwordx4 with a scalar offset + a VALU write of its first data register in the
+    next instruction stored the new value now and then (k_fc1_bwd_fused with two waves per SIMD).  The build scan flags it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dpp_hazard as chk
+    bad = chk.scan_store_data("0000 <k>:\n\tbuffer_store_dwordx4 v[10:13], v238, s[8:11], s92 offen\n\tv_mov_b32_e32 v10, v204\n")
+    assert len(bad) == 1 and bad[0][3] == 0
+    ok = chk.scan_store_data("0000 <k>:\n\tbuffer_store_dwordx4 v[10:13], v238, s[8:11], s92 offen\n\ts_nop 2\n\tv_mov_b32_e32 v10, v204\n")
+    assert not ok
+    ok = chk.scan_store_data("0000 <k>:\n\tbuffer_store_dwordx4 v[10:13], v238, s[8:11], s92 offen\n\tv_mov_b32_e32 v20, v204\n"
+                             "\tv_mov_b32_e32 v21, v204\n\tv_mov_b32_e32 v10, v204\n")
+    assert not ok

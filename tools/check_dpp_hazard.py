@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Scan the gfx950 code objects of the built library for DPP data hazards the compiler cannot see.
+"""Scan the gfx950 code objects of the built library for data hazards the compiler does not guard: DPP reads of freshly
+written registers inside asm statements (rule 1 below), and 16-byte buffer stores whose data registers are overwritten by the
+very next instruction (rule 2, scan_store_data).
 
 Rule (gfx9 / CDNA data-hazard table): a DPP instruction must not read a VGPR that a VALU instruction wrote fewer than TWO wait
 states earlier; the hardware does not interlock.  The compiler's hazard recognizer inserts the s_nop itself for DPP instructions
@@ -102,6 +104,43 @@ def scan_disassembly(text, need=2):
     return bad
 
 
+def scan_store_data(text, need=2):
+    """Second rule (round 6, found on hardware with k_fc1_bwd_fused): `buffer_store_dwordx3/x4 ... sN offen` followed by a VALU
+    write of one of its DATA registers with no wait state in between stored the NEW value of the first data dword now and then
+    (gfx950, two waves per SIMD; the compiler's hazard model exempts buffer stores whose soffset is a scalar register, so it puts
+    nothing in between -- tools/micro/check_fc1_fused.py: 2,300 of 6.1 M tangent row sums wrong and different from run to run, 0
+    with `s_nop 2` behind the store).  Flag every such store whose data is overwritten fewer than `need` wait states later.
+    -> list of (kernel, store line, writer line, wait states)"""
+    bad, kernel = [], "?"
+    lines = text.splitlines()
+    for i, raw in enumerate(lines):
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", raw.strip())
+        if m:
+            if not (m.group(1).startswith("L") and m.group(1)[1:].isdigit()):
+                kernel = m.group(1)
+            continue
+        s = raw.split("//")[0].strip()
+        if not (s.startswith("buffer_store_dwordx4") or s.startswith("buffer_store_dwordx3")):
+            continue
+        data = _regs(s.split(",")[0])
+        ws = 0
+        for k in range(1, need + 2):
+            if i + k >= len(lines) or ws >= need:
+                break
+            n = lines[i + k].split("//")[0].strip()
+            mn, ops = _split(lines[i + k])
+            if mn is None or re.match(r"^[0-9a-f]+ <", n):
+                break
+            if mn == "s_nop":
+                ws += int(ops[0], 0) + 1 if ops else 1
+                continue
+            if _valu_writes(mn, ops) & data:
+                bad.append((kernel, s, n, ws))
+                break
+            ws += 1
+    return bad
+
+
 def disassemble(obj, scratch):
     """gfx950 disassembly text of one host object with an embedded offload bundle ('' if it has none).  The fat binary section
     is dumped with llvm-objcopy and un-bundled with clang-offload-bundler, which also inflates the compressed bundles of
@@ -132,7 +171,7 @@ def scan_build(build_dir=BUILD, verbose=False):
             text = disassemble(o, scratch)
             n = len(re.findall(r"_dpp\b", text))
             ndpp += n
-            b = scan_disassembly(text)
+            b = scan_disassembly(text) + scan_store_data(text)
             if verbose:
                 print("%-28s %6d dpp instructions, %d hazards" % (os.path.basename(o), n, len(b)))
             bad += [(os.path.basename(o),) + x for x in b]
