@@ -137,6 +137,11 @@ typedef struct {
    * of stpde_jet_layer_bwd / _bwd_to, including the layer-0 adjoint of a first-hidden-layer call: adjoint format),
    * 4 = abar_out (input of the backward / weight-gradient kernels) is a packed adjoint buffer. */
   int packed;
+  /* Deterministic mode (round 6; stpde_jet_wgrad / stpde_jet_fc1_bwd only): != 0 -> dW_aug addresses long accumulators (six
+   * zero-filled 64-bit integers per element instead of one float, see stpde_conv3d_desc.det), into which the workgroups'
+   * partial sums are added with integer atomics -- order-independent, bit-identical from run to run; stpde_det_finalize turns
+   * them into fp32.  (The adjoint of a learnable swish beta keeps its fp32 atomics.) */
+  int det;
 } stpde_layer_desc;
 /* Wh_pack_bf16 (used when d->mfma_bf16 != 0, may be NULL otherwise): [KT/2][MT][64] blocks of 8 bf16 =
  * the two fp32 blocks (2q, mt) and (2q+1, mt) of Wh_pack, lane by lane, rounded to bf16.
@@ -252,7 +257,8 @@ int stpde_lig_reduce_bwd(const stpde_jet_cfg* cfg, int S_mlp, int P, int n_out, 
                          const float* coef, float* abar_out, void* stream);
 
 /* dW_aug[16*MT][ldw] (layer 0: ldw = 16 * XT) column d  +=  sum over tiles of abar0_tan[tile][mt][d][:]. */
-int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, void* stream);
+int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, int det /* as stpde_layer_desc.det */,
+                          void* stream);
 
 /* ---- backward of the gather: d latent (index_put accumulate, backward of :65-66) --------------------
  * xbar = sum_l W_s,l^T * abar_l(value stream); latent channels are scatter-added into dlatent
@@ -347,6 +353,9 @@ typedef struct {
  * the same value of this bit and of STPDE_F_WGRAD: phase B skips fc1's weight gradient exactly when phase A's fused kernel
  * produced it. */
 #define STPDE_F_NO_FC1_FUSED 512
+/* backward: dW_flat addresses long accumulators (stpde_layer_desc.det): [sum of the layers' dW_aug elements][6] int64, layer l at
+ * element offset dw_off[l]; bit-reproducible IM-NET weight gradients */
+#define STPDE_F_DET 1024
 /* cfg_mlp = streams the layer kernels carry, cfg_out = streams of `jets` (they differ for piecewise-linear activations,
  * see stpde_lig_reduce_fwd); jets points at the first point of the chunk inside [S_out][n_out][ldp]. */
 int stpde_lig_imnet_jet_fwd(const stpde_imnet_plan* plan, const stpde_jet_cfg* cfg_mlp, const stpde_jet_cfg* cfg_out,
@@ -387,7 +396,17 @@ int stpde_interp_bwd_grid(const stpde_interp_desc* d, const float* pts, const fl
  * The input-gradient is the same kernel called with the transposed, tap-flipped pack (no bias). */
 typedef struct {
   int B, T, Z, X, Ci, Co, ksize; /* ksize 1 or 3 */
+  /* Deterministic mode (round 6; 0 = off).  != 0: every sum the kernels of this call accumulate with atomics -- dW / dbias of
+   * the weight-gradient calls, out_sums / m_bsum of stpde_conv3d_fused -- goes to ORDER-INDEPENDENT long accumulators instead
+   * of fp32 / fp64 atomics: the destination pointer then addresses STPDE_DET_K (6) zero-filled signed 64-bit integers per
+   * element (48 bytes instead of 4; element e at windows [6 e, 6 e + 6)), the result is bit-identical from run to run, and
+   * stpde_det_finalize turns an accumulator array into fp32 (statistics / backward sums are read by the BatchNorm kernels
+   * directly: a single replica [2][C][6] in the same scratch).  The forward does not split its taps over workgroups. */
+  int det;
 } stpde_conv3d_desc;
+/* acc [n][STPDE_DET_K] long accumulators (a deterministic-mode destination, see stpde_conv3d_desc.det) -> out [n] fp32. */
+#define STPDE_DET_K 6
+int stpde_det_finalize(const void* acc, long n, float* out, void* stream);
 int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, const float* w_pack, const float* bias, float* y,
                      void* stream);
 /* dW[tap][Co][Ci] += sum_voxels ybar[v][co] * x[v + offset(tap)][ci]  (fp32 atomics; caller zero-fills dW). */
@@ -467,6 +486,9 @@ typedef struct {
                            format, already complete (no statistics pass) */
   int reduce_done;      /* backward: bsum is already complete and dy already carries the ReLU mask (stpde_conv3d_fused, m):
                            only the elementwise pass runs; pass relu = 0 */
+  int det;              /* deterministic mode (stpde_conv3d_desc.det): sums / bsum hold long accumulators -- forward statistics
+                           [2][C][6] int64 (sum x, sum x^2; stats_mode 1 / 2 only), backward sums [2][C][6] -- in the same
+                           zero-filled scratch */
 } stpde_bn_desc;
 int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float* residual, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float* sums, float* stat, float* y, void* stream);
@@ -519,6 +541,10 @@ int stpde_residual_bwd(const stpde_res_ins* prog_dev, int nins, int n_eq, int n_
 #define STPDE_LOSS_L1 0
 #define STPDE_LOSS_L2 1
 #define STPDE_LOSS_HUBER 2
+/* kind | STPDE_LOSS_DET (stpde_loss_sum only): out_sum addresses ONE long accumulator (six zero-filled 64-bit integers, see
+ * stpde_conv3d_desc.det) instead of a float -- the block sums are added with integer atomics, bit-identical from run to run;
+ * stpde_det_finalize(out_sum, 1, ...) gives the float. */
+#define STPDE_LOSS_DET 16
 int stpde_loss_sum(int kind, long n, const float* a, const float* b, float* out_sum, void* stream);
 int stpde_loss_grad(int kind, long n, const float* a, const float* b, const float* grad_sum_dev, float* grad_a,
                     void* stream);

@@ -19,7 +19,7 @@ _SOURCES = ["jet_layer.hip", "jet_layer_s00.hip", "jet_layer_s03.hip", "jet_laye
 _HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
              "--offload-compress"]
 
-ABI_VERSION = 312   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
+ABI_VERSION = 314   # == stpde_version() of the library these ctypes signatures were written for (csrc/api.cpp)
 
 ACT_CODES = {"tanh": 0, "relu": 1, "softplus": 2, "elu": 3, "swish": 4, "leakyrelu": 5}
 PBAR_SLOTS = 64   # STPDE_PBAR_SLOTS: accumulation slots of the swish-beta adjoint
@@ -39,7 +39,7 @@ class GatherDesc(C.Structure):
 
 class LayerDesc(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("KT", C.c_int), ("MT", C.c_int), ("first_hidden", C.c_int), ("cfg", JetCfg),
-                ("mfma_bf16", C.c_int), ("packed", C.c_int)]
+                ("mfma_bf16", C.c_int), ("packed", C.c_int), ("det", C.c_int)]
 
 
 class XbarDesc(C.Structure):
@@ -62,12 +62,13 @@ class LigWorkspace(C.Structure):        # stpde_lig_workspace
 
 
 F_STASH, F_VALUE_TILES, F_FUSED_TAIL, F_TAN0_ROWSUM, F_DETERMINISTIC, F_WGRAD, F_WGRAD_FP32 = 1, 2, 4, 8, 16, 32, 64
-F_PHASE_A, F_PHASE_B, F_NO_FC1_FUSED = 128, 256, 512
+F_PHASE_A, F_PHASE_B, F_NO_FC1_FUSED, F_DET = 128, 256, 512, 1024
+LOSS_DET = 16      # STPDE_LOSS_DET: stpde_loss_sum into a long accumulator
 
 
 class Conv3dDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("Z", C.c_int), ("X", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
-                ("ksize", C.c_int)]
+                ("ksize", C.c_int), ("det", C.c_int)]
 
 
 class Conv3dFusedArgs(C.Structure):     # stpde_conv3d_fused_args
@@ -86,11 +87,19 @@ class ResampleDesc(C.Structure):
 
 
 BN_REP = 16        # STPDE_BN_REP: replicas of the BatchNorm reduction scratch (include/stpde_hip.h)
+DET_K = 6          # STPDE_DET_K: 64-bit windows of a deterministic-mode long accumulator (12 floats of storage per element)
+# Deterministic mode (round 6; STPDE_DETERMINISTIC=1 or ``_lib.deterministic = True``): every sum the step accumulates with
+# fp32 / fp64 atomics -- U-Net convolution weight / bias gradients, BatchNorm statistics and backward sums, IM-NET weight
+# gradients, the loss sums -- goes to order-independent long accumulators (csrc/common.h); with the deterministic d latent
+# (the default) a whole training step is then bit-identical from run to run, like the reference's CPU path
+# (experiments/rb2d/train.py:58-77).  The one exception: the adjoint of a learnable swish beta keeps its fp32 atomics.
+deterministic = os.environ.get("STPDE_DETERMINISTIC", "0") == "1"
 
 
 class BnDesc(C.Structure):
     _fields_ = [("N", C.c_long), ("C", C.c_int), ("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float),
-                ("momentum", C.c_float), ("scratch_zeroed", C.c_int), ("stats_mode", C.c_int), ("reduce_done", C.c_int)]
+                ("momentum", C.c_float), ("scratch_zeroed", C.c_int), ("stats_mode", C.c_int), ("reduce_done", C.c_int),
+                ("det", C.c_int)]
 
 
 class AdamDesc(C.Structure):
@@ -201,7 +210,7 @@ _SIGNATURES = {
                               C.POINTER(_VP), _VP, C.c_int, C.POINTER(_VP), _VP], C.c_int),
     "stpde_jet_tail_bwd_p": ([C.POINTER(JetCfg), C.c_int, C.c_int, _VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _VP,
                               _VP, C.c_int, C.POINTER(_VP), _VP], C.c_int),
-    "stpde_jet_tan0_reduce": ([C.c_int, C.c_int, _VP, _VP, C.c_int, _VP], C.c_int),
+    "stpde_jet_tan0_reduce": ([C.c_int, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP], C.c_int),
     "stpde_jet_wgrad": ([C.POINTER(LayerDesc), C.c_int] + [_VP] * 7, C.c_int),
     "stpde_jet_fc1_bwd_supported": ([C.POINTER(LayerDesc)], C.c_int),
     "stpde_jet_fc1_bwd": ([C.POINTER(LayerDesc)] + [_VP] * 11, C.c_int),
@@ -228,6 +237,7 @@ _SIGNATURES = {
     "stpde_residual_bwd": ([_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP],
                            C.c_int),
     "stpde_resample3d": ([C.POINTER(ResampleDesc), C.c_int, _VP, _VP, _VP, _VP], C.c_int),
+    "stpde_det_finalize": ([_VP, C.c_long, _VP, _VP], C.c_int),
     "stpde_bn_fwd": ([C.POINTER(BnDesc)] + [_VP] * 10, C.c_int),
     "stpde_bn_bwd": ([C.POINTER(BnDesc)] + [_VP] * 11, C.c_int),
     "stpde_loss_sum": ([C.c_int, C.c_long, _VP, _VP, _VP, _VP], C.c_int),

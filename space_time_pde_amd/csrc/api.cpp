@@ -29,7 +29,7 @@ int stpde_check_launch(const char* what) {
 }
 
 // ABI version: bumped whenever a descriptor or a signature of include/stpde_hip.h changes (_lib.ABI_VERSION must match)
-extern "C" int stpde_version(void) { return 312; }
+extern "C" int stpde_version(void) { return 314; }
 
 // ---- launch-geometry overrides for tests (stpde_tune, include/stpde_hip.h) ---------------------------------------
 // Not performance switches: the persistent-grid kernels of the U-Net pick their own grid and their own minimum volume; tests

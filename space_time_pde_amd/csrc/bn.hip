@@ -109,8 +109,14 @@ __global__ __launch_bounds__(256) void k_bn_stats(BnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const double sh = shift[i], t1 = s1[i], t2 = s2[i];
-      atomicAdd(rep + c + i, t1 + n * sh);
-      atomicAdd(rep + C + c + i, t2 + 2. * sh * t1 + n * sh * sh);
+      if (a.d.det) {       // order-independent long accumulators, one replica (common.h)
+        long long* acc = reinterpret_cast<long long*>(a.sums);
+        det_add_f64(acc + (size_t)(c + i) * STPDE_DET_K, t1 + n * sh);
+        det_add_f64(acc + ((size_t)C + c + i) * STPDE_DET_K, t2 + 2. * sh * t1 + n * sh * sh);
+      } else {
+        atomicAdd(rep + c + i, t1 + n * sh);
+        atomicAdd(rep + C + c + i, t2 + 2. * sh * t1 + n * sh * sh);
+      }
     }
   } else if (m.row0 == 0) {
     // the partial sums of a block go to replica blockIdx % STPDE_BN_REP: with one copy, ~1000 blocks queue up on the same 2 C
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(BnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float mi, vi, ri;
-      bn_stat_f64(reinterpret_cast<const double*>(a.sums), C, c + i, N, a.d.eps, mi, vi, ri);
+      bn_stat_f64(reinterpret_cast<const double*>(a.sums), C, c + i, N, a.d.eps, a.d.det, mi, vi, ri);
       mean[i] = mi;
       var[i] = vi;
     }
@@ -236,7 +242,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(BnArgs a) {
   }
   s1 = bn_block_sum(s1, sh, m);
   s2 = bn_block_sum(s2, sh, m);
-  if (m.row0 == 0) {
+  if (m.row0 == 0 && a.d.det) {
+    long long* acc = reinterpret_cast<long long*>(a.bsum);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      det_add_f32(acc + (size_t)(c + i) * STPDE_DET_K, s1[i]);
+      det_add_f32(acc + ((size_t)C + c + i) * STPDE_DET_K, s2[i]);
+    }
+  } else if (m.row0 == 0) {
     float* rep = a.bsum + (size_t)(blockIdx.x % STPDE_BN_REP) * 2 * C;
     atomic_add4(rep + c, s1);
     atomic_add4(rep + C + c, s2);
@@ -253,9 +266,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnArgs a) {
   const int c = 4 * m.q;
   const f32x4 mean = ld4(a.stat + c), rstd = ld4(a.stat + C + c);
   f32x4 sdz = f32x4{0.f, 0.f, 0.f, 0.f}, sdzx = sdz;
-  for (int r = 0; r < STPDE_BN_REP; ++r) {
-    sdz += ld4(a.bsum + ((size_t)r * 2) * C + c);
-    sdzx += ld4(a.bsum + ((size_t)r * 2 + 1) * C + c);
+  if (a.d.det) {
+    const long long* acc = reinterpret_cast<const long long*>(a.bsum);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sdz[i] = (float)det_value(acc + (size_t)(c + i) * STPDE_DET_K);
+      sdzx[i] = (float)det_value(acc + ((size_t)C + c + i) * STPDE_DET_K);
+    }
+  } else {
+    for (int r = 0; r < STPDE_BN_REP; ++r) {
+      sdz += ld4(a.bsum + ((size_t)r * 2) * C + c);
+      sdzx += ld4(a.bsum + ((size_t)r * 2 + 1) * C + c);
+    }
   }
   if (blockIdx.x == 0 && m.row0 == 0) {
     if (a.dbeta) st4(a.dbeta + c, sdz);
@@ -331,6 +353,10 @@ extern "C" int stpde_bn_fwd(const stpde_bn_desc* d, const float* x, const float*
   if (!x || !y || !stat || (d->training && !sums) || (!d->training && (!running_mean || !running_var))) {
     stpde_set_error("bn_fwd: null pointer");
     return STPDE_E_BADARG;
+  }
+  if (d->det && d->training && d->stats_mode == 0) {
+    stpde_set_error("bn_fwd: the deterministic mode takes its statistics in the double format (stats_mode 1 or 2)");
+    return STPDE_E_UNSUPPORTED;
   }
   BnArgs a{};
   a.d = *d;
@@ -408,4 +434,23 @@ int stpde_bn_stats_f64(const float* x, long N, int C, double* sums, hipStream_t 
   const unsigned grid = bn_grid(&d);
   STPDE_LAUNCH(k_bn_stats, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, stream, a);
   return stpde_check_launch("k_bn_stats");
+}
+
+
+// ---- deterministic mode: long accumulators -> fp32 (include/stpde_hip.h: stpde_det_finalize) -------------------------------
+__global__ __launch_bounds__(256) void k_det_finalize(const long long* acc, long n, float* out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = (float)det_value(acc + (size_t)i * STPDE_DET_K);
+}
+
+extern "C" int stpde_det_finalize(const void* acc, long n, float* out, void* stream) {
+  if (!acc || !out || n < 0) {
+    stpde_set_error("det_finalize: bad argument");
+    return STPDE_E_BADARG;
+  }
+  if (n == 0) return STPDE_OK;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  STPDE_LAUNCH(k_det_finalize, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long long*>(acc), n, out);
+  return stpde_check_launch("k_det_finalize");
 }

@@ -564,6 +564,80 @@ __device__ __forceinline__ f32x4 row_sum16x4(f32x4 v) {
   return f32x4{a, b, c, d};
 }
 
+// ---- Order-independent ("long accumulator") sums: the deterministic mode of the U-Net kernels (round 6) -----------------------
+// An fp32 / fp64 atomic sum depends on the order the hardware serves the atomics in.  Integer addition does not: a value is
+// split exactly into 32-bit pieces at FIXED binary positions and each piece is added to its own signed 64-bit accumulator
+// ("window") with an integer atomic -- whatever the order, the K windows end up holding the same integers, and det_value()
+// turns them into the same floating-point number.  Window j weighs 2^(STPDE_DET_BASE + 32 j); a window takes 2^31 pieces before
+// it can overflow.  Range: bit positions 2^-110 ... 2^+81 (values up to ~2^80; magnitudes below 2^-86 (float) / 2^-57 (double)
+// lose their lowest bits -- truncated the same way every time).  A non-finite value poisons the top window (-> NaN).
+// Layout: accumulator e of an array = windows [e * STPDE_DET_K ... + K); the caller zero-fills.
+#define STPDE_DET_BASE (-110)      // (STPDE_DET_K = 6 windows: include/stpde_hip.h)
+__device__ __forceinline__ void det_add_pieces(long long* acc, unsigned long long m, int shift, bool neg) {
+  // |value| = m * 2^(BASE + shift), m < 2^53
+  if (shift < 0) {
+    m = shift > -64 ? (m >> (-shift)) : 0ull;
+    shift = 0;
+  }
+  const int j = shift >> 5, r = shift & 31;
+  const unsigned long long lo64 = m << r;                       // bits 0 .. 63 of m << r
+  const unsigned long long hi = r ? (m >> (64 - r)) : 0ull;     // bits 64 .. of m << r (< 2^21)
+  unsigned long long p0 = lo64 & 0xffffffffull, p1 = lo64 >> 32, p2 = hi;
+  if (j >= STPDE_DET_K || (p1 && j + 1 >= STPDE_DET_K) || (p2 && j + 2 >= STPDE_DET_K)) {
+    // too large for the windows (>= 2^70): poison the top window (-> NaN at read-out)
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + STPDE_DET_K - 1), 1ull << 62);
+    return;
+  }
+  if (neg) {
+    p0 = 0ull - p0;
+    p1 = 0ull - p1;
+    p2 = 0ull - p2;
+  }
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(acc) + j;
+  if (p0) atomicAdd(a, p0);
+  if (p1) atomicAdd(a + 1, p1);
+  if (p2) atomicAdd(a + 2, p2);
+}
+__device__ __forceinline__ void det_add_f32(long long* acc, float v) {
+  const unsigned b = __float_as_uint(v);
+  const int ex = (b >> 23) & 0xff;
+  if (ex == 0xff) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + STPDE_DET_K - 1), 1ull << 62);
+    return;
+  }
+  const unsigned long long m = ex ? ((b & 0x7fffffu) | 0x800000u) : (b & 0x7fffffu);
+  if (!m) return;
+  // value = m * 2^((ex ? ex : 1) - 150)
+  det_add_pieces(acc, m, (ex ? ex : 1) - 150 - STPDE_DET_BASE, (b >> 31) != 0);
+}
+__device__ __forceinline__ void det_add_f64(long long* acc, double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const int ex = (int)((b >> 52) & 0x7ff);
+  if (ex == 0x7ff) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + STPDE_DET_K - 1), 1ull << 62);
+    return;
+  }
+  const unsigned long long m = ex ? ((b & 0xfffffffffffffull) | 0x10000000000000ull) : (b & 0xfffffffffffffull);
+  if (!m) return;
+  det_add_pieces(acc, m, (ex ? ex : 1) - 1075 - STPDE_DET_BASE, (b >> 63) != 0);
+}
+// the sum as a double: the windows from the top down (each term exact or rounded the same way every time)
+__device__ __forceinline__ double det_value(const long long* acc) {
+  const long long top = acc[STPDE_DET_K - 1];
+  if (top >= (1ll << 61) || top <= -(1ll << 61)) return __longlong_as_double(0x7ff8000000000000ll);
+  double s = 0.;
+#pragma unroll
+  for (int j = STPDE_DET_K - 1; j >= 0; --j) s += ldexp((double)acc[j], STPDE_DET_BASE + 32 * j);
+  return s;
+}
+// one destination element of a sum the kernels accumulate with atomics: plain fp32 atomic, or -- det -- long accumulator
+__device__ __forceinline__ void acc_add_f32(float* dst, size_t idx, float v, int det) {
+  if (det)
+    det_add_f32(reinterpret_cast<long long*>(dst) + idx * STPDE_DET_K, v);
+  else
+    atomicAdd(dst + idx, v);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -603,12 +677,19 @@ __device__ __forceinline__ void load_cq(const float* cw, int point, float* cq) {
 // Host-side helpers (api.cpp)
 // mean / biased variance / rstd of one channel from the double-format BatchNorm sums ([STPDE_BN_REP][2][C]: sum x, sum x^2);
 // every consumer (k_bn_apply, the on-load transform of k_conv_fused) calls this one function, so all of them see the same bits
-__device__ __forceinline__ void bn_stat_f64(const double* sums, int C, int c, long N, float eps, float& mean, float& var,
+// (det: the same sums as ONE set of long accumulators [2][C][STPDE_DET_K], stpde_bn_desc.det)
+__device__ __forceinline__ void bn_stat_f64(const double* sums, int C, int c, long N, float eps, int det, float& mean, float& var,
                                             float& rstd) {
   double s1 = 0., s2 = 0.;
-  for (int r = 0; r < STPDE_BN_REP; ++r) {
-    s1 += sums[(size_t)(2 * r) * C + c];
-    s2 += sums[(size_t)(2 * r + 1) * C + c];
+  if (det) {
+    const long long* acc = reinterpret_cast<const long long*>(sums);
+    s1 = det_value(acc + (size_t)c * STPDE_DET_K);
+    s2 = det_value(acc + ((size_t)C + c) * STPDE_DET_K);
+  } else {
+    for (int r = 0; r < STPDE_BN_REP; ++r) {
+      s1 += sums[(size_t)(2 * r) * C + c];
+      s2 += sums[(size_t)(2 * r + 1) * C + c];
+    }
   }
   const double m = s1 / (double)N;
   double v = s2 / (double)N - m * m;

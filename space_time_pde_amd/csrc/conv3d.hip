@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       const int mt = mb * MCW + mi;
-      if (kk == 0 && mt < MT) atomicAdd(a.dbias + 16 * mt + i, v);
+      if (kk == 0 && mt < MT) acc_add_f32(a.dbias, 16 * mt + i, v, a.d.det);
     }
   }
   const int g = lane >> 4, c = lane & 15;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_conv3d_wgrad(ConvArgs a) {
         if (mt >= MT || kt >= KT) continue;          // block-uniform
         // wave w sums and adds register r == w of every lane's fragment
         const float sum = (red[0][lane * 4 + wv] + red[1][lane * 4 + wv]) + (red[2][lane * 4 + wv] + red[3][lane * 4 + wv]);
-        atomicAdd(a.dW + ((size_t)(tap0 + tg) * Co + 16 * mt + 4 * g + wv) * Ci + 16 * kt + c, sum);
+        acc_add_f32(a.dW, ((size_t)(tap0 + tg) * Co + 16 * mt + 4 * g + wv) * Ci + 16 * kt + c, sum, a.d.det);
       }
 }
 
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int k = 0; k < 512 / Co; ++k) sum += xs[threadIdx.x + Co * k];
-      atomicAdd(a.dbias + 16 * coh + threadIdx.x, sum);
+      acc_add_f32(a.dbias, 16 * coh + threadIdx.x, sum, a.d.det);
     }
   }
 #pragma unroll
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void k_conv3d_wgrad_lds(ConvArgs a) {
       for (int ci = 0; ci < CIT; ++ci)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          atomicAdd(a.dW + ((size_t)(tap0 + ti) * CoF + 16 * (coh + co) + 4 * g + rr) * Ci + 16 * ci + j, acc[ti][co][ci][rr]);
+          acc_add_f32(a.dW, ((size_t)(tap0 + ti) * CoF + 16 * (coh + co) + 4 * g + rr) * Ci + 16 * ci + j, acc[ti][co][ci][rr], a.d.det);
   }
 }
 
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512) void k_conv1_wgrad_lds(ConvArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int k = 0; k < 512 / Co; ++k) sum += red[threadIdx.x + Co * k];
-      atomicAdd(a.dbias + threadIdx.x, sum);
+      acc_add_f32(a.dbias, threadIdx.x, sum, a.d.det);
     }
   }
 #pragma unroll
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512) void k_conv1_wgrad_lds(ConvArgs a) {
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) sum += red[w * 256 + threadIdx.x];
-        atomicAdd(a.dW + ((size_t)(16 * co + 4 * (l >> 4) + rr)) * Ci + 16 * ci + (l & 15), sum);
+        acc_add_f32(a.dW, ((size_t)(16 * co + 4 * (l >> 4) + rr)) * Ci + 16 * ci + (l & 15), sum, a.d.det);
       }
     }
 }
@@ -637,7 +637,7 @@ extern "C" int stpde_conv3d_fwd(const stpde_conv3d_desc* d, const float* x, cons
     const int gy = gx >= 1024 ? 1 : nchunks;
     // 3x3x3 convs of the deep levels: too few (voxel tile, channel chunk) pairs to fill 256 CUs -> split the taps
     int gz = 1;
-    if (d->ksize == 3 && gx * gy < 256) {
+    if (d->ksize == 3 && gx * gy < 256 && !d->det) {      // (the tap split adds partial outputs with atomics: not in deterministic mode)
       gz = (256 + gx * gy - 1) / (gx * gy);
       if (gz > 27) gz = 27;
     }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_conv_fused(FusedArgs a) {
   if (ONLOAD) {
     for (int c = threadIdx.x; c < Ci; c += 256) {
       float mean, var, rstd;
-      bn_stat_f64(a.f.in_sums, Ci, c, N, a.f.in_eps, mean, var, rstd);
+      bn_stat_f64(a.f.in_sums, Ci, c, N, a.f.in_eps, a.f.d.det, mean, var, rstd);
       const float gm = a.f.in_gamma ? a.f.in_gamma[c] : 1.f, bt = a.f.in_beta ? a.f.in_beta[c] : 0.f;
       tab[c] = mean;
       tab[512 + c] = rstd * gm;
@@ -233,7 +233,16 @@ __global__ __launch_bounds__(256) void k_conv_fused(FusedArgs a) {
             t2 += red[((w * MC + mi) * 16 + c) * 2 + 1];
           }
           const int rep = blockIdx.x % STPDE_BN_REP;
-          if (EPI == 1) {
+          if (a.f.d.det) {      // order-independent long accumulators, one replica [2][Co][STPDE_DET_K] (common.h)
+            long long* acc = reinterpret_cast<long long*>(EPI == 1 ? (void*)a.f.out_sums : (void*)a.f.m_bsum);
+            if (EPI == 1) {
+              det_add_f64(acc + (size_t)(16 * mt + c) * STPDE_DET_K, t1);
+              det_add_f64(acc + ((size_t)Co + 16 * mt + c) * STPDE_DET_K, t2);
+            } else {
+              det_add_f32(acc + (size_t)(16 * mt + c) * STPDE_DET_K, (float)t1);
+              det_add_f32(acc + ((size_t)Co + 16 * mt + c) * STPDE_DET_K, (float)t2);
+            }
+          } else if (EPI == 1) {
             atomicAdd(a.f.out_sums + (size_t)(2 * rep) * Co + 16 * mt + c, t1);
             atomicAdd(a.f.out_sums + (size_t)(2 * rep + 1) * Co + 16 * mt + c, t2);
           } else {
@@ -513,7 +522,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3_lds(FusedArgs a) {
         t2 += red[(w * 16 + c) * 2 + 1];
       }
       const int rep = blockIdx.x % STPDE_BN_REP;
-      if (EPI == 1) {
+      if (a.f.d.det) {
+        long long* acc = reinterpret_cast<long long*>(EPI == 1 ? (void*)a.f.out_sums : (void*)a.f.m_bsum);
+        if (EPI == 1) {
+          det_add_f64(acc + (size_t)(16 * m + c) * STPDE_DET_K, t1);
+          det_add_f64(acc + ((size_t)C + 16 * m + c) * STPDE_DET_K, t2);
+        } else {
+          det_add_f32(acc + (size_t)(16 * m + c) * STPDE_DET_K, (float)t1);
+          det_add_f32(acc + ((size_t)C + 16 * m + c) * STPDE_DET_K, (float)t2);
+        }
+      } else if (EPI == 1) {
         atomicAdd(a.f.out_sums + (size_t)(2 * rep) * C + 16 * m + c, t1);
         atomicAdd(a.f.out_sums + (size_t)(2 * rep + 1) * C + 16 * m + c, t2);
       } else {
@@ -606,8 +624,8 @@ extern "C" int stpde_conv3d_fused(const stpde_conv3d_fused_args* f, int* epilogu
   } else {
     const int gx = (ntiles + 3) / 4;
     const int gy = gx >= 1024 ? 1 : nchunks;
-    if (d->ksize == 3 && gx * gy < 256) {
-      // deep levels: the tap-split kernel of conv3d.hip fills the chip; its output holds partial sums until the last atomic,
+    if (d->ksize == 3 && gx * gy < 256 && !d->det) {
+      // deep levels: the tap-split kernel of conv3d.hip fills the chip (not in deterministic mode: partial outputs by atomics); its output holds partial sums until the last atomic,
       // so the statistics take a pass of their own and a mask epilogue is left to the caller (stpde_bn_bwd)
       int rc = stpde_conv3d_fwd(d, f->x, f->w_pack, f->bias, f->y, stream);
       if (rc) return rc;

@@ -59,6 +59,7 @@ struct Fc1BwdArgs {
   float* dW;            // [256][16 * (32 + XT)] fp32, atomically accumulated
   float* pbar;          // swish: [STPDE_PBAR_SLOTS] (nullable)
   int ntiles;
+  int det;              // dW addresses long accumulators (stpde_layer_desc.det)
   stpde_jet_cfg cfg;
 };
 
@@ -80,7 +81,9 @@ struct Fc1BwdArgs {
     asm volatile("" ::: "memory");                         \
   } while (0)
 
-template <int S2, int ACT>
+// DET (compile time, not a run-time branch: with one the 256 accumulator registers of dW1h went to scratch -- 1040 bytes per
+// lane, configs[3] 145 -> 182 ms): the final sums go to long accumulators (deterministic mode, common.h) instead of fp32 atomics
+template <int S2, int ACT, bool DET = false>
 __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
   constexpr int S1 = 3, S = 1 + S1 + S2, MT = 32, KT = 16, KP = KT / 2, NQ = 4;
   constexpr int NCH = S * KT / 2;          // 1 KiB chunks of a packed adjoint tile (40 at S = 5)
@@ -369,18 +372,43 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
 
   const int g = lane >> 4, c = lane & 15;
   const int ldw = 16 * (MT + XT);
+  if constexpr (DET) {
+    // Deterministic mode: 1024 long-accumulator adds per lane.  Unrolled they are ~60k instructions -- the compiler gives up on
+    // the unroll, indexes dw dynamically and moves the whole accumulator array to scratch (every MFMA of the launch through
+    // scratch).  So: 16 blocks at a time through this wave's quarter of the (now idle) staging buffers, written with static
+    // register indices, read back by a ROLLED loop.
+    __syncthreads();
+    float* stg = &bst[0][0] + w * 4096;
+    long long* accb = reinterpret_cast<long long*>(a.dW);
 #pragma unroll
-  for (int m = 0; m < KT; ++m)
+    for (int m0 = 0; m0 < KT; m0 += 4) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+      for (int mm = 0; mm < 4; ++mm)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * m + 4 * g + r) * ldw + 16 * (kt0 + 4 * q) + c, dw[m][q][r]);
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(stg + ((mm * NQ + q) * 64 + lane) * 4) = dw[m0 + mm][q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int i = 0; i < 4 * NQ * 4; ++i) {
+        const int blk = i >> 2, r = i & 3, mm = blk / NQ, q = blk % NQ;
+        const float v = stg[(blk * 64 + lane) * 4 + r];
+        det_add_f32(accb + ((size_t)(16 * (m0 + mm) + 4 * g + r) * ldw + 16 * (kt0 + 4 * q) + c) * STPDE_DET_K, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * m + 4 * g + r) * ldw + 16 * (kt0 + 4 * q) + c, dw[m][q][r]);
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * (mx + mi) + 4 * g + r) * ldw + 16 * (MT + xt) + c, dwx[mi][xt][r]);
+      for (int r = 0; r < 4; ++r) acc_add_f32(a.dW, (size_t)(16 * (mx + mi) + 4 * g + r) * ldw + 16 * (MT + xt) + c, dwx[mi][xt][r], DET ? 1 : 0);
   if (ACT == STPDE_ACT_SWISH && a.pbar) {
     const float v = wave_sum(pacc);
     if (lane == 0) atomicAdd(a.pbar + (blockIdx.x % STPDE_PBAR_SLOTS), v);
@@ -395,7 +423,10 @@ static int launch_fused(const Fc1BwdArgs& a, hipStream_t stream) {
   int pairs = ncu / 2;
   if (pairs > a.ntiles) pairs = a.ntiles;
   if (pairs < 1) pairs = 1;
-  STPDE_LAUNCH((k_fc1_bwd_fused<S2, ACT>), dim3(2 * pairs), dim3(256), 0, stream, a);
+  if (a.det)
+    STPDE_LAUNCH((k_fc1_bwd_fused<S2, ACT, true>), dim3(2 * pairs), dim3(256), 0, stream, a);
+  else
+    STPDE_LAUNCH((k_fc1_bwd_fused<S2, ACT, false>), dim3(2 * pairs), dim3(256), 0, stream, a);
   return stpde_check_launch("k_fc1_bwd_fused");
 }
 
@@ -443,6 +474,7 @@ extern "C" int stpde_jet_fc1_bwd(const stpde_layer_desc* d, const float* abar1, 
   a.dW = dW_aug;
   a.pbar = act_param_bar;
   a.ntiles = d->ntiles;
+  a.det = d->det;
   a.cfg = d->cfg;
   int rc = d->cfg.S2 == 1 ? launch_fused_act<1>(a, (hipStream_t)stream) : launch_fused_act<0>(a, (hipStream_t)stream);
   if (rc) return rc;

@@ -34,6 +34,7 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
   a.cfg = d->cfg;
   a.bf16 = d->mfma_bf16;
   a.pk = d->packed & 5;      // 1: in_pre (Q) packed, 4: abar_out (P) packed
+  a.det = d->det;
   if (d->KT > 0 && !in_pre) {
     stpde_set_error("jet_wgrad: null in_pre");
     return STPDE_E_BADARG;
@@ -51,7 +52,7 @@ extern "C" int stpde_jet_wgrad(const stpde_layer_desc* d, int SP, const float* a
 
 // d W0[:, d] += sum over tiles of the row-reduced tangent-stream adjoints of layer 0 (written by the layer-1 dgrad
 // epilogue): [tile][MT][3][16] -> one column per d.  Grid-stride partial sums, one atomic per (block, element).
-__global__ __launch_bounds__(256) void k_tan0_reduce(const float* tan, float* dW, int ntiles, int MT, int ldw) {
+__global__ __launch_bounds__(256) void k_tan0_reduce(const float* tan, float* dW, int ntiles, int MT, int ldw, int det) {
   const int n = MT * 48;
   const int e = blockIdx.y * 256 + threadIdx.x;     // grid.y covers the n elements of a tile, grid.x strides the tiles
   if (e >= n) return;
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(256) void k_tan0_reduce(const float* tan, float* dW
   }
   for (; t < ntiles; t += G) s0 += tan[(size_t)t * n + e];
   const int mt = e / 48, d = (e % 48) / 16, f = e % 16;
-  atomicAdd(dW + (size_t)(16 * mt + f) * ldw + d, (s0 + s1) + (s2 + s3));
+  acc_add_f32(dW, (size_t)(16 * mt + f) * ldw + d, (s0 + s1) + (s2 + s3), det);
 }
 
-extern "C" int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, void* stream) {
+extern "C" int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan, float* dW_aug, int ldw, int det, void* stream) {
   if (ntiles <= 0 || MT <= 0 || !abar0_tan || !dW_aug || ldw < 3) {
     stpde_set_error("jet_tan0_reduce: bad argument");
     return STPDE_E_BADARG;
@@ -78,6 +79,6 @@ extern "C" int stpde_jet_tan0_reduce(int ntiles, int MT, const float* abar0_tan,
   const int gy = (MT * 48 + 255) / 256;
   int gx = 4096 / gy;                        // ~16 blocks per CU
   if (gx > ntiles) gx = ntiles;
-  STPDE_LAUNCH(k_tan0_reduce, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, abar0_tan, dW_aug, ntiles, MT, ldw);
+  STPDE_LAUNCH(k_tan0_reduce, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, abar0_tan, dW_aug, ntiles, MT, ldw, det);
   return stpde_check_launch("k_tan0_reduce");
 }

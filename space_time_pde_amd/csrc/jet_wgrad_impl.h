@@ -34,6 +34,7 @@ struct WgradArgs {
   int SP, KT, MT, ntiles;
   int gx, gy, gz;      // logical grid: tile splits (multiple of 8), m-groups, k-groups of 8 tiles
   int kz0;             // first k-group of this launch (hidden-only groups and raw-input groups are launched separately)
+  int det;             // dW addresses long accumulators (stpde_layer_desc.det, common.h: acc_add_f32)
   int bf16;            // != 0: contract with bf16-rounded operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation
   int pk;              // packed-buffer flags (common.h: ld_blk): 1 = Q (the layer input's pre-activations), 4 = P (abar_out)
   int xfold;           // fp32 hidden-group launches: the (k-group, k-slot) pairs 0 .. XT-1 also contract their abar blocks with
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
       if (kq >= KT + XT) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * kq + c, acc[mi][ki][r]);
+        acc_add_f32(a.dW, (size_t)(16 * mt + 4 * g + r) * ldw + 16 * kq + c, acc[mi][ki][r], a.det);
     }
   }
   if constexpr (XB || XS) {
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         if (mt >= MT) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r]);
+          acc_add_f32(a.dW, (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r], a.det);
       }
     }
   }
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
         if (mt >= MT) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r]);
+          acc_add_f32(a.dW, (size_t)(16 * mt + 4 * g + r) * ldw + 16 * (KT + xslot) + c, accx[mi][r], a.det);
         if constexpr (S1 == 3) {
           if (xslot == 0) {
             // column d of the raw-input block: sum over all rows of the tangent-stream adjoint d (lane (g, c) holds the rows
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
               float v = acct[d][mi];
               v += __shfl_xor(v, 16, 64);
               v += __shfl_xor(v, 32, 64);
-              if (g == 0) atomicAdd(a.dW + (size_t)(16 * mt + c) * ldw + 16 * KT + d, v);
+              if (g == 0) acc_add_f32(a.dW, (size_t)(16 * mt + c) * ldw + 16 * KT + d, v, a.det);
             }
           }
         }
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(256, (MCW * (KTT + XT) <= 8) ? 3 : ((MCW * (KTT + X
       const int mt = mt0 + mi;
       if (mt >= MT) continue;      // block-uniform
       const float sum = (red[lo + wv] + red[256 + lo + wv]) + (red[512 + lo + wv] + red[768 + lo + wv]);
-      atomicAdd(a.dW + (size_t)(16 * mt + 4 * g + wv) * ldw + 16 * ki + c, sum);
+      acc_add_f32(a.dW, (size_t)(16 * mt + 4 * g + wv) * ldw + 16 * ki + c, sum, a.det);
     }
   if constexpr (S1 == 3) {
     // tangent columns: lane (g, c) holds the partial row sums (rows 4g..4g+3 of every tile this wave walked) of output
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(256, (MCW * (KTT + XT) <= 8) ? 3 : ((MCW * (KTT + X
         float v = acct[d][mi];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (g == 0) atomicAdd(a.dW + (size_t)(16 * mt + c) * ldw + 16 * KTT + d, v);
+        if (g == 0) acc_add_f32(a.dW, (size_t)(16 * mt + c) * ldw + 16 * KTT + d, v, a.det);
       }
     }
   }
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
       if (k == KW && wv >= XT) continue;
       const int col = k < KW ? 16 * (KW * wv + k) : 16 * (KTT + wv);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r]);
+      for (int r = 0; r < 4; ++r) acc_add_f32(a.dW, (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r], a.det);
     }
   }
   if (S1 == 3 && wv >= XT) {
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_quad(Wgrad
         float v = acct[d][mi];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (g == 0) atomicAdd(a.dW + (size_t)(16 * mi + c) * ldw + 16 * KTT + d, v);
+        if (g == 0) acc_add_f32(a.dW, (size_t)(16 * mi + c) * ldw + 16 * KTT + d, v, a.det);
       }
   }
 }
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void k_wgrad_oct_bf(Wgr
       if (k == KW && wv >= XT) continue;
       const int col = k < KW ? 16 * (KW * wv + k) : 16 * (KTT + wv);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.dW + (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r]);
+      for (int r = 0; r < 4; ++r) acc_add_f32(a.dW, (size_t)(16 * mi + 4 * g + r) * ldw + col + c, acc[mi][k][r], a.det);
     }
   }
 }

@@ -169,6 +169,9 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   const stpde_jet_cfg& cfg = *cfg_mlp;
   const int S = 1 + cfg.S1 + cfg.S2, SP0 = 1 + cfg.S1;
   const bool wgrad = (flags & STPDE_F_WGRAD) && dW_flat;
+  // deterministic mode: dW_flat holds long accumulators (STPDE_F_DET; 2 * STPDE_DET_K floats of storage per element)
+  const int det = (flags & STPDE_F_DET) ? 1 : 0;
+  const long aw = det ? 2 * STPDE_DET_K : 1;
   const bool phaseA = flags & STPDE_F_PHASE_A, phaseB = flags & STPDE_F_PHASE_B;
   const bool dfirst = phaseA || phaseB;                 // dgrad-first order, two calls
   Seq seq;
@@ -207,9 +210,10 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     const void* w16 = p->mfma_bf16 ? p->WhT16[l] : nullptr;
     // same operand mode as the layer kernels; only the wide layers (MT >= 8) have bf16-pipe weight-gradient kernels
     stpde_layer_desc dwg = layer_desc(nt, p, l, cfg, (w16 && p->MT[l] >= 8 && (p->mfma_bf16 == 1 || !(flags & STPDE_F_WGRAD_FP32))) ? p->mfma_bf16 : 0);
+    dwg.det = det;
     dwg.packed = packed_flags(p, l, -1) & 5;
     seq([&] {
-      return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->X, p->tanc[0], dW_flat + p->dw_off[l], ws->cw,
+      return stpde_jet_wgrad(&dwg, S, abar[l], l > 1 ? ws->pre[l - 1] : z0, ws->X, p->tanc[0], dW_flat + aw * p->dw_off[l], ws->cw,
                              stream);
     });
   };
@@ -217,11 +221,12 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
     stpde_layer_desc d = layer_desc(nt, p, 0, cfg, is_packed(p, 0) ? 1 : 0);    // (bf16 mode: bf16 contraction over the rows)
     d.first_hidden = 0;
     d.packed = packed_flags(p, 0, -1) & 4;
-    float* dw0 = dW_flat + p->dw_off[0];
+    d.det = det;
+    float* dw0 = dW_flat + aw * p->dw_off[0];
     if (split0) {
       d.cfg = *cfg_val;       // value stream x raw input (the S = 1 weight-gradient kernels)
       seq([&] { return stpde_jet_wgrad(&d, 1, abar0, nullptr, ws->X, nullptr, dw0, nullptr, stream); });
-      seq([&] { return stpde_jet_tan0_reduce(nt, MT0, ws->tan0, dw0, 16 * STPDE_XT, stream); });
+      seq([&] { return stpde_jet_tan0_reduce(nt, MT0, ws->tan0, dw0, 16 * STPDE_XT, det, stream); });
     } else {
       seq([&] { return stpde_jet_wgrad(&d, SP0, abar0, nullptr, ws->X, nullptr, dw0, ws->cw, stream); });
     }
@@ -267,9 +272,10 @@ extern "C" int stpde_lig_imnet_jet_bwd(const stpde_imnet_plan* p, const stpde_je
   auto fc1_fused = [&] {
     stpde_layer_desc d = layer_desc(nt, p, 1, cfg, p->mfma_bf16);
     d.packed = packed_flags(p, 1, 0);
+    d.det = det;
     seq([&] {
       return stpde_jet_fc1_bwd(&d, abar[1], p->WhT16[1], z0, p->tanc[0], ws->cw, ws->X, abar0, ws->tan0,
-                               dW_flat + p->dw_off[1], act_param_bar, stream);
+                               dW_flat + aw * p->dw_off[1], act_param_bar, stream);
     });
   };
   auto dlatent_part = [&] {

