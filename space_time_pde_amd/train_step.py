@@ -255,7 +255,19 @@ class GraphedStep:
         def run():
             for p in self.params:
                 p.grad = None
-            return sharded_step(*args, distributed=False)
+            out = sharded_step(*args, distributed=False)
+            # the layer's forward method closes over this step's latent grid, i.e. over its whole autograd graph: dropped, or
+            # the graph -- and the parameters' AccumulateGrad nodes with it -- outlives the step
+            pde_layer.forward_method = None
+            return out
+
+        # Steps that ran BEFORE this constructor on the default stream leave exactly that behind (pde_layer.forward_method ->
+        # latent grid -> U-Net graph -> AccumulateGrad nodes bound to the default stream); the autograd engine would then make the
+        # capture stream wait on the default stream, which ends the capture in a crash inside hipStreamEndCapture (seen: bench.py
+        # after eager steps).  Drop that graph so that the warm-up below re-creates the nodes on its side stream.
+        import gc
+        pde_layer.forward_method = None
+        gc.collect()
 
         # lazy initialisation (kernel modules, function attributes, cached index tables, sympy lambdas) must not happen inside
         # the capture: a few eager steps on a side stream first (torch's recipe for whole-network capture)

@@ -303,6 +303,10 @@ def test_graphed_step_replays_the_eager_step(hiplib):
         return [float(loss), float(reg), float(pde)], [p.grad.clone() for p in params]
 
     a = draw()
+    # (an eager step on the default stream FIRST: it leaves pde_layer.forward_method -> latent grid -> the U-Net's autograd graph
+    # -> AccumulateGrad nodes bound to the default stream behind, which used to end the capture in a crash inside
+    # hipStreamEndCapture; GraphedStep drops that graph before its warm-up)
+    eager(*a)
     n0 = lig.stats["hip_jet_calls"]
     gstep = GraphedStep(unet, net, layer, *a, N, 1.0, 0.0125, "l1")
     assert lig.stats["hip_jet_calls"] > n0                       # the HIP jet path is what was captured
