@@ -339,3 +339,30 @@ def test_hazard_scanner_flags_a_store_whose_data_is_overwritten_at_once():
     ok = chk.scan_store_data("0000 <k>:\n\tbuffer_store_dwordx4 v[10:13], v238, s[8:11], s92 offen\n\tv_mov_b32_e32 v20, v204\n"
                              "\tv_mov_b32_e32 v21, v204\n\tv_mov_b32_e32 v10, v204\n")
     assert not ok
+
+
+def test_tune_overrides_and_no_environment_in_the_library(hiplib):
+    """Round 6: launch-geometry overrides for tests go through stpde_tune (process-wide, restored by the context manager); the
+    library itself reads no environment variable -- no getenv call in csrc/ -- and the Python package is
+    down to the ten documented switches."""
+    from space_time_pde_amd import _lib
+    assert _lib.tune("conv3_lds_gx", 7) == 0
+    with _lib.tuned(conv3_lds_gx=24, conv3_lds_minblk=1):
+        assert hiplib.stpde_tune(b"conv3_lds_gx", 24) == 24 and hiplib.stpde_tune(b"conv3_lds_minblk", 1) == 1
+    assert _lib.tune("conv3_lds_gx", 0) == 7 and _lib.tune("conv3_lds_minblk", 0) == 0
+    with pytest.raises(KeyError):
+        _lib.tune("no_such_key", 1)
+    csrc = os.path.join(ROOT, "space_time_pde_amd", "csrc")          # (the sort primitives of rocPRIM import getenv themselves)
+    calls = [(fn, n + 1) for fn in os.listdir(csrc) if fn.endswith((".hip", ".h", ".cpp"))
+             for n, ln in enumerate(open(os.path.join(csrc, fn))) if re.search(r"\bgetenv\s*\(", ln)]
+    assert not calls, calls
+    pkg = os.path.join(ROOT, "space_time_pde_amd")
+    found = set()
+    for fn in os.listdir(pkg) + ["../bench.py"]:
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            for m in re.finditer(r"environ[^\n]*?[\"'](STPDE_[A-Z0-9_]+)[\"']", src):
+                found.add(m.group(1))
+    assert found == {"STPDE_LIB", "STPDE_MLP_PRECISION", "STPDE_MEM_BUDGET_GB", "STPDE_DETERMINISTIC", "STPDE_S34", "STPDE_FC1_FUSED",
+                     "STPDE_FUSED_RESBLOCK", "STPDE_UNET_DEFERRED", "STPDE_OVERLAP_SYNC", "STPDE_BENCH_ONE_DEVICE",
+                     "STPDE_BENCH_BACKEND"}, sorted(found)
