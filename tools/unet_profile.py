@@ -14,6 +14,7 @@ from space_time_pde_amd import _lib, unet3d  # noqa: E402
 
 CONV_CALLS = ("stpde_conv3d_fwd", "stpde_conv3d_wgrad", "stpde_conv3d_wgrad_bias", "stpde_conv3d_wgrad_onload",
               "stpde_conv3d_fused")
+BN_CALLS = ("stpde_bn_fwd", "stpde_bn_bwd")
 
 
 class _Proxy:
@@ -27,6 +28,8 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
+        if name in BN_CALLS:
+            return self._bn(name, fn)
         if name not in CONV_CALLS:
             return fn
 
@@ -46,6 +49,34 @@ class _Proxy:
         return wrapped
 
 
+def _bn_method(self, name, fn):
+    """BatchNorm entry points: key carries the number of whole-tensor HBM passes the call makes (csrc/bn.hip), so that the
+    table can print a rate.  forward: statistics pass (unless the convolution's epilogue delivered them: stats_mode 2) reads x;
+    elementwise pass reads x (+ residual), writes y.  backward: reduction pass (unless reduce_done) reads dy, x (+ y under a
+    ReLU); elementwise pass reads dy, x (+ y), writes dx (+ d residual)."""
+    def wrapped(desc, *args):
+        d = C.cast(desc, C.POINTER(_lib.BnDesc)).contents
+        if name == "stpde_bn_fwd":
+            x, res = args[0], args[1]
+            passes = (1 if d.training and d.stats_mode != 2 else 0) + 2 + (1 if res else 0)
+        else:
+            x, y, dy, gamma, stat, bsum, dx, dres = args[:8]
+            rd = 2 + (1 if d.relu else 0)
+            passes = (0 if d.reduce_done else rd) + rd + (1 if dx else 0) + (1 if dres else 0)
+        key = (name[6:], d.N, d.C, passes, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(desc, *args)
+        e1.record()
+        self._bnrec.append((key, e0, e1))
+        return rc
+    return wrapped
+
+
+_Proxy._bn = _bn_method
+_Proxy._bnrec = []
+
+
 def main():
     igres = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 128, 128)
     dev = torch.device("cuda:0")
@@ -62,6 +93,7 @@ def main():
     for it in range(4):
         if it == 1:
             rec.clear()
+            del _Proxy._bnrec[:]
         for p in net.parameters():
             p.grad = None
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -89,6 +121,18 @@ def main():
                                                               flop / (ms / n * 1e-3) / 1e12))
         tot += ms / 3
     print("conv kernels total: %.2f ms/step (event-bracketed, includes launch gaps)" % tot)
+    agg = collections.OrderedDict()
+    for key, e0, e1 in _Proxy._bnrec:
+        a = agg.setdefault(key, [0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+    tot = 0.0
+    print("%-8s %9s %4s %6s %6s %9s %9s %7s" % ("bn call", "nvox", "C", "passes", "calls", "ms/step", "us/call", "TB/s"))
+    for (kind, nvox, c, passes, _), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%-8s %9d %4d %6d %6d %9.3f %9.1f %7.2f" % (kind, nvox, c, passes, n // 3, ms / 3, 1e3 * ms / n,
+                                                         4.0 * nvox * c * passes / (ms / n * 1e-3) / 1e12))
+        tot += ms / 3
+    print("batch-norm calls total: %.2f ms/step" % tot)
 
 
 if __name__ == "__main__":
