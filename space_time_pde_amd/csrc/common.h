@@ -143,6 +143,24 @@ __device__ __forceinline__ void opt_st4(__amdgpu_buffer_rsrc_t r, int byte_off, 
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
 }
 
+// Global memory -> LDS without registers (LDS-DMA): 16 (4) bytes per lane to the wave-uniform LDS address `lptr` + 16 (4) * lane.
+// Issued from an asm statement, NOT through __builtin_amdgcn_global_load_lds (round 6).  The compiler books the builtin as a
+// pending LDS write and puts `s_waitcnt vmcnt(0)` in front of the first LDS read it cannot prove disjoint from the target --
+// with double buffers picked by a run-time index that is every read of the OTHER buffer.  Found in the listings of both kernels
+// that stage row tiles this way: k_fc1_bwd_fused waited for the tile it had just requested "an iteration ahead" in front of its
+// first MFMA (phase stamps: 3,364 cycles for the first 80 input-gradient MFMAs, 1,676 for the second 80), k_fc2_fwd_bf waited
+// for the acknowledgements of the output stores it had just issued (they share the counter).  An asm statement is invisible to
+// that bookkeeping; the caller owns the counter waits that cover these requests (vector-memory results return in order:
+// `s_waitcnt vmcnt(n)` with n = the number of vector-memory instructions issued since).
+__device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lptr));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(la) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4(const void* gptr, void* lptr) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lptr));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(la) : "memory", "m0");
+}
+
 // Store a column-major ("D") fragment block held in registers (lane 16g+j: features 4g..4g+3 of row j) into the
 // row-major ("R") image of the same 16x16 block (lane 16g'+c: rows 4g'..4g'+3 of feature c): pure addressing.
 __device__ __forceinline__ void st_R(float* block, int lane, f32x4 v) {

@@ -70,9 +70,9 @@ struct Fc1BwdArgs {
 #ifndef STPDE_FC1F_VPM
 #define STPDE_FC1F_VPM 10    // vector instructions placed behind every MFMA of the mixed phases
 #endif
-#define FC1F_GLDS16(gptr, lptr)                                                                          \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// row tiles are staged by LDS-DMA through common.h's glds16 (an asm statement: the compiler's bookkeeping of the builtin put
+// vmcnt(0) in front of the first read of the OTHER staging buffer, i.e. right behind the request)
+#define FC1F_GLDS16(gptr, lptr) glds16((gptr), (lptr))
 // workgroup barrier without the compiler's vector-memory drain in front of it (LDS traffic of this wave complete)
 #define FC1F_BARRIER()                                     \
   do {                                                     \
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     const int buf = it & 1;
     const bool more = it + 1 < ntl;
     const int tnext = more ? tile + npairs : tile;
-    if (more && STPDE_FC1F_ABL != 6) stage(tnext, buf ^ 1);
+    // (the next row tile's request: see below, behind the second input-gradient phase)
     float* const cq = cqn;
 
     // Schedule of a row tile.  One wave per SIMD: nothing but this wave's own instruction stream hides a latency, so the matrix
@@ -286,6 +286,12 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     dgrad2(2);
     __builtin_amdgcn_sched_barrier(0);
     FSTAMP(3);
+    // The next row tile's adjoint goes to the other buffer from HERE (round 6; it used to be requested at the top of the
+    // iteration): vector-memory results return in order, so every load issued behind these ten requests waits for them too --
+    // and the input-gradient phases consume weight fragments a few hundred cycles after they ask for them.  From this point on
+    // the iteration issues stores and loads that are not needed before its last MFMAs (next tile's z0 blocks / weight ring,
+    // the raw-input fragments): ~8,000 cycles for an HBM round trip.
+    if (more && STPDE_FC1F_ABL != 6) stage(tnext, buf ^ 1);
     epi(2);
     __builtin_amdgcn_sched_barrier(0);
     epi(3);

@@ -294,10 +294,8 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
     __builtin_amdgcn_s_barrier();                          \
     asm volatile("" ::: "memory");                         \
   } while (0)
-// 16 bytes per lane from global memory straight into LDS (no registers, no wait at a use)
-#define STPDE_GLDS16(gptr, lptr)                                                                         \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// 16 bytes per lane from global memory straight into LDS (no registers, no wait at a use; common.h: glds16)
+#define STPDE_GLDS16(gptr, lptr) glds16((gptr), (lptr))
 
 template <int S1, int S2, int ACT>
 static int launch_fc1_fwd_spec(const LayerArgs& a, hipStream_t stream) {
@@ -363,15 +361,16 @@ __global__ __launch_bounds__(512, 1) void k_fc2_fwd_bf(LayerArgs a) {
     }
   };
   // requests of one row tile, all by LDS-DMA: its stash pieces (every wave), its raw-input tile (waves 0-2, one KiB each), its
-  // 16 combined-stream weights (wave 3, lanes 0-15, 4 bytes each).  The loop has NO ordinary global load, so the compiler
-  // places no vector-memory wait of its own; the raw-input / weight slots rotate through three buffers (a slot is rewritten
+  // 16 combined-stream weights (wave 3, lanes 0-15, 4 bytes each).  The loop has NO ordinary global load and the requests are
+  // invisible to the compiler (glds16: until round 6 it put a vmcnt(0) in front of the first read of raw[buf], which waited
+  // for the acknowledgements of the stores issued right above it), so the only vector-memory wait of a tile is the counted one
+  // below; the raw-input / weight slots rotate through three buffers (a slot is rewritten
   // two tiles after its last reader, with two barriers in between).
   auto request = [&](int tile, int buf, int b3) {
     stage(tile, buf);
     if (w < XT) STPDE_GLDS16(a.X + ((size_t)tile * XT + w) * 256 + lo, &xs[b3][w][0]);
     if (S2 == 1 && w == 3 && lane < 16)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.cw + (size_t)tile * 16 + lane),
-                                       (__attribute__((address_space(3))) void*)(&cqs[b3][0]), 4, 0, 0);
+      glds4(a.cw + (size_t)tile * 16 + lane, &cqs[b3][0]);
   };
   request(blockIdx.x, 0, 0);
   if (ntl > 1) request(blockIdx.x + gridDim.x, 1, 1);

@@ -426,6 +426,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     }
   }
   __syncthreads();
+  // Round 6: every load of the prologue is waited for HERE, with a counter wait the compiler's own wait insertion sees.  The
+  // raw-input fragment `xr` loaded above is first used at the head of the loop below, behind the loop's early loads of the next
+  // tile's adjoint blocks -- and those sit in `st < SP` branches, so the number of loads issued after xr's is path-dependent
+  // and the only statically safe wait in front of xr's use is "all but the last one": the listing had `s_waitcnt vmcnt(1)`
+  // right behind the ten 16-byte loads that were meant to land during the MFMAs, i.e. every wave sat through an HBM round trip
+  // per row tile in front of its matrix phase (since round 4).  Exact fp32 23.56 -> 22.68 ms per 2^18 points, the plain bf16 variant
+  // 7.07 -> 6.22 ms.  (Tried with it and dropped: the adjoint fragments loaded already transposed -- four dword loads per block
+  // instead of the LDS round trip, 23.43 ms -- and the next tile's z0 blocks requested before the MFMAs as well, 23.7-24.3 ms.)
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
   int buf = 0;
   // Phase swap (round 4, plain bf16 mode, hidden k-groups): the two waves of a SIMD meet at one barrier per row tile, and in
   // the loop below both run the same phases at the same time -- ring reads + bf16 MFMAs (the vector ALU idle), then the

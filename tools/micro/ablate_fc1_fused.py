@@ -16,6 +16,8 @@ CSRC = os.path.join(ROOT, "space_time_pde_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "micro", "_abl")
 VARIANTS = {0: "full kernel", 1: "no activation jets", 2: "no weight-gradient MFMAs", 3: "no input-gradient MFMAs",
             7: "full kernel with phase stamps"}
+if os.environ.get("FC1F_VARIANTS"):      # subset, e.g. FC1F_VARIANTS=0,7
+    VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["FC1F_VARIANTS"].split(",")}
 TAG = os.environ.get("FC1F_TAG", "")      # private builds with other compiler flags live side by side (FC1F_TAG=name)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 

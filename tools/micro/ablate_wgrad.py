@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "space_time_pde_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "micro", "_abl")
-VARIANTS = [0, 1, 2, 3, 4, 5]
+VARIANTS = [int(v) for v in os.environ.get("ABLW_VARIANTS", "0,1,2,3,4,5").split(",")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 
@@ -23,7 +23,7 @@ def build():
     stub = os.path.join(OUT, "stubw.cpp")
     open(stub, "w").write('#include <hip/hip_runtime.h>\nstruct WgradArgs;\n' + "".join(
         "int stpde_wgrad_launch_%s(const WgradArgs&, int, hipStream_t) { return 2; }\n" % k
-        for k in ("0_0", "3_0", "3_2", "3_6")))
+        for k in ("0_0", "3_0", "3_2", "3_4", "3_6")))
     for n in VARIANTS:
         so = os.path.join(OUT, "libablw_%d.so" % n)
         srcs = [os.path.join(CSRC, f) for f in ("jet_wgrad.hip", "jet_wgrad_s31.hip", "api.cpp")]
