@@ -533,6 +533,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     // per step; with fp32 operands the early loads cost 1.5 %, so the fp32 kernels keep them behind the MFMAs)
     constexpr bool EARLYQ = BF && SPL == 1;     // (three-term split mode: 77.9 -> 93.2 ms with the early loads)
     if (EARLYQ && NBUF == 2 && STPDE_ABLATE_W != 3) load_q(nx, preq, cqq);
+    // exact fp32, first hidden layer (round 6): only the z0 block -- the one load of the produce stage that comes from HBM --
+    // before the MFMAs: 22.78 -> 22.45 ms per 2^18 points.  (All of load_q there: slower, 23.7 ms.  And without the
+    // sched_barrier behind the MFMA loop the compiler hoisted the jets' first compares on z0 INTO the loop -- with a vmcnt(1)
+    // behind the twelve early loads in front of them: 23.5 ms.)
+    constexpr bool EARLYZ = !BF && MODE == 1 && !HASX && NBUF == 2;
+    f32x4 z0e = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EARLYZ) z0e = ld4(a.Q + ((size_t)nx * KT + kq0 + wv) * 256 + lo);
     f32x4 xrn = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (XB) {
       xrn = ld4(a.X + ((size_t)nx * XT + xsel) * 256 + lo);
@@ -682,7 +689,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_coop(WgradArgs a) {
     if constexpr (XF || XB || XS) xr = xrn;
     if (NBUF == 2) {
       if (STPDE_ABLATE_W != 3) {
+        if constexpr (EARLYZ) __builtin_amdgcn_sched_barrier(0);   // (the jets' first compares were hoisted into the MFMA loop: vmcnt(1) behind the early loads)
         if (!EARLYQ) load_q(nx, preq, cqq);
+        if constexpr (EARLYZ) preq[0] = z0e;
         finish_q(preq, cqq, buf ^ 1);
       }
       if (!EARLYP) load_p_raw(nx, raw);
