@@ -341,6 +341,51 @@ def test_hazard_scanner_flags_a_store_whose_data_is_overwritten_at_once():
     assert not ok
 
 
+def test_early_loads_are_not_waited_for_in_front_of_the_matrix_phase():
+    """Round 6, found in the listings: three kernels requested the next row tile's operands ahead of their matrix phase and the
+    compiler's (conservative, correct) counter waits made them wait for those loads at once -- k_wgrad_coop `s_waitcnt vmcnt(1)`
+    behind its ten early loads (a prologue-loaded register used at the loop head, the early loads in run-time branches),
+    k_fc1_bwd_fused / k_fc2_fwd_bf `vmcnt(0)` in front of the first LDS read after an LDS-DMA request the compiler could not prove
+    disjoint.  The scan of tools/micro/isa_near_waits.py over those kernels' loops must stay clean: a compiler that
+    decides differently would bring the stall back without failing any numerical test."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tools", "micro"))
+    import check_dpp_hazard
+    import isa_near_waits as nw
+    # the scanner itself: ten loads, then "all but one", then a matrix phase, inside a loop
+    body = [(4 * i, "global_load_dwordx4 v[%d:%d], v[0:1], off" % (8 + 4 * i, 11 + 4 * i)) for i in range(10)]
+    body += [(40, "s_waitcnt vmcnt(1)")] + [(44 + 4 * i, "v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]") for i in range(12)]
+    body += [(92, "s_cbranch_scc1 65512")]          # back to address 0
+    assert len(nw.scan(body)) == 1
+    body[10] = (40, "s_waitcnt vmcnt(10)")
+    assert not nw.scan(body)
+    want = {"jet_wgrad_s31.hip.o": ["_Z12k_wgrad_coopILi3ELi1ELi1ELi2ELi8ELb0ELb0ELi1ELi0E", "_Z12k_wgrad_coopILi3ELi1ELi1ELi2ELi8ELb0ELb1ELi1E"],
+            "jet_fc1_bwd.hip.o": ["_Z15k_fc1_bwd_fusedILi1ELi2ELb0E", "_Z15k_fc1_bwd_fusedILi1ELi2ELb1E"],
+            "jet_layer_s31.hip.o": ["_Z12k_fc2_fwd_bfILi3ELi1ELi2E"]}
+    if not all(os.path.exists(os.path.join(check_dpp_hazard.BUILD, o)) for o in want):
+        pytest.skip("no object files next to the library (a tree that received only the built .so)")
+    import tempfile
+    with tempfile.TemporaryDirectory() as scratch:
+        for obj, needles in want.items():
+            text = check_dpp_hazard.disassemble(os.path.join(check_dpp_hazard.BUILD, obj), scratch)
+            seen = set()
+            for name, kbody in nw.kernels(text):
+                for nd in needles:
+                    if name.startswith(nd):
+                        seen.add(nd)
+                        # "all but at most two" right behind five or more requests, a matrix phase behind it
+                        hits = [h for h in nw.scan(kbody) if h[1] <= 2 and h[2] >= 5 and h[3] >= 20]
+                        assert not hits, (name, [(hex(a), n, l, m) for a, n, l, m in hits])
+                        if "k_fc2_fwd_bf" in nd:
+                            # (its guarded read sat behind the previous tile's output stores and in front of the activation
+                            # jets, not of MFMAs: no full drain of the counter within 30 instructions behind a store)
+                            ins = [i for _, i in kbody]
+                            drains = [k for k, i in enumerate(ins) if re.match(r"s_waitcnt.*vmcnt\(0\)", i)
+                                      and any(j.startswith("global_store") for j in ins[max(0, k - 30):k])]
+                            assert not drains, (name, drains)
+            assert seen == set(needles), (obj, sorted(set(needles) - seen))
+
+
 def test_tune_overrides_and_no_environment_in_the_library(hiplib):
     """Round 6: launch-geometry overrides for tests go through stpde_tune (process-wide, restored by the context manager); the
     library itself reads no environment variable -- no getenv call in csrc/ -- and the Python package is
