@@ -682,13 +682,42 @@ void stpde_trace_note(const char* launcher, const char* kernel);
 template <int S2>
 __device__ __forceinline__ void load_cq(const float* cw, int point, float* cq) {
   if (S2 == 1) {
-    const f32x4 v0 = ld4(cw + (size_t)point * 8), v1 = ld4(cw + (size_t)point * 8 + 4);
+    // (16 + 8 bytes: where the second load stayed a 16-byte one, the allocator re-used its two dead result registers at once
+    // and had to wait for the load in front of that write -- `s_waitcnt vmcnt(0)` right behind a prefetch, k_fc1_fwd_spec)
+    const f32x4 v0 = ld4(cw + (size_t)point * 8);
+    const float2 v1 = *reinterpret_cast<const float2*>(cw + (size_t)point * 8 + 4);
     cq[0] = v0[0];
     cq[1] = v0[1];
     cq[2] = v0[2];
     cq[3] = v0[3];
-    cq[4] = v1[0];
-    cq[5] = v1[1];
+    cq[4] = v1.x;
+    cq[5] = v1.y;
+  }
+}
+
+// The same weights requested a row tile AHEAD of their use: the two loads' results stay whole vectors until unpack_cq() where
+// they are used.  (As six loop-carried floats the allocator copied single elements into other registers right behind the
+// loads -- `s_waitcnt vmcnt(1) ; v_mov_b32` in the listing of k_fc1_fwd_spec: the prefetch was waited for at once, round 6.)
+struct CqRaw {
+  f32x4 a;
+  float2 b;
+};
+template <int S2>
+__device__ __forceinline__ void load_cq_raw(const float* cw, int point, CqRaw& r) {
+  if (S2 == 1) {
+    r.a = ld4(cw + (size_t)point * 8);
+    r.b = *reinterpret_cast<const float2*>(cw + (size_t)point * 8 + 4);
+  }
+}
+template <int S2>
+__device__ __forceinline__ void unpack_cq(const CqRaw& r, float* cq) {
+  if (S2 == 1) {
+    cq[0] = r.a[0];
+    cq[1] = r.a[1];
+    cq[2] = r.a[2];
+    cq[3] = r.a[3];
+    cq[4] = r.b.x;
+    cq[5] = r.b.y;
   }
 }
 

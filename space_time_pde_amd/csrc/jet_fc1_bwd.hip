@@ -164,11 +164,12 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     }
   };
   f32x4 z0n[NQ];
-  float cqn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  CqRaw cqn{};         // combination weights of the NEXT row tile as loaded (common.h: unpacked where the tile starts)
+  float cq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int tile) {               // z0 blocks and combination weights of row tile `tile`
 #pragma unroll
     for (int q = 0; q < NQ; ++q) z0n[q] = ld4(a.Z0 + ((size_t)tile * MT + kt0 + 4 * q) * 256 + lo);
-    load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cqn);
+    load_cq_raw<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cqn);
   };
   if (ntl > 0) {
     stage(pair, 0);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void k_fc1_bwd_fused(Fc1BwdArgs a) {
     const bool more = it + 1 < ntl;
     const int tnext = more ? tile + npairs : tile;
     // (the next row tile's request: see below, behind the second input-gradient phase)
-    float* const cq = cqn;
+    unpack_cq<S2>(cqn, cq);
 
     // Schedule of a row tile.  One wave per SIMD: nothing but this wave's own instruction stream hides a latency, so the matrix
     // phases request every LDS operand one step ahead of its MFMAs and a step carries enough MFMAs (20 / 12 x 17 cycles) to

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
     // =========================================== producers ===========================================
     f32x4 w0r[NST][2][XT];
     f32x4 xb[XT], xn[XT];
-    float cq[6], cqn[6];
+    float cq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    CqRaw cqn{};
 #pragma unroll
     for (int g = 0; g < NST; ++g)
 #pragma unroll
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
     if (ntl > 0) {
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)blockIdx.x * XT + xt) * 256 + lo);
-      load_cq<S2>(a.cw, blockIdx.x * 2 + ((lane & 15) >> 3), cqn);
+      load_cq_raw<S2>(a.cw, blockIdx.x * 2 + ((lane & 15) >> 3), cqn);
     }
     auto produce = [&](auto gc, int tile) {
       constexpr int g = decltype(gc)::value;
@@ -115,8 +116,7 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
       if (it < ntl) {
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt) xb[xt] = xn[xt];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cq[i] = cqn[i];
+        unpack_cq<S2>(cqn, cq);
         SPEC_STAMP(it, 0);
         produce(std::integral_constant<int, 0>{}, tile);
       }
@@ -126,10 +126,15 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
       if (it == ntl) break;
       auto step = [&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        if (g == NST - 1 && it + 1 < ntl) {           // prefetch the next tile's raw input (HBM latency behind this step)
+        if (g == NST - 1) {           // prefetch the next tile's raw input (HBM latency behind this step)
+          // Branch-free (round 6; the last tile re-reads itself): under `it + 1 < ntl` the number of loads issued here was
+          // path-dependent, so every counter wait behind them -- the write-after-read waits on the z0 store data inside
+          // produce() -- had to assume the path WITHOUT them: the listing had vmcnt(4) right behind the five requests, i.e. the
+          // step that was to hide their HBM round trip waited for it.
+          const int tn = it + 1 < ntl ? tile + G : tile;
 #pragma unroll
-          for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)(tile + G) * XT + xt) * 256 + lo);
-          load_cq<S2>(a.cw, (tile + G) * 2 + ((lane & 15) >> 3), cqn);
+          for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)tn * XT + xt) * 256 + lo);
+          load_cq_raw<S2>(a.cw, tn * 2 + ((lane & 15) >> 3), cqn);
         }
         produce(gc, tile);
         SPEC_STAMP(it, 1 + 2 * g);
