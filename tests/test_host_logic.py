@@ -361,7 +361,7 @@ def test_early_loads_are_not_waited_for_in_front_of_the_matrix_phase():
     assert not nw.scan(body)
     want = {"jet_wgrad_s31.hip.o": ["_Z12k_wgrad_coopILi3ELi1ELi1ELi2ELi8ELb0ELb0ELi1ELi0E", "_Z12k_wgrad_coopILi3ELi1ELi1ELi2ELi8ELb0ELb1ELi1E"],
             "jet_fc1_bwd.hip.o": ["_Z15k_fc1_bwd_fusedILi1ELi2ELb0E", "_Z15k_fc1_bwd_fusedILi1ELi2ELb1E"],
-            "jet_layer_s31.hip.o": ["_Z12k_fc2_fwd_bfILi3ELi1ELi2E"]}
+            "jet_layer_s31.hip.o": ["_Z12k_fc2_fwd_bfILi3ELi1ELi2E", "_Z14k_fc1_fwd_specILi3ELi1ELi2ELi4E"]}
     if not all(os.path.exists(os.path.join(check_dpp_hazard.BUILD, o)) for o in want):
         pytest.skip("no object files next to the library (a tree that received only the built .so)")
     import tempfile
@@ -376,6 +376,11 @@ def test_early_loads_are_not_waited_for_in_front_of_the_matrix_phase():
                         # "all but at most two" right behind five or more requests, a matrix phase behind it
                         hits = [h for h in nw.scan(kbody) if h[1] <= 2 and h[2] >= 5 and h[3] >= 20]
                         assert not hits, (name, [(hex(a), n, l, m) for a, n, l, m in hits])
+                        if "k_fc1_fwd_spec" in nd:
+                            # (its producers' prefetch of the next tile -- five requests -- sat in front of the layer-0 MFMAs of
+                            # the step with `vmcnt(4)` behind it)
+                            hits = [h for h in nw.scan(kbody) if h[2] >= 5 and h[1] < 5 and h[3] >= 8]
+                            assert not hits, (name, [(hex(a), n, l, m) for a, n, l, m in hits])
                         if "k_fc2_fwd_bf" in nd:
                             # (its guarded read sat behind the previous tile's output stores and in front of the activation
                             # jets, not of MFMAs: no full drain of the counter within 30 instructions behind a store)
