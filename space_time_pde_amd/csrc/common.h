@@ -13,6 +13,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // = 36 features is exactly what the reference's 32 latent channels need; wider latents take the generic path).
 __host__ __device__ constexpr int x_live(int xt) { return xt == XT - 1 ? 1 : 4; }
 
+// Fragment of tile xt (compile time) of an augmented-input operand -- the raw-input image X or a weight pack against it: the
+// sparse last tile is loaded as the ONE dword that is used (round 6).  As a 16-byte load its three dead result registers were
+// handed out again at once -- to the address of the next load, to the next load's own result -- and every such write has to
+// wait for the load: `global_load_dwordx4 v[24:27] ; s_waitcnt vmcnt(0) ; v_lshl_add_u64 v[26:27] ; global_load_dwordx4
+// v[26:29]` in the listing of k_layer_coop's layer-0 prefetch, i.e. serialised L2 round trips inside a burst of loads that was
+// written to be in flight together.
+__device__ __forceinline__ f32x4 ld4x(const float* p, int xt) {
+  if (xt == XT - 1) return f32x4{p[0], 0.f, 0.f, 0.f};
+  return *reinterpret_cast<const f32x4*>(p);
+}
+
 // One v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[l&15][l>>4], B[l>>4][l&15],
 // D rows 4*(l>>4)+r (r = register), column l&15.  Exact fp32 (k-ordered fma chain).
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -131,6 +142,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t load_rsrc(const void* base, un
 }
 __device__ __forceinline__ u32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, lane_byte_off, uniform_byte_off, 0);
+}
+__device__ __forceinline__ float buf_ld4(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_byte_off, uniform_byte_off, 0));
 }
 __device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_byte_off, uniform_byte_off, 0);

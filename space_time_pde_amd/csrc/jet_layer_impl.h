@@ -114,7 +114,7 @@ __device__ __forceinline__ f32x4 layer0_block(const float* W0s, int nblk, int bl
   f32x4 part[XT];
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
-    f32x4 w = ld4(W0s + ((size_t)xt * nblk + blk) * 256 + lo);
+    f32x4 w = ld4x(W0s + ((size_t)xt * nblk + blk) * 256 + lo, xt);
     f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < x_live(xt); ++r) c = mfma4(w[r], xb[xt][r], c);
@@ -141,7 +141,7 @@ __device__ __forceinline__ void layer_epilogue(const LayerArgs& a, int tile, int
     if (EPI == EPI_FWD) {
 #pragma unroll
       for (int xt = 0; xt < XT; ++xt) {
-        f32x4 w = wspf ? wspf[xt] : ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
+        f32x4 w = wspf ? wspf[xt] : ld4x(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo, xt);
 #pragma unroll
         for (int sv = 0; sv < (VT ? S : 1); ++sv)
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_layer(LayerArgs a) {
 #pragma unroll
     for (int sv = 0; sv < NX; ++sv)
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
+      for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4x(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo, xt);
   }
   const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
 #pragma unroll
     for (int sv = 0; sv < NX; ++sv)
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
+      for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4x(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo, xt);
   }
   const auto z0r = opt_store_rsrc(a.Z0 ? a.Z0 + (size_t)tile * KT * 256 : nullptr, (unsigned)KT * 1024u);
 
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
         for (int k = 0; k < PK; ++k) {
           const int kt = GK * gnext + NW * k + wv;
 #pragma unroll
-          for (int xt = 0; xt < XT; ++xt) w0n[k][xt] = ld4(a.W0s + ((size_t)xt * KT + kt) * 256 + lo);
+          for (int xt = 0; xt < XT; ++xt) w0n[k][xt] = ld4x(a.W0s + ((size_t)xt * KT + kt) * 256 + lo, xt);
           if (S1 == 3) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) tcn[k][d] = ld4(a.tanc0 + ((size_t)d * KT + kt) * 256 + lo);
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64 * NW, ((!BF || SPL == 1) && PRO == PRO_ACT && EP
       f32x4 wsc[XT], tcc[3], wsn[XT], tcn2[3];
       auto fetch = [&](int mt, f32x4* w, f32x4* t) {
 #pragma unroll
-        for (int xt = 0; xt < XT; ++xt) w[xt] = ld4(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo);
+        for (int xt = 0; xt < XT; ++xt) w[xt] = ld4x(a.Wsp + ((size_t)xt * MT + mt) * 256 + lo, xt);
 #pragma unroll
         for (int d = 0; d < 3; ++d) t[d] = ld4(a.tanc + ((size_t)d * MT + mt) * 256 + lo);
       };

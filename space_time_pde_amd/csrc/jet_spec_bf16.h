@@ -75,10 +75,10 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int xt = 0; xt < XT; ++xt) w0r[g][k][xt] = ld4(a.W0s + ((size_t)xt * KT + GK * g + 4 * k + w) * 256 + lo);
+        for (int xt = 0; xt < XT; ++xt) w0r[g][k][xt] = ld4x(a.W0s + ((size_t)xt * KT + GK * g + 4 * k + w) * 256 + lo, xt);
     if (ntl > 0) {
 #pragma unroll
-      for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)blockIdx.x * XT + xt) * 256 + lo);
+      for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4x(a.X + ((size_t)blockIdx.x * XT + xt) * 256 + lo, xt);
       load_cq_raw<S2>(a.cw, blockIdx.x * 2 + ((lane & 15) >> 3), cqn);
     }
     auto produce = [&](auto gc, int tile) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
           // step that was to hide their HBM round trip waited for it.
           const int tn = it + 1 < ntl ? tile + G : tile;
 #pragma unroll
-          for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4(a.X + ((size_t)tn * XT + xt) * 256 + lo);
+          for (int xt = 0; xt < XT; ++xt) xn[xt] = ld4x(a.X + ((size_t)tn * XT + xt) * 256 + lo, xt);
           load_cq_raw<S2>(a.cw, tn * 2 + ((lane & 15) >> 3), cqn);
         }
         produce(gc, tile);
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
       for (int p = 0; p < PER; ++p) {
         const int mi = slot * PER + p;
 #pragma unroll
-        for (int xt = 0; xt < XT; ++xt) sk[p][xt] = __builtin_bit_cast(f32x4, buf_ld16(srs, wlane, (xt * MT + mt0 + mi) * 1024));
+        for (int xt = 0; xt < XT; ++xt)
+          sk[p][xt] = xt == XT - 1 ? f32x4{buf_ld4(srs, wlane, (xt * MT + mt0 + mi) * 1024), 0.f, 0.f, 0.f}      // (sparse tile: common.h ld4x)
+                               : __builtin_bit_cast(f32x4, buf_ld16(srs, wlane, (xt * MT + mt0 + mi) * 1024));
         if (S1 == 3) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) sk[p][XT + d] = __builtin_bit_cast(f32x4, buf_ld16(trs, wlane, (d * MT + mt0 + mi) * 1024));
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void k_fc1_fwd_spec(LayerArgs a) {
 #pragma unroll
             for (int st = 0; st < S; ++st) acc[mi][st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int xt = 0; xt < XT; ++xt) xb[0][xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);   // for the epilogue
+          for (int xt = 0; xt < XT; ++xt) xb[0][xt] = ld4x(a.X + ((size_t)tile * XT + xt) * 256 + lo, xt);   // for the epilogue
         }
         skip_load(g - 1);
         consume(std::integral_constant<int, g - 1>{});
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void k_fc2_fwd_bf(LayerArgs a) {
   for (int q = 0; q < KP; ++q) wk[q] = reinterpret_cast<const bf16x8*>(a.Wp16)[((size_t)q * MT + w) * 64 + lane];
   f32x4 wsk[XT], tck[3];
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) wsk[xt] = ld4(a.Wsp + ((size_t)xt * MT + w) * 256 + lo);
+  for (int xt = 0; xt < XT; ++xt) wsk[xt] = ld4x(a.Wsp + ((size_t)xt * MT + w) * 256 + lo, xt);
 #pragma unroll
   for (int d = 0; d < 3; ++d) tck[d] = S1 == 3 ? ld4(a.tanc + ((size_t)d * MT + w) * 256 + lo) : f32x4{0.f, 0.f, 0.f, 0.f};
   auto stage = [&](int tile, int buf) {

@@ -40,13 +40,13 @@ __global__ __launch_bounds__(256) void k_tail_fwd(TailArgs a) {
 #pragma unroll
   for (int sv = 0; sv < NX; ++sv)
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo);
+    for (int xt = 0; xt < XT; ++xt) xb[sv][xt] = ld4x(a.X + (((size_t)tile * NX + sv) * XT + xt) * 256 + lo, xt);
 
   // epilogue of one layer: skip GEMM with the raw input (bias through its ones column), tangent constants, store
   auto finish = [&](int l, int MT, int mt, f32x4* acc) {
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
-      const f32x4 w = ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
+      const f32x4 w = ld4x(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo, xt);
 #pragma unroll
       for (int sv = 0; sv < NX; ++sv)
 #pragma unroll
@@ -199,13 +199,13 @@ __global__ __launch_bounds__(LDSW ? 512 : 256, LDSW ? 1 : 2) void k_tail_fwd_bf(
   load_cq<S2>(a.cw, tile * 2 + ((lane & 15) >> 3), cq);
   f32x4 xb[XT];
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4(a.X + ((size_t)tile * XT + xt) * 256 + lo);
+  for (int xt = 0; xt < XT; ++xt) xb[xt] = ld4x(a.X + ((size_t)tile * XT + xt) * 256 + lo, xt);
 
   // epilogue of one layer: skip GEMM (fp32), tangent constants, store (packed: derivative streams rounded in place)
   auto finish = [&](int l, int MT, int mt, f32x4* acc, bool pk) {
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
-      const f32x4 w = LDSW ? ld4(sm + OWS[l] + (xt * MT + mt) * 256 + lo) : ld4(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo);
+      const f32x4 w = LDSW ? ld4(sm + OWS[l] + (xt * MT + mt) * 256 + lo) : ld4x(a.Ws[l] + ((size_t)xt * MT + mt) * 256 + lo, xt);
 #pragma unroll
       for (int r = 0; r < x_live(xt); ++r) acc[0] = mfma4(w[r], xb[xt][r], acc[0]);
     }
